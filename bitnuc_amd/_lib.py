@@ -1,0 +1,72 @@
+"""ctypes binding of libbitnuc_hip.so (the C ABI in include/bitnuc_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises
+at import of the symbol table, and every compute call on a machine without a HIP
+device returns BITNUC_BACKEND_ERROR, surfaced as `BackendError`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbitnuc_hip.so")
+
+# bitnuc_status (include/bitnuc_hip.h) == NucleotideError (src/error.rs:3-18)
+OK, INVALID_BASE, SEQUENCE_TOO_LONG, INVALID_LENGTH = 0, 1, 2, 3
+INDEX_OUT_OF_BOUNDS, INVALID_RANGE, UNSUPPORTED, BACKEND_ERROR = 4, 5, 6, 100
+
+
+class BitnucErr(C.Structure):
+    _fields_ = [("status", C.c_int32), ("backend_code", C.c_int32), ("value", C.c_uint64),
+                ("index", C.c_uint64), ("byte", C.c_uint8), ("_pad", C.c_uint8 * 7)]
+
+
+_P = C.c_void_p
+_SZ = C.c_size_t
+_U64 = C.c_uint64
+_ERR = C.POINTER(BitnucErr)
+
+# name -> (restype, argtypes); every symbol include/bitnuc_hip.h declares
+SIGNATURES = {
+    "bitnuc_version": (C.c_char_p, []),
+    "bitnuc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P), _ERR]),
+    "bitnuc_ctx_create_on_stream": (C.c_int, [C.c_int, _P, C.POINTER(_P), _ERR]),
+    "bitnuc_ctx_destroy": (None, [_P]),
+    "bitnuc_ctx_sync": (C.c_int, [_P, _ERR]),
+    "bitnuc_ctx_stream": (_P, [_P]),
+    "bitnuc_ctx_set_variant": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "bitnuc_as_2bit": (C.c_int, [_P, _P, _SZ, C.POINTER(_U64), _ERR]),
+    "bitnuc_from_2bit": (C.c_int, [_P, _U64, _SZ, _P, _ERR]),
+    "bitnuc_hdist_scalar": (C.c_int, [_P, _U64, _U64, _SZ, C.POINTER(C.c_uint32), _ERR]),
+    "bitnuc_encode": (C.c_int, [_P, _P, _SZ, _P, C.POINTER(_SZ), _ERR]),
+    "bitnuc_decode": (C.c_int, [_P, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_hdist": (C.c_int, [_P, _P, _SZ, _P, _SZ, _SZ, C.POINTER(C.c_uint32), _ERR]),
+    "bitnuc_as_2bit_batch": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_kmer_hdist_scan": (C.c_int, [_P, _P, _SZ, _SZ, _U64, _P, _ERR]),
+    "bitnuc_encode_dev": (C.c_int, [_P, _P, _SZ, _P, _ERR]),
+    "bitnuc_decode_dev": (C.c_int, [_P, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_as_2bit_batch_dev": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_kmer_hdist_scan_dev": (C.c_int, [_P, _P, _SZ, _SZ, _U64, _P, _ERR]),
+    "bitnuc_hdist_dev": (C.c_int, [_P, _P, _SZ, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_nucgen_dev": (C.c_int, [_P, _P, _SZ, _U64, _U64, C.c_int, _ERR]),
+    "bitnuc_stream_probe_dev": (C.c_int, [_P, C.c_int, _P, _P, _SZ, _ERR]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libbitnuc_hip.so and type every exported entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m bitnuc_amd.build` "
+            "(hipcc, gfx950). bitnuc_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

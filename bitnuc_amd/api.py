@@ -1,0 +1,319 @@
+"""Host-side mirror of bitnuc's public API over the C ABI (Python flavour).
+
+Same names, argument meaning and error behaviour as the reference's
+`pub use` list (src/lib.rs:214-220):
+
+    as_2bit, from_2bit, from_2bit_alloc, encode, encode_alloc, decode,
+    hdist_scalar, hdist, NucleotideError
+
+`Vec<u64>` / `Vec<u8>` arguments map to Python mutable sequences:
+  * `encode(seq, ebuf)` CLEARS `ebuf` then fills it     (packing/avx.rs:132)
+  * `decode(ebuf, n, dbuf)` / `from_2bit(p, n, seq)` APPEND (unpacking/avx.rs:122,140)
+`ebuf` may be a list or array('Q'); `dbuf` a bytearray.
+
+All arithmetic runs on the GPU through libbitnuc_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class NucleotideError(Exception):
+    """src/error.rs:3-18.  `kind` is the variant name; payload fields as in Rust."""
+
+    def __init__(self, kind, **payload):
+        self.kind = kind
+        self.payload = payload
+        for k, v in payload.items():
+            setattr(self, k, v)
+        super().__init__(self._display())
+
+    def _display(self):  # Display impl, src/error.rs:20-45
+        p = self.payload
+        if self.kind == "InvalidBase":
+            return f"Invalid nucleotide base: {p['byte']}"
+        if self.kind == "SequenceTooLong":
+            return f"Sequence length {p['len']} exceeds maximum"
+        if self.kind == "InvalidLength":
+            return f"Invalid length: {p['len']}"
+        if self.kind == "Unsupported":
+            return "Unsupported architecture"
+        return self.kind
+
+    def __eq__(self, other):  # derive(PartialEq, Eq), src/error.rs:3
+        return isinstance(other, NucleotideError) and self.kind == other.kind and \
+            {k: v for k, v in self.payload.items() if k != "index"} == \
+            {k: v for k, v in other.payload.items() if k != "index"}
+
+    __hash__ = Exception.__hash__
+
+
+class BackendError(RuntimeError):
+    """HIP runtime failure (no reference counterpart)."""
+
+
+def _raise(err):
+    st = err.status
+    if st == L.INVALID_BASE:
+        raise NucleotideError("InvalidBase", byte=int(err.byte), index=int(err.index))
+    if st == L.SEQUENCE_TOO_LONG:
+        raise NucleotideError("SequenceTooLong", len=int(err.value))
+    if st == L.INVALID_LENGTH:
+        raise NucleotideError("InvalidLength", len=int(err.value))
+    if st == L.UNSUPPORTED:
+        raise NucleotideError("Unsupported")
+    if st == L.BACKEND_ERROR:
+        raise BackendError(f"HIP error {err.backend_code} (is a gfx950 device visible? bitnuc_amd has no CPU fallback)")
+    raise RuntimeError(f"bitnuc status {st}")
+
+
+def _as_u8(buf):
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+    if a.dtype != np.uint8:
+        raise TypeError("sequence must be bytes-like / uint8")
+    return np.ascontiguousarray(a)
+
+
+def _as_u64(buf):
+    if isinstance(buf, np.ndarray):
+        if buf.dtype != np.uint64:
+            raise TypeError("ebuf must be uint64")
+        return np.ascontiguousarray(buf)
+    return np.asarray(list(buf), dtype=np.uint64)
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data if a.size else 0)
+
+
+def _dev_ptr(x):
+    """int device address, or anything with .data_ptr() (torch tensor)."""
+    if x is None:
+        return C.c_void_p(0)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+class Context:
+    """One device + stream + scratch (bitnuc_ctx).  Not thread-safe; make one per thread."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        err = L.BitnucErr()
+        if stream is None:
+            st = self._lib.bitnuc_ctx_create(device, C.byref(self._h), C.byref(err))
+        else:
+            st = self._lib.bitnuc_ctx_create_on_stream(device, C.c_void_p(int(stream)), C.byref(self._h), C.byref(err))
+        if st != L.OK:
+            self._h = C.c_void_p()
+            _raise(err)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.bitnuc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- tuning --------------------------------------------------------------------
+    def set_variant(self, key, value):
+        return self._lib.bitnuc_ctx_set_variant(self._h, key.encode(), int(value))
+
+    def get(self, key):
+        return self._lib.bitnuc_ctx_set_variant(self._h, key.encode(), -1)
+
+    @property
+    def stream(self):
+        return self._lib.bitnuc_ctx_stream(self._h)
+
+    def sync(self):
+        err = L.BitnucErr()
+        if self._lib.bitnuc_ctx_sync(self._h, C.byref(err)) != L.OK:
+            _raise(err)
+
+    # -- host-pointer API -------------------------------------------------------------
+    def as_2bit(self, seq):
+        s = _as_u8(seq)
+        out = C.c_uint64(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_as_2bit(self._h, _ptr(s), s.size, C.byref(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out.value
+
+    def from_2bit_alloc(self, packed, expected_size):
+        out = np.empty(min(int(expected_size), 32), dtype=np.uint8)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_from_2bit(self._h, C.c_uint64(packed), int(expected_size), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out.tobytes()
+
+    def from_2bit(self, packed, expected_size, sequence):
+        sequence += self.from_2bit_alloc(packed, expected_size)  # append (unpacking/avx.rs:59,73)
+
+    def encode_array(self, sequence):
+        """-> (words ndarray[uint64]) or raises; on InvalidBase the exception carries
+        `.words`, the words the reference's Vec holds at that point."""
+        s = _as_u8(sequence)
+        if s.size == 0:
+            # packing/avx.rs:138: `0..n_chunks - 1` underflows -> the reference panics
+            raise RuntimeError("encode of an empty sequence panics in the reference (attempt to subtract with overflow)")
+        out = np.empty((s.size + 31) // 32, dtype=np.uint64)
+        nw = C.c_size_t(0)
+        err = L.BitnucErr()
+        st = self._lib.bitnuc_encode(self._h, _ptr(s), s.size, _ptr(out), C.byref(nw), C.byref(err))
+        if st != L.OK:
+            try:
+                _raise(err)
+            except NucleotideError as e:
+                e.words = out[: nw.value].copy()
+                raise
+        return out
+
+    def encode(self, sequence, ebuf):
+        del ebuf[:]  # ebuf.clear(), packing/avx.rs:132
+        try:
+            words = self.encode_array(sequence)
+        except NucleotideError as e:
+            ebuf.extend(int(w) for w in getattr(e, "words", ()))
+            raise
+        ebuf.extend(words.tolist())
+
+    def encode_alloc(self, sequence):
+        ebuf = []
+        self.encode(sequence, ebuf)
+        return ebuf
+
+    def decode_array(self, ebuf, n_bases):
+        e = _as_u64(ebuf)
+        out = np.empty(int(n_bases), dtype=np.uint8)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_decode(self._h, _ptr(e), e.size, int(n_bases), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out
+
+    def decode(self, ebuf, n_bases, dbuf):
+        dbuf += self.decode_array(ebuf, n_bases).tobytes()  # append (unpacking/avx.rs:122,140)
+
+    def hdist_scalar(self, u, v, length):
+        out = C.c_uint32(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_hdist_scalar(self._h, C.c_uint64(u), C.c_uint64(v), int(length), C.byref(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out.value
+
+    def hdist(self, ebuf1, ebuf2, n_bases):
+        a, b = _as_u64(ebuf1), _as_u64(ebuf2)
+        out = C.c_uint32(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_hdist(self._h, _ptr(a), a.size, _ptr(b), b.size, int(n_bases), C.byref(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out.value
+
+    def as_2bit_batch(self, kmers, k, stride=None, count=None):
+        s = _as_u8(kmers)
+        stride = k if stride is None else stride
+        if count is None:
+            count = 0 if s.size < k else (s.size - k) // stride + 1
+        out = np.empty(count, dtype=np.uint64)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_as_2bit_batch(self._h, _ptr(s), int(k), int(stride), int(count), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out
+
+    def kmer_hdist_scan(self, ref, k, query):
+        s = _as_u8(ref)
+        nwin = s.size - k + 1 if (s.size >= k and k > 0) else 0
+        out = np.empty(nwin, dtype=np.uint8)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_kmer_hdist_scan(self._h, _ptr(s), s.size, int(k), C.c_uint64(query), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out
+
+    # -- device-pointer API (async; data errors surface at sync()) -----------------------
+    def _call_dev(self, fn, *args):
+        err = L.BitnucErr()
+        if fn(self._h, *args, C.byref(err)) != L.OK:
+            _raise(err)
+
+    def encode_dev(self, d_seq, length, d_out):
+        self._call_dev(self._lib.bitnuc_encode_dev, _dev_ptr(d_seq), int(length), _dev_ptr(d_out))
+
+    def decode_dev(self, d_ebuf, n_words, n_bases, d_out):
+        self._call_dev(self._lib.bitnuc_decode_dev, _dev_ptr(d_ebuf), int(n_words), int(n_bases), _dev_ptr(d_out))
+
+    def as_2bit_batch_dev(self, d_kmers, k, stride, count, d_out):
+        self._call_dev(self._lib.bitnuc_as_2bit_batch_dev, _dev_ptr(d_kmers), int(k), int(stride), int(count), _dev_ptr(d_out))
+
+    def kmer_hdist_scan_dev(self, d_ref, n, k, query, d_dist):
+        self._call_dev(self._lib.bitnuc_kmer_hdist_scan_dev, _dev_ptr(d_ref), int(n), int(k), C.c_uint64(query), _dev_ptr(d_dist))
+
+    def hdist_dev(self, d_a, na, d_b, nb, n_bases, d_result):
+        self._call_dev(self._lib.bitnuc_hdist_dev, _dev_ptr(d_a), int(na), _dev_ptr(d_b), int(nb), int(n_bases), _dev_ptr(d_result))
+
+    def nucgen_dev(self, d_out, length, seed, first=0, flags=0):
+        self._call_dev(self._lib.bitnuc_nucgen_dev, _dev_ptr(d_out), int(length), C.c_uint64(seed), C.c_uint64(first), int(flags))
+
+    def stream_probe_dev(self, mode, d_src, d_dst, nbytes):
+        self._call_dev(self._lib.bitnuc_stream_probe_dev, int(mode), _dev_ptr(d_src), _dev_ptr(d_dst), int(nbytes))
+
+
+# ---- module-level functions with the reference's names (default context, device 0) ----------
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default
+
+
+def as_2bit(seq):
+    return default_context().as_2bit(seq)
+
+
+def from_2bit(packed, expected_size, sequence):
+    return default_context().from_2bit(packed, expected_size, sequence)
+
+
+def from_2bit_alloc(packed, expected_size):
+    return default_context().from_2bit_alloc(packed, expected_size)
+
+
+def encode(sequence, ebuf):
+    return default_context().encode(sequence, ebuf)
+
+
+def encode_alloc(sequence):
+    return default_context().encode_alloc(sequence)
+
+
+def decode(ebuf, n_bases, dbuf):
+    return default_context().decode(ebuf, n_bases, dbuf)
+
+
+def hdist_scalar(u, v, length):
+    return default_context().hdist_scalar(u, v, length)
+
+
+def hdist(ebuf1, ebuf2, n_bases):
+    return default_context().hdist(ebuf1, ebuf2, n_bases)
+
+
+def as_2bit_batch(kmers, k, stride=None, count=None):
+    return default_context().as_2bit_batch(kmers, k, stride, count)
+
+
+def kmer_hdist_scan(ref, k, query):
+    return default_context().kmer_hdist_scan(ref, k, query)

@@ -1,0 +1,637 @@
+// bitnuc_hip.hip -- host runtime + C ABI of libbitnuc_hip.so (see include/bitnuc_hip.h).
+//
+// Owns: the context (device, stream, per-launch error slots, staging scratch),
+// kernel-variant dispatch, argument validation with the reference's error
+// vocabulary (src/error.rs:3-18), and the host-pointer convenience paths.
+// All arithmetic of the path runs in the kernels of codec_device.h /
+// kmer_device.h; there is deliberately no CPU implementation in this library.
+#include "../../include/bitnuc_hip.h"
+#include "codec_device.h"
+#include "kmer_device.h"
+
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+using namespace bitnuc_dev;
+
+namespace {
+
+constexpr int kSlots = 4096;                    // data-error slots between two syncs
+constexpr size_t kHostChunk = (size_t)128 << 20; // bases per staged chunk on the host-pointer path
+
+struct Pending {
+    const uint8_t *src;        // device pointer the slot's byte index is relative to
+    unsigned long long base;   // added to the slot's index (host path chunk offset)
+};
+
+} // namespace
+
+struct bitnuc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    unsigned long long *d_slots = nullptr;
+    unsigned long long *h_slots = nullptr; // pinned mirror
+    Pending pending[kSlots];
+    int n_pending = 0;
+    bool have_deferred = false; // an error found by an implicit drain, reported at next sync
+    bitnuc_err deferred;
+    uint8_t *scratch[3] = {nullptr, nullptr, nullptr};
+    size_t scratch_cap[3] = {0, 0, 0};
+    uint32_t *d_sink = nullptr;
+    int enc_variant = 1, dec_variant = 1;
+    int grid_mult = 8; // blocks per CU for grid-stride launches; 0 = one tile per block
+};
+
+namespace {
+
+void clear_err(bitnuc_err *e) {
+    if (e) memset(e, 0, sizeof *e);
+}
+int fail(bitnuc_err *e, int status, uint64_t value = 0) {
+    if (e) { memset(e, 0, sizeof *e); e->status = status; e->value = value; }
+    return status;
+}
+int fail_hip(bitnuc_err *e, hipError_t rc) {
+    if (e) { memset(e, 0, sizeof *e); e->status = BITNUC_BACKEND_ERROR; e->backend_code = (int32_t)rc; }
+    return BITNUC_BACKEND_ERROR;
+}
+#define HIPCHK(expr)                                       \
+    do {                                                   \
+        hipError_t rc__ = (expr);                          \
+        if (rc__ != hipSuccess) return fail_hip(err, rc__); \
+    } while (0)
+
+struct DeviceGuard { // hipSetDevice is per-thread state: make every entry point self-contained
+    int prev = -1;
+    bool ok;
+    explicit DeviceGuard(int dev) {
+        ok = hipGetDevice(&prev) == hipSuccess;
+        if (ok && prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {}
+};
+
+int ensure_scratch(bitnuc_ctx *c, int which, size_t bytes, bitnuc_err *err) {
+    if (bytes <= c->scratch_cap[which]) return BITNUC_OK;
+    if (c->scratch[which]) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(c->scratch[which]));
+        c->scratch[which] = nullptr;
+        c->scratch_cap[which] = 0;
+    }
+    size_t cap = (bytes + 4095) & ~(size_t)4095;
+    HIPCHK(hipMalloc(&c->scratch[which], cap));
+    c->scratch_cap[which] = cap;
+    return BITNUC_OK;
+}
+
+// Drain: wait for the stream, find the first latched data error among the pending
+// launches (launch order), reset the slots.
+int drain(bitnuc_ctx *c, bitnuc_err *err) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->n_pending == 0) { clear_err(err); return BITNUC_OK; }
+    const int n = c->n_pending;
+    HIPCHK(hipMemcpyAsync(c->h_slots, c->d_slots, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int hit = -1;
+    for (int i = 0; i < n; ++i)
+        if (c->h_slots[i] != kNoBad) { hit = i; break; }
+    bitnuc_err found;
+    memset(&found, 0, sizeof found);
+    if (hit >= 0) {
+        const unsigned long long idx = c->h_slots[hit];
+        uint8_t byte = 0;
+        HIPCHK(hipMemcpyAsync(&byte, c->pending[hit].src + idx, 1, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        found.status = BITNUC_INVALID_BASE;
+        found.byte = byte;
+        found.index = c->pending[hit].base + idx;
+        HIPCHK(hipMemsetAsync(c->d_slots, 0xFF, sizeof(unsigned long long) * n, c->stream));
+    }
+    c->n_pending = 0;
+    if (err) *err = found;
+    return found.status;
+}
+
+// Reserve the error slot of the next launch (drains implicitly when the ring is full).
+int take_slot(bitnuc_ctx *c, const uint8_t *src, unsigned long long base, unsigned long long **slot, bitnuc_err *err) {
+    if (c->n_pending == kSlots) {
+        bitnuc_err e;
+        int st = drain(c, &e);
+        if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
+        if (st != BITNUC_OK && !c->have_deferred) { c->have_deferred = true; c->deferred = e; }
+    }
+    c->pending[c->n_pending] = Pending{src, base};
+    *slot = c->d_slots + c->n_pending;
+    c->n_pending++;
+    return BITNUC_OK;
+}
+
+unsigned grid_for(const bitnuc_ctx *c, unsigned long long tiles) {
+    if (tiles == 0) return 1;
+    if (c->grid_mult <= 0) return (unsigned)(tiles < 0x7FFFFFFFull ? tiles : 0x7FFFFFFFull);
+    const unsigned long long cap = (unsigned long long)c->num_cu * c->grid_mult;
+    return (unsigned)(tiles < cap ? tiles : cap);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- kernel-variant tables -------------------------------------------------------
+struct Variant { int vpl, unroll; bool nt, xpose; };
+constexpr Variant kVariants[] = {
+    {1, 4, false, false}, // 0
+    {1, 4, true, false},  // 1  (default)
+    {1, 8, false, false}, // 2
+    {1, 8, true, false},  // 3
+    {1, 2, true, false},  // 4
+    {2, 2, true, false},  // 5
+    {2, 4, true, false},  // 6
+    {4, 1, true, false},  // 7
+    {4, 2, true, false},  // 8
+    {1, 4, false, true},  // 9  LDS transpose
+    {1, 4, true, true},   // 10 LDS transpose, nt
+    {1, 1, true, false},  // 11
+    {4, 2, false, false}, // 12
+    {2, 4, false, false}, // 13
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+template <int VPL, int UNROLL, bool NT, bool XPOSE>
+hipError_t launch_encode_t(bitnuc_ctx *c, const uint8_t *seq, uint32_t *out32, unsigned long long len,
+                           unsigned long long *slot, bool al) {
+    const unsigned long long tile = (unsigned long long)kBlock * UNROLL * VPL;
+    const unsigned grid = grid_for(c, (len >> 4) / tile + 1);
+    if (al) encode_kernel<VPL, UNROLL, NT, true, XPOSE><<<grid, kBlock, 0, c->stream>>>(seq, out32, len, slot);
+    else if constexpr (!XPOSE) encode_kernel<VPL, UNROLL, NT, false, false><<<grid, kBlock, 0, c->stream>>>(seq, out32, len, slot);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode(bitnuc_ctx *c, const uint8_t *seq, uint64_t *out, unsigned long long len, unsigned long long *slot) {
+    uint32_t *o = reinterpret_cast<uint32_t *>(out);
+    const bool in_al = aligned16(seq), out_al = aligned16(out);
+    int v = c->enc_variant;
+    // wide packed-side accesses need a 16-byte aligned packed buffer; the LDS
+    // transpose variant also needs aligned input
+    if ((kVariants[v].vpl == 4 && !out_al) || (kVariants[v].xpose && !(in_al && out_al))) v = 1;
+    switch (v) {
+    case 0: return launch_encode_t<1, 4, false, false>(c, seq, o, len, slot, in_al);
+    case 1: return launch_encode_t<1, 4, true, false>(c, seq, o, len, slot, in_al);
+    case 2: return launch_encode_t<1, 8, false, false>(c, seq, o, len, slot, in_al);
+    case 3: return launch_encode_t<1, 8, true, false>(c, seq, o, len, slot, in_al);
+    case 4: return launch_encode_t<1, 2, true, false>(c, seq, o, len, slot, in_al);
+    case 5: return launch_encode_t<2, 2, true, false>(c, seq, o, len, slot, in_al);
+    case 6: return launch_encode_t<2, 4, true, false>(c, seq, o, len, slot, in_al);
+    case 7: return launch_encode_t<4, 1, true, false>(c, seq, o, len, slot, in_al);
+    case 8: return launch_encode_t<4, 2, true, false>(c, seq, o, len, slot, in_al);
+    case 9: return launch_encode_t<1, 4, false, true>(c, seq, o, len, slot, true);
+    case 10: return launch_encode_t<1, 4, true, true>(c, seq, o, len, slot, true);
+    case 11: return launch_encode_t<1, 1, true, false>(c, seq, o, len, slot, in_al);
+    case 12: return launch_encode_t<4, 2, false, false>(c, seq, o, len, slot, in_al);
+    default: return launch_encode_t<2, 4, false, false>(c, seq, o, len, slot, in_al);
+    }
+}
+
+template <int VPL, int UNROLL, bool NT, bool XPOSE>
+hipError_t launch_decode_t(bitnuc_ctx *c, const uint32_t *in32, uint8_t *out, unsigned long long n_bases, bool al) {
+    const unsigned long long tile = (unsigned long long)kBlock * UNROLL * VPL;
+    const unsigned grid = grid_for(c, (n_bases >> 4) / tile + 1);
+    if (al) decode_kernel<VPL, UNROLL, NT, true, XPOSE><<<grid, kBlock, 0, c->stream>>>(in32, out, n_bases);
+    else decode_kernel<VPL, UNROLL, NT, false, XPOSE><<<grid, kBlock, 0, c->stream>>>(in32, out, n_bases);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsigned long long n_bases) {
+    const uint32_t *i = reinterpret_cast<const uint32_t *>(ebuf);
+    const bool in_al = aligned16(ebuf), out_al = aligned16(out);
+    int v = c->dec_variant;
+    if ((kVariants[v].vpl == 4 || kVariants[v].xpose) && !in_al) v = 1;
+    switch (v) {
+    case 0: return launch_decode_t<1, 4, false, false>(c, i, out, n_bases, out_al);
+    case 1: return launch_decode_t<1, 4, true, false>(c, i, out, n_bases, out_al);
+    case 2: return launch_decode_t<1, 8, false, false>(c, i, out, n_bases, out_al);
+    case 3: return launch_decode_t<1, 8, true, false>(c, i, out, n_bases, out_al);
+    case 4: return launch_decode_t<1, 2, true, false>(c, i, out, n_bases, out_al);
+    case 5: return launch_decode_t<2, 2, true, false>(c, i, out, n_bases, out_al);
+    case 6: return launch_decode_t<2, 4, true, false>(c, i, out, n_bases, out_al);
+    case 7: return launch_decode_t<4, 1, true, false>(c, i, out, n_bases, out_al);
+    case 8: return launch_decode_t<4, 2, true, false>(c, i, out, n_bases, out_al);
+    case 9: return launch_decode_t<1, 4, false, true>(c, i, out, n_bases, out_al);
+    case 10: return launch_decode_t<1, 4, true, true>(c, i, out, n_bases, out_al);
+    case 11: return launch_decode_t<1, 1, true, false>(c, i, out, n_bases, out_al);
+    case 12: return launch_decode_t<4, 2, false, false>(c, i, out, n_bases, out_al);
+    default: return launch_decode_t<2, 4, false, false>(c, i, out, n_bases, out_al);
+    }
+}
+
+hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t stride, size_t count, uint64_t *out,
+                        unsigned long long *slot) {
+    const unsigned grid = grid_for(c, (count + kBlock - 1) / kBlock);
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
+    if (stride <= (size_t)kStagedMaxStride)
+        kmer_batch_kernel<true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, stride, count, o, slot);
+    else
+        kmer_batch_kernel<false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, stride, count, o, slot);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist,
+                       unsigned long long *slot) {
+    const unsigned long long rounds = n >= 1056 ? (n - 1056) / 1024 + 1 : 0;
+    const unsigned grid = grid_for(c, rounds / (kBlock / 64) + 1);
+    if (aligned16(ref) && aligned16(dist))
+        kmer_scan_kernel<true, true><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot);
+    else
+        kmer_scan_kernel<false, false><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot);
+    return hipGetLastError();
+}
+
+// shared argument checks --------------------------------------------------------------
+int check_ctx(bitnuc_ctx *c, bitnuc_err *err) {
+    if (!c) return fail(err, BITNUC_UNSUPPORTED);
+    return BITNUC_OK;
+}
+
+} // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+const char *bitnuc_version(void) { return "bitnuc_hip 0.1.0 gfx950"; }
+
+int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, bitnuc_err *err) {
+    clear_err(err);
+    if (!out) return fail(err, BITNUC_UNSUPPORTED);
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail_hip(err, hipErrorInvalidDevice);
+    HIPCHK(hipSetDevice(device));
+    bitnuc_ctx *c = new bitnuc_ctx();
+    c->device = device;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    hipDeviceProp_t prop;
+    hipError_t rc = hipGetDeviceProperties(&prop, device);
+    if (rc == hipSuccess) c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (rc == hipSuccess) rc = hipMalloc(&c->d_slots, sizeof(unsigned long long) * kSlots);
+    if (rc == hipSuccess) rc = hipHostMalloc(reinterpret_cast<void **>(&c->h_slots), sizeof(unsigned long long) * kSlots, hipHostMallocDefault);
+    if (rc == hipSuccess) rc = hipMalloc(&c->d_sink, 64);
+    if (rc == hipSuccess) rc = hipMemset(c->d_slots, 0xFF, sizeof(unsigned long long) * kSlots);
+    if (rc == hipSuccess) rc = hipMemset(c->d_sink, 0, 64);
+    if (rc != hipSuccess) {
+        bitnuc_ctx_destroy(c);
+        return fail_hip(err, rc);
+    }
+    *out = c;
+    return BITNUC_OK;
+}
+
+int bitnuc_ctx_create(int device, bitnuc_ctx **out, bitnuc_err *err) {
+    clear_err(err);
+    if (!out) return fail(err, BITNUC_UNSUPPORTED);
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail_hip(err, hipErrorInvalidDevice);
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int st = bitnuc_ctx_create_on_stream(device, s, out, err);
+    if (st != BITNUC_OK) { (void)hipStreamDestroy(s); return st; }
+    (*out)->own_stream = true;
+    return BITNUC_OK;
+}
+
+void bitnuc_ctx_destroy(bitnuc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 3; ++i)
+        if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    if (c->d_slots) (void)hipFree(c->d_slots);
+    if (c->h_slots) (void)hipHostFree(c->h_slots);
+    if (c->d_sink) (void)hipFree(c->d_sink);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void *bitnuc_ctx_stream(bitnuc_ctx *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+int bitnuc_ctx_sync(bitnuc_ctx *c, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    DeviceGuard g(c->device);
+    bitnuc_err e;
+    int st = drain(c, &e);
+    if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
+    if (c->have_deferred) { // an earlier implicit drain saw an error first
+        c->have_deferred = false;
+        e = c->deferred;
+        st = e.status;
+    }
+    if (err) *err = e;
+    return st;
+}
+
+int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
+    if (!c || !key) return -1;
+    int prev = -1;
+    if (!strcmp(key, "encode")) { prev = c->enc_variant; if (value >= 0 && value < kNumVariants) c->enc_variant = value; }
+    else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0 && value < kNumVariants) c->dec_variant = value; }
+    else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }
+    else if (!strcmp(key, "num_variants")) { prev = kNumVariants; }
+    else if (!strcmp(key, "num_cu")) { prev = c->num_cu; }
+    return prev;
+}
+
+// ---- device-pointer entry points ---------------------------------------------------------
+int bitnuc_encode_dev(bitnuc_ctx *c, const uint8_t *d_seq, size_t len, uint64_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (len == 0) return BITNUC_OK; // 0 words (the reference panics: packing/avx.rs:138)
+    if (!d_seq || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    unsigned long long *slot;
+    if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
+    HIPCHK(launch_encode(c, d_seq, d_out, len, slot));
+    return BITNUC_OK;
+}
+
+int bitnuc_decode_dev(bitnuc_ctx *c, const uint64_t *d_ebuf, size_t n_words, size_t n_bases, uint8_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    // unpacking/mod.rs:40-45: missing words -> InvalidLength(n_bases)
+    if (n_words < (n_bases + 31) / 32) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (n_bases == 0) return BITNUC_OK; // unpacking/avx.rs:134-145: nothing appended
+    if (!d_ebuf || !d_out || (reinterpret_cast<uintptr_t>(d_ebuf) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    HIPCHK(launch_decode(c, d_ebuf, d_out, n_bases));
+    return BITNUC_OK;
+}
+
+int bitnuc_as_2bit_batch_dev(bitnuc_ctx *c, const uint8_t *d_kmers, size_t k, size_t stride, size_t count, uint64_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0) return BITNUC_OK;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k); // packing/naive.rs:5-7, before any base
+    if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 7) || stride == 0) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (k == 0) { // as_2bit(b"") == Ok(0)
+        HIPCHK(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * count, c->stream));
+        return BITNUC_OK;
+    }
+    if (!d_kmers) return fail(err, BITNUC_UNSUPPORTED);
+    unsigned long long *slot;
+    if (int st = take_slot(c, d_kmers, 0, &slot, err)) return st;
+    HIPCHK(launch_batch(c, d_kmers, k, stride, count, d_out, slot));
+    return BITNUC_OK;
+}
+
+int bitnuc_kmer_hdist_scan_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, size_t k, uint64_t query, uint8_t *d_dist, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k);
+    if (k == 0 || n < k) return BITNUC_OK; // no windows
+    if (!d_ref || !d_dist) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    unsigned long long *slot;
+    if (int st = take_slot(c, d_ref, 0, &slot, err)) return st;
+    HIPCHK(launch_scan(c, d_ref, n, k, query, d_dist, slot));
+    return BITNUC_OK;
+}
+
+int bitnuc_hdist_dev(bitnuc_ctx *c, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, size_t n_bases, uint32_t *d_result, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    const size_t need = (n_bases + 31) / 32;
+    if (na < need || nb < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases); // hamming/multi.rs:124-127
+    if (!d_result) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    HIPCHK(hipMemsetAsync(d_result, 0, sizeof(uint32_t), c->stream));
+    if (n_bases == 0) return BITNUC_OK;
+    if (!d_a || !d_b) return fail(err, BITNUC_UNSUPPORTED);
+    const unsigned grid = grid_for(c, (n_bases / 32) / (kBlock * 4) + 1);
+    hdist_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
+                                                 reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_nucgen_dev(bitnuc_ctx *c, uint8_t *d_out, size_t len, uint64_t seed, uint64_t first, int flags, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (len == 0) return BITNUC_OK;
+    if (!d_out) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const unsigned grid = grid_for(c, ((len + 15) / 16 + kBlock - 1) / kBlock);
+    nucgen_kernel<<<grid, kBlock, 0, c->stream>>>(d_out, len, seed, first, flags);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_stream_probe_dev(bitnuc_ctx *c, int mode, const void *d_src, void *d_dst, size_t bytes, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    DeviceGuard g(c->device);
+    const unsigned long long n16 = bytes / 16;
+    const unsigned grid = grid_for(c, n16 / (kBlock * 4) + 1);
+    const bool nt = (mode & 8) != 0;
+    switch (mode & 7) {
+    case 0:
+        if (!d_src || !aligned16(d_src)) return fail(err, BITNUC_UNSUPPORTED);
+        if (nt) probe_read_kernel<4, true><<<grid, kBlock, 0, c->stream>>>(static_cast<const u32x4 *>(d_src), n16, c->d_sink);
+        else probe_read_kernel<4, false><<<grid, kBlock, 0, c->stream>>>(static_cast<const u32x4 *>(d_src), n16, c->d_sink);
+        break;
+    case 1:
+        if (!d_src || !d_dst || !aligned16(d_src) || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
+        if (nt) probe_copy_kernel<4, true><<<grid, kBlock, 0, c->stream>>>(static_cast<const u32x4 *>(d_src), static_cast<u32x4 *>(d_dst), n16);
+        else probe_copy_kernel<4, false><<<grid, kBlock, 0, c->stream>>>(static_cast<const u32x4 *>(d_src), static_cast<u32x4 *>(d_dst), n16);
+        break;
+    case 2:
+        if (!d_dst || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
+        if (nt) probe_fill_kernel<4, true><<<grid, kBlock, 0, c->stream>>>(static_cast<u32x4 *>(d_dst), n16);
+        else probe_fill_kernel<4, false><<<grid, kBlock, 0, c->stream>>>(static_cast<u32x4 *>(d_dst), n16);
+        break;
+    default:
+        return fail(err, BITNUC_UNSUPPORTED);
+    }
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+// ---- host-pointer entry points (synchronous, staged through device scratch) -------------------
+int bitnuc_encode(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, size_t *n_words, bitnuc_err *err) {
+    clear_err(err);
+    if (n_words) *n_words = 0;
+    if (int st = check_ctx(c, err)) return st;
+    if (len == 0) return BITNUC_OK;
+    if (!seq || !out) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    { bitnuc_err e; int st = bitnuc_ctx_sync(c, &e); if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; } }
+    const size_t chunk = len < kHostChunk ? len : kHostChunk;
+    if (int st = ensure_scratch(c, 0, chunk + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, ((chunk + 31) / 32) * 8 + 16, err)) return st;
+    for (size_t off = 0; off < len; off += chunk) {
+        const size_t n = len - off < chunk ? len - off : chunk;
+        const size_t nw = (n + 31) / 32;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], seq + off, n, hipMemcpyHostToDevice, c->stream));
+        unsigned long long *slot;
+        if (int st = take_slot(c, c->scratch[0], off, &slot, err)) return st;
+        HIPCHK(launch_encode(c, c->scratch[0], reinterpret_cast<uint64_t *>(c->scratch[1]), n, slot));
+        HIPCHK(hipMemcpyAsync(out + off / 32, c->scratch[1], nw * 8, hipMemcpyDeviceToHost, c->stream));
+        // the chunk's slot must be resolved before scratch[0] is overwritten (its byte is read back from there)
+        bitnuc_err e;
+        int st = drain(c, &e);
+        if (st != BITNUC_OK) {
+            if (err) *err = e;
+            if (st == BITNUC_INVALID_BASE && n_words) *n_words = (size_t)(e.index / 32);
+            return st;
+        }
+    }
+    if (n_words) *n_words = (len + 31) / 32;
+    return BITNUC_OK;
+}
+
+int bitnuc_decode(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_words, size_t n_bases, uint8_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (n_words < (n_bases + 31) / 32) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (n_bases == 0) return BITNUC_OK;
+    if (!ebuf || !out) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const size_t chunk = n_bases < kHostChunk ? n_bases : kHostChunk;
+    if (int st = ensure_scratch(c, 0, chunk + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, ((chunk + 31) / 32) * 8 + 16, err)) return st;
+    for (size_t off = 0; off < n_bases; off += chunk) {
+        const size_t n = n_bases - off < chunk ? n_bases - off : chunk;
+        const size_t nw = (n + 31) / 32;
+        HIPCHK(hipMemcpyAsync(c->scratch[1], ebuf + off / 32, nw * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(launch_decode(c, reinterpret_cast<const uint64_t *>(c->scratch[1]), c->scratch[0], n));
+        HIPCHK(hipMemcpyAsync(out + off, c->scratch[0], n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return BITNUC_OK;
+}
+
+int bitnuc_as_2bit_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t stride, size_t count, uint64_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0) return BITNUC_OK;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k);
+    if (!out || stride == 0) return fail(err, BITNUC_UNSUPPORTED);
+    if (k == 0) { memset(out, 0, sizeof(uint64_t) * count); return BITNUC_OK; }
+    if (!kmers) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    { bitnuc_err e; int st = bitnuc_ctx_sync(c, &e); if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; } }
+    // chunk by k-mers so a staged chunk stays <= kHostChunk bytes
+    size_t per = kHostChunk / stride;
+    if (per == 0) per = 1;
+    if (per > count) per = count;
+    if (int st = ensure_scratch(c, 0, (per - 1) * stride + k + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, per * 8, err)) return st;
+    for (size_t j0 = 0; j0 < count; j0 += per) {
+        const size_t m = count - j0 < per ? count - j0 : per;
+        const size_t bytes = (m - 1) * stride + k;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], kmers + j0 * stride, bytes, hipMemcpyHostToDevice, c->stream));
+        unsigned long long *slot;
+        if (int st = take_slot(c, c->scratch[0], (unsigned long long)j0 * stride, &slot, err)) return st;
+        HIPCHK(launch_batch(c, c->scratch[0], k, stride, m, reinterpret_cast<uint64_t *>(c->scratch[1]), slot));
+        HIPCHK(hipMemcpyAsync(out + j0, c->scratch[1], m * 8, hipMemcpyDeviceToHost, c->stream));
+        bitnuc_err e;
+        int st = drain(c, &e);
+        if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    }
+    return BITNUC_OK;
+}
+
+int bitnuc_kmer_hdist_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k);
+    if (k == 0 || n < k) return BITNUC_OK;
+    if (!ref || !dist) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    { bitnuc_err e; int st = bitnuc_ctx_sync(c, &e); if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; } }
+    const size_t nwin = n - k + 1;
+    const size_t chunk = nwin < kHostChunk ? nwin : kHostChunk; // windows per staged chunk
+    if (int st = ensure_scratch(c, 0, chunk + k + 16, err)) return st;
+    if (int st = ensure_scratch(c, 2, chunk + 16, err)) return st;
+    for (size_t off = 0; off < nwin; off += chunk) {
+        const size_t w = nwin - off < chunk ? nwin - off : chunk;
+        const size_t bytes = w + k - 1;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], ref + off, bytes, hipMemcpyHostToDevice, c->stream));
+        unsigned long long *slot;
+        if (int st = take_slot(c, c->scratch[0], off, &slot, err)) return st;
+        HIPCHK(launch_scan(c, c->scratch[0], bytes, k, query, c->scratch[2], slot));
+        HIPCHK(hipMemcpyAsync(dist + off, c->scratch[2], w, hipMemcpyDeviceToHost, c->stream));
+        bitnuc_err e;
+        int st = drain(c, &e);
+        if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    }
+    return BITNUC_OK;
+}
+
+int bitnuc_hdist(bitnuc_ctx *c, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, size_t n_bases, uint32_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    const size_t need = (n_bases + 31) / 32;
+    if (na < need || nb < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (!out) return fail(err, BITNUC_UNSUPPORTED);
+    if (n_bases == 0) { *out = 0; return BITNUC_OK; }
+    if (!a || !b) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const size_t chunk_words = kHostChunk / 8;
+    const size_t cw = need < chunk_words ? need : chunk_words;
+    if (int st = ensure_scratch(c, 0, cw * 8, err)) return st;
+    if (int st = ensure_scratch(c, 1, cw * 8, err)) return st;
+    if (int st = ensure_scratch(c, 2, 64, err)) return st;
+    uint32_t total = 0;
+    for (size_t w0 = 0; w0 < need; w0 += cw) {
+        const size_t m = need - w0 < cw ? need - w0 : cw;
+        const size_t bases = (w0 + m == need) ? n_bases - w0 * 32 : m * 32;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], a + w0, m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->scratch[1], b + w0, m * 8, hipMemcpyHostToDevice, c->stream));
+        bitnuc_err e;
+        int st = bitnuc_hdist_dev(c, reinterpret_cast<const uint64_t *>(c->scratch[0]), m,
+                                  reinterpret_cast<const uint64_t *>(c->scratch[1]), m, bases,
+                                  reinterpret_cast<uint32_t *>(c->scratch[2]), &e);
+        if (st != BITNUC_OK) { if (err) *err = e; return st; }
+        uint32_t part = 0;
+        HIPCHK(hipMemcpyAsync(&part, c->scratch[2], 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        total += part; // u32 wrap-around like the reference's accumulator (multi.rs:130)
+    }
+    *out = total;
+    return BITNUC_OK;
+}
+
+// ---- single-word API: batches of one on the device ---------------------------------------------
+int bitnuc_as_2bit(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (len > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, len);
+    if (!out) return fail(err, BITNUC_UNSUPPORTED);
+    return bitnuc_as_2bit_batch(c, seq, len, len ? len : 1, 1, out, err);
+}
+
+int bitnuc_from_2bit(bitnuc_ctx *c, uint64_t packed, size_t n, uint8_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (n > 32) return fail(err, BITNUC_INVALID_LENGTH, n); // unpacking/naive.rs:8-10
+    if (n == 0) return BITNUC_OK;
+    return bitnuc_decode(c, &packed, 1, n, out, err);
+}
+
+int bitnuc_hdist_scalar(bitnuc_ctx *c, uint64_t u, uint64_t v, size_t len, uint32_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (len > 32) return fail(err, BITNUC_INVALID_LENGTH, len); // hamming/scalar.rs:13-15
+    return bitnuc_hdist(c, &u, 1, &v, 1, len, out, err);
+}
+
+} // extern "C"

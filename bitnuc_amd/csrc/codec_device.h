@@ -1,0 +1,415 @@
+// codec_device.h -- gfx950 device code for bulk 2-bit encode / decode.
+//
+// What is computed (bit-exact target):
+//   encode : word[w] = sum_i code(seq[32w+i]) << 2i, code A/a,C/c,G/g,T/t -> 0..3
+//            (reference: src/utils/packing/naive.rs:8-18, avx.rs:130-151)
+//   decode : out[32w+i] = "ACGT"[(word[w] >> 2i) & 3]
+//            (reference: src/utils/unpacking/naive.rs:12-22, avx.rs:116-153)
+//
+// How (MI355X-first, nothing here is a translation of the reference's SIMD):
+//   * the unit of work is a 16-base "group": 16 input bytes <-> one u32 (half a
+//     u64 word, little-endian), so a lane's global access is one dwordx4 on the
+//     ASCII side and adjacent lanes touch adjacent 16-byte groups: every
+//     wave-instruction is a fully coalesced 1 KiB (ASCII) / 256 B (packed) span;
+//   * per dword of 4 bases: index = b & 7 (A=1,C=3,T=4,G=7, case-insensitive)
+//     -> v_perm_b32 as an 8-entry byte LUT yields code | (ascii & 0xD8); XOR with
+//     (x & 0xD8D8D8D8) cancels the ASCII bits iff the byte is a valid base, so the
+//     same word carries the code (bits 0-1) and the validity residue (bits 2-7);
+//     v_dot4_u32_u8 with weights {1,4,16,64} compacts 4 codes into one byte;
+//   * an invalid byte is rare: lanes that see a residue take a slow path that
+//     atomicMin's the absolute byte index into a per-launch slot, which gives the
+//     reference's "first invalid byte in sequence order" (avx.rs:86-91) without
+//     serialising the stream;
+//   * optional wave-private LDS transpose (XPOSE) turns 4 coalesced 4-byte
+//     accesses per lane on the packed side into one 16-byte access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bitnuc_dev {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x4 u32x4_u __attribute__((aligned(1))); // any byte address (gfx950 unaligned-access mode)
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
+typedef uint32_t u32_u __attribute__((aligned(1)));
+
+constexpr unsigned long long kNoBad = ~0ull;
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------
+// per-dword primitives
+// ---------------------------------------------------------------------------------
+
+// 4 ASCII bases -> one byte of 4 codes (base 0 in bits 0-1).  `bad` accumulates the
+// validity residue: (bad & 0xFCFCFCFC) != 0 <=> some byte was not in ACGTacgt.
+__device__ __forceinline__ uint32_t enc4(uint32_t x, uint32_t &bad) {
+    const uint32_t sel = x & 0x07070707u;
+    // LUT[idx] : 1->'A'(0x40|0) 3->'C'(0x40|1) 7->'G'(0x40|2) 4->'T'(0x50|3); others 0x04 (bit 2 = invalid)
+    const uint32_t t = __builtin_amdgcn_perm(0x42040453u, 0x41044004u, sel);
+    const uint32_t d = t ^ (x & 0xD8D8D8D8u);
+    bad |= d;
+    return __builtin_amdgcn_udot4(d, 0x40100401u, 0u, false);
+}
+
+__device__ __forceinline__ bool residue_is_bad(uint32_t bad) { return (bad & 0xFCFCFCFCu) != 0u; }
+
+__device__ __forceinline__ uint32_t enc16(u32x4 v, uint32_t &bad) {
+    const uint32_t r0 = enc4(v.x, bad), r1 = enc4(v.y, bad), r2 = enc4(v.z, bad), r3 = enc4(v.w, bad);
+    return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+}
+
+__device__ __forceinline__ bool valid_base(uint32_t b) {
+    const uint32_t u = b & 0xDFu;
+    return u == 'A' || u == 'C' || u == 'G' || u == 'T';
+}
+
+__device__ __forceinline__ uint32_t code_of(uint32_t b) { return ((b >> 1) ^ (b >> 2)) & 3u; }
+
+// slow path (rare): re-read `nbytes` bytes starting at absolute index `start` and latch
+// the first invalid one.  One non-unrolled copy per kernel keeps the hot loop's
+// register/SGPR footprint small.
+__device__ __forceinline__ void rescan_bytes(const uint8_t *seq, unsigned long long start, unsigned nbytes,
+                                             unsigned long long *slot) {
+#pragma unroll 1
+    for (unsigned i = 0; i < nbytes; ++i) {
+        if (!valid_base(seq[start + i])) {
+            atomicMin(slot, start + i);
+            return;
+        }
+    }
+}
+
+// 8 bits (4 codes) -> 4 ASCII bytes.
+__device__ __forceinline__ uint32_t dec4(uint32_t v) {
+    uint32_t s = (v | (v << 12)) & 0x000F000Fu;
+    s = (s | (s << 6)) & 0x03030303u;
+    return __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, s);
+}
+
+__device__ __forceinline__ u32x4 dec16(uint32_t w) {
+    u32x4 o;
+    o.x = dec4(w & 0xFFu);
+    o.y = dec4(__builtin_amdgcn_ubfe(w, 8, 8));
+    o.z = dec4(__builtin_amdgcn_ubfe(w, 16, 8));
+    o.w = dec4(w >> 24);
+    return o;
+}
+
+// ---------------------------------------------------------------------------------
+// memory helpers
+// ---------------------------------------------------------------------------------
+template <bool NT, bool ALIGNED>
+__device__ __forceinline__ u32x4 load_group(const uint8_t *p) {
+    if constexpr (ALIGNED) {
+        if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        else return *reinterpret_cast<const u32x4 *>(p);
+    } else {
+        return *reinterpret_cast<const u32x4_u *>(p);
+    }
+}
+
+template <bool NT, bool ALIGNED>
+__device__ __forceinline__ void store_group(uint8_t *p, u32x4 v) {
+    if constexpr (ALIGNED) {
+        if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+        else *reinterpret_cast<u32x4 *>(p) = v;
+    } else {
+        *reinterpret_cast<u32x4_u *>(p) = v;
+    }
+}
+
+template <bool NT>
+__device__ __forceinline__ void store_u32(uint32_t *p, uint32_t v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <bool NT>
+__device__ __forceinline__ uint32_t load_u32(const uint32_t *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS ops of one wave complete in order; this only stops the compiler from
+    // moving the ds_read above the ds_write of the other lanes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------
+// encode
+// ---------------------------------------------------------------------------------
+// Geometry: a tile is kBlock*UNROLL*VPL groups.  Thread t, round u owns the VPL
+// consecutive groups starting at tile + (u*kBlock + t)*VPL, so one round of a wave is
+// one contiguous 64*VPL*16-byte span.  VPL=1: dwordx4 load, dword store.  VPL=2/4:
+// the lane's packed output is one dwordx2/dwordx4 store.  XPOSE (VPL==1, UNROLL==4):
+// loads stay 16 B/lane coalesced, results cross a wave-private LDS strip so each lane
+// stores 16 contiguous packed bytes.
+template <int VPL, int UNROLL, bool NT, bool ALIGNED, bool XPOSE>
+__global__ void __launch_bounds__(kBlock)
+encode_kernel(const uint8_t *__restrict__ seq, uint32_t *__restrict__ out32, unsigned long long len,
+              unsigned long long *__restrict__ slot) {
+    static_assert(!XPOSE || (VPL == 1 && UNROLL == 4), "XPOSE needs VPL=1, UNROLL=4");
+    constexpr unsigned long long TILE = (unsigned long long)kBlock * UNROLL * VPL;
+    const unsigned long long n16 = len >> 4;
+    const unsigned long long full_tiles = n16 / TILE;
+    const unsigned t = threadIdx.x;
+    __shared__ uint32_t strip[XPOSE ? kBlock * 4 : 1];
+
+    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+        const unsigned long long g0 = tile * TILE;
+        if constexpr (XPOSE) {
+            const unsigned wave = t >> 6, lane = t & 63;
+            const unsigned long long gw = g0 + (unsigned long long)wave * 256;
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = load_group<NT, true>(seq + ((gw + u * 64 + lane) << 4));
+            uint32_t bad = 0;
+            uint32_t *ws = strip + wave * 256;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ws[u * 64 + lane] = enc16(v[u], bad);
+            if (__builtin_expect(residue_is_bad(bad), 0)) {
+#pragma unroll 1
+                for (int u = 0; u < 4; ++u) rescan_bytes(seq, (gw + u * 64 + lane) << 4, 16, slot);
+            }
+            wave_lds_fence();
+            const u32x4 r = *reinterpret_cast<const u32x4 *>(ws + 4 * lane);
+            wave_lds_fence();
+            store_group<NT, true>(reinterpret_cast<uint8_t *>(out32 + gw + 4 * lane), r);
+        } else {
+            u32x4 v[UNROLL][VPL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j)
+                    v[u][j] = load_group<NT, ALIGNED>(seq + ((g0 + ((unsigned long long)u * kBlock + t) * VPL + j) << 4));
+            uint32_t bad = 0;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const unsigned long long g = g0 + ((unsigned long long)u * kBlock + t) * VPL;
+                uint32_t r[VPL];
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) r[j] = enc16(v[u][j], bad);
+                if constexpr (VPL == 1) {
+                    store_u32<NT>(out32 + g, r[0]);
+                } else if constexpr (VPL == 2) {
+                    u32x2 o = {r[0], r[1]};
+                    if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(out32 + g));
+                    else *reinterpret_cast<u32x2 *>(out32 + g) = o;
+                } else {
+                    u32x4 o = {r[0], r[1], r[2], r[3]};
+                    store_group<NT, true>(reinterpret_cast<uint8_t *>(out32 + g), o);
+                }
+            }
+            if (__builtin_expect(residue_is_bad(bad), 0)) {
+#pragma unroll 1
+                for (int u = 0; u < UNROLL; ++u)
+                    rescan_bytes(seq, (g0 + ((unsigned long long)u * kBlock + t) * VPL) << 4, 16 * VPL, slot);
+            }
+        }
+    }
+
+    // groups past the last full tile: one block, bounds-checked, plain path
+    if (blockIdx.x == (unsigned)(full_tiles % gridDim.x)) {
+        for (unsigned long long g = full_tiles * TILE + t; g < n16; g += kBlock) {
+            const u32x4 v = load_group<false, ALIGNED>(seq + (g << 4));
+            uint32_t b = 0;
+            const uint32_t r = enc16(v, b);
+            if (residue_is_bad(b)) rescan_bytes(seq, g << 4, 16, slot);
+            out32[g] = r;
+        }
+        if (t == 0) {
+            // last 1..15 bases, and the zero upper half of the final u64 when the
+            // number of 16-base groups is odd
+            const unsigned rem = (unsigned)(len & 15);
+            unsigned long long ngroups = n16;
+            if (rem) {
+                uint32_t r = 0;
+                bool flagged = false;
+                for (unsigned i = 0; i < rem; ++i) {
+                    const uint32_t b = seq[(n16 << 4) + i];
+                    if (!valid_base(b) && !flagged) {
+                        atomicMin(slot, (n16 << 4) + i);
+                        flagged = true;
+                    }
+                    r |= code_of(b) << (2 * i);
+                }
+                out32[n16] = r;
+                ngroups = n16 + 1;
+            }
+            if (ngroups & 1) out32[ngroups] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------
+// Same geometry seen from the packed side: thread t, round u owns VPL consecutive
+// u32 half-words and writes VPL consecutive 16-byte ASCII groups.  XPOSE: dwordx4
+// load of 4 consecutive half-words per lane, transposed through a wave-private LDS
+// strip so that each of the 4 ASCII stores of a wave is one contiguous 1 KiB span.
+template <int VPL, int UNROLL, bool NT, bool ALIGNED, bool XPOSE>
+__global__ void __launch_bounds__(kBlock)
+decode_kernel(const uint32_t *__restrict__ in32, uint8_t *__restrict__ out, unsigned long long n_bases) {
+    static_assert(!XPOSE || (VPL == 1 && UNROLL == 4), "XPOSE needs VPL=1, UNROLL=4");
+    constexpr unsigned long long TILE = (unsigned long long)kBlock * UNROLL * VPL;
+    const unsigned long long n16 = n_bases >> 4;
+    const unsigned long long full_tiles = n16 / TILE;
+    const unsigned t = threadIdx.x;
+    __shared__ uint32_t strip[XPOSE ? kBlock * 4 : 1];
+
+    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+        const unsigned long long g0 = tile * TILE;
+        if constexpr (XPOSE) {
+            const unsigned wave = t >> 6, lane = t & 63;
+            const unsigned long long gw = g0 + (unsigned long long)wave * 256;
+            uint32_t *ws = strip + wave * 256;
+            const u32x4 w = load_group<NT, true>(reinterpret_cast<const uint8_t *>(in32 + gw + 4 * lane));
+            *reinterpret_cast<u32x4 *>(ws + 4 * lane) = w;
+            wave_lds_fence();
+            uint32_t h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h[u] = ws[u * 64 + lane];
+            wave_lds_fence();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) store_group<NT, ALIGNED>(out + ((gw + u * 64 + lane) << 4), dec16(h[u]));
+        } else {
+            uint32_t h[UNROLL][VPL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const unsigned long long g = g0 + ((unsigned long long)u * kBlock + t) * VPL;
+                if constexpr (VPL == 1) {
+                    h[u][0] = load_u32<NT>(in32 + g);
+                } else if constexpr (VPL == 2) {
+                    u32x2 w;
+                    if constexpr (NT) w = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(in32 + g));
+                    else w = *reinterpret_cast<const u32x2 *>(in32 + g);
+                    h[u][0] = w.x; h[u][1] = w.y;
+                } else {
+                    const u32x4 w = load_group<NT, true>(reinterpret_cast<const uint8_t *>(in32 + g));
+                    h[u][0] = w.x; h[u][1] = w.y; h[u][2] = w.z; h[u][3] = w.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const unsigned long long g = g0 + ((unsigned long long)u * kBlock + t) * VPL;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) store_group<NT, ALIGNED>(out + ((g + j) << 4), dec16(h[u][j]));
+            }
+        }
+    }
+
+    if (blockIdx.x == (unsigned)(full_tiles % gridDim.x)) {
+        for (unsigned long long g = full_tiles * TILE + t; g < n16; g += kBlock)
+            store_group<false, ALIGNED>(out + (g << 4), dec16(in32[g]));
+        if (t == 0) {
+            const unsigned rem = (unsigned)(n_bases & 15);
+            if (rem) {
+                const uint32_t w = in32[n16];
+                for (unsigned i = 0; i < rem; ++i) out[(n16 << 4) + i] = "ACGT"[(w >> (2 * i)) & 3];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// synthetic input generator (seeded, counter-based; regenerable on the host)
+// ---------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ unsigned long long gen_word(unsigned long long seed, unsigned long long widx, int flags) {
+    if (flags & 1) return 0xE4E4E4E4E4E4E4E4ull; // "ACGT" cyclic (bases[i % 4])
+    return mix64(seed + (widx + 1) * 0x9E3779B97F4A7C15ull);
+}
+
+__global__ void __launch_bounds__(kBlock)
+nucgen_kernel(uint8_t *__restrict__ out, unsigned long long len, unsigned long long seed,
+              unsigned long long first, int flags) {
+    const unsigned long long ngroups = (len + 15) >> 4;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; g < ngroups;
+         g += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long a = first + (g << 4); // absolute index of this group's first base
+        const unsigned long long widx = a >> 5;
+        const unsigned s = 2 * (unsigned)(a & 31);
+        const unsigned long long w0 = gen_word(seed, widx, flags);
+        unsigned long long bits = w0 >> s;
+        if (s > 32) bits |= gen_word(seed, widx + 1, flags) << (64 - s);
+        const u32x4 v = dec16((uint32_t)bits);
+        const unsigned long long o = g << 4;
+        if (o + 16 <= len) {
+            store_group<false, false>(out + o, v);
+        } else {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (unsigned i = 0; o + i < len; ++i) out[o + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// streaming probes: the box's own HBM ceiling, measured next to the codec
+// ---------------------------------------------------------------------------------
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(kBlock)
+probe_read_kernel(const u32x4 *__restrict__ src, unsigned long long n16, uint32_t *__restrict__ sink) {
+    constexpr unsigned long long TILE = (unsigned long long)kBlock * UNROLL;
+    u32x4 acc = {0, 0, 0, 0};
+    const unsigned long long full_tiles = n16 / TILE;
+    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u32x4 *p = src + tile * TILE + u * kBlock + threadIdx.x;
+            if constexpr (NT) v[u] = __builtin_nontemporal_load(p); else v[u] = *p;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
+    }
+    const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x9E3779B9u) sink[0] = r; // never true for real data; keeps the loads alive
+}
+
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(kBlock)
+probe_copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, unsigned long long n16) {
+    constexpr unsigned long long TILE = (unsigned long long)kBlock * UNROLL;
+    const unsigned long long full_tiles = n16 / TILE;
+    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u32x4 *p = src + tile * TILE + u * kBlock + threadIdx.x;
+            if constexpr (NT) v[u] = __builtin_nontemporal_load(p); else v[u] = *p;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            u32x4 *q = dst + tile * TILE + u * kBlock + threadIdx.x;
+            if constexpr (NT) __builtin_nontemporal_store(v[u], q); else *q = v[u];
+        }
+    }
+}
+
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(kBlock)
+probe_fill_kernel(u32x4 *__restrict__ dst, unsigned long long n16) {
+    constexpr unsigned long long TILE = (unsigned long long)kBlock * UNROLL;
+    const unsigned long long full_tiles = n16 / TILE;
+    const u32x4 v = {0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u};
+    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            u32x4 *q = dst + tile * TILE + u * kBlock + threadIdx.x;
+            if constexpr (NT) __builtin_nontemporal_store(v, q); else *q = v;
+        }
+    }
+}
+
+} // namespace bitnuc_dev

@@ -1,0 +1,141 @@
+/*
+ * bitnuc_hip.h -- C ABI of libbitnuc_hip.so: the MI355X (gfx950) replacement for
+ * bitnuc's 2-bit pack/unpack + bulk encode/decode hot path.
+ *
+ * The reference (drbh/bitnuc, a pure-Rust crate) has no FFI of its own; the
+ * drop-in boundary is its public Rust API (src/lib.rs:214-220).  Each entry point
+ * below names the reference function it replaces.  A Rust `extern "C"` binding
+ * for every symbol is shown in INTEGRATION.md / rust/src/ffi.rs; include/bitnuc.hpp
+ * is the compiled C++ host layer with the reference's names and Vec semantics.
+ *
+ * All compute happens in hand-written HIP kernels (bitnuc_amd/csrc/).  There is
+ * no CPU fallback: without a usable HIP device every compute entry point returns
+ * BITNUC_BACKEND_ERROR.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch / C++ types in signatures;
+ *   - return value == err->status (err may be NULL);
+ *   - "host" entry points take host pointers, stage through pinned buffers and
+ *     are synchronous; "_dev" entry points take device pointers, are enqueued
+ *     on the context's stream and return immediately -- data-dependent errors
+ *     (InvalidBase) are latched on the device and reported by bitnuc_ctx_sync();
+ *   - a bitnuc_ctx owns one device + stream + scratch and must not be used from
+ *     two threads at once; separate contexts are independent.
+ */
+#ifndef BITNUC_HIP_H
+#define BITNUC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* NucleotideError, src/error.rs:3-18, plus a backend status that has no reference
+ * counterpart (HIP runtime failure). */
+typedef enum bitnuc_status {
+    BITNUC_OK = 0,
+    BITNUC_INVALID_BASE = 1,        /* InvalidBase(u8)         -> err.byte, err.index */
+    BITNUC_SEQUENCE_TOO_LONG = 2,   /* SequenceTooLong(usize)  -> err.value */
+    BITNUC_INVALID_LENGTH = 3,      /* InvalidLength(usize)    -> err.value */
+    BITNUC_INDEX_OUT_OF_BOUNDS = 4, /* not produced by this path */
+    BITNUC_INVALID_RANGE = 5,       /* not produced by this path */
+    BITNUC_UNSUPPORTED = 6,         /* Unsupported (bad argument combination) */
+    BITNUC_BACKEND_ERROR = 100      /* hipError_t in err.backend_code */
+} bitnuc_status;
+
+typedef struct bitnuc_err {
+    int32_t status;       /* bitnuc_status */
+    int32_t backend_code; /* hipError_t when status == BITNUC_BACKEND_ERROR */
+    uint64_t value;       /* offending length for TOO_LONG / INVALID_LENGTH */
+    uint64_t index;       /* absolute byte index of the first invalid base */
+    uint8_t byte;         /* the first invalid base */
+    uint8_t _pad[7];
+} bitnuc_err;
+
+typedef struct bitnuc_ctx bitnuc_ctx;
+
+/* ---- context ------------------------------------------------------------------ */
+/* Create a context on HIP device `device` with its own non-blocking stream. */
+int bitnuc_ctx_create(int device, bitnuc_ctx **out, bitnuc_err *err);
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch's current stream;
+ * NULL = the default stream).  The stream is not destroyed with the context. */
+int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, bitnuc_err *err);
+void bitnuc_ctx_destroy(bitnuc_ctx *ctx);
+/* Wait for everything enqueued on the context's stream, then report (and clear)
+ * the first latched data error of the launches since the last sync. */
+int bitnuc_ctx_sync(bitnuc_ctx *ctx, bitnuc_err *err);
+/* The context's hipStream_t, for callers that order their own work against it. */
+void *bitnuc_ctx_stream(bitnuc_ctx *ctx);
+/* Library / build identification ("bitnuc_hip <ver> gfx950"). */
+const char *bitnuc_version(void);
+
+/* ---- single-word API (host) ------------------------------------------------- */
+/* as_2bit(seq:&[u8]) -> Result<u64>          src/utils/packing/mod.rs:80-110
+ * len > 32 -> SEQUENCE_TOO_LONG(len) before any base is looked at; first bad byte
+ * -> INVALID_BASE(byte); len == 0 -> OK, 0.  Runs as a batch of one on the GPU:
+ * for many k-mers use bitnuc_as_2bit_batch. */
+int bitnuc_as_2bit(bitnuc_ctx *ctx, const uint8_t *seq, size_t len, uint64_t *out, bitnuc_err *err);
+/* from_2bit(packed, expected_size, &mut Vec<u8>)  src/utils/unpacking/mod.rs:119-147
+ * n > 32 -> INVALID_LENGTH(n).  Writes exactly n bytes at out (the Vec append
+ * offset is the caller's: include/bitnuc.hpp, rust/src/lib.rs). */
+int bitnuc_from_2bit(bitnuc_ctx *ctx, uint64_t packed, size_t n, uint8_t *out, bitnuc_err *err);
+/* hdist_scalar(u, v, len) -> Result<u32>     src/utils/functions/hamming/scalar.rs:11-48 */
+int bitnuc_hdist_scalar(bitnuc_ctx *ctx, uint64_t u, uint64_t v, size_t len, uint32_t *out, bitnuc_err *err);
+
+/* ---- bulk API, host pointers (synchronous) ------------------------------------ */
+/* encode(sequence, &mut Vec<u64>)            src/utils/mod.rs:22-25 -> packing/avx.rs:130-151
+ * out must hold ceil(len/32) words.  On success *n_words = ceil(len/32), last word
+ * zero-padded high.  On INVALID_BASE: err.byte/err.index = first invalid byte of
+ * the whole sequence and *n_words = err.index/32 (the words the reference's Vec
+ * holds at that point); out[*n_words..] is unspecified.  len == 0 -> OK with 0
+ * words (the reference panics there; shims may mirror that). */
+int bitnuc_encode(bitnuc_ctx *ctx, const uint8_t *seq, size_t len, uint64_t *out, size_t *n_words, bitnuc_err *err);
+/* decode(ebuf, n_bases, &mut Vec<u8>)        src/utils/mod.rs:60-62 -> unpacking/avx.rs:116-153
+ * Writes n_bases bytes at out.  n_words < ceil(n_bases/32) -> INVALID_LENGTH(n_bases)
+ * (the rule of unpacking/mod.rs:40-45; the AVX2 path panics there). */
+int bitnuc_decode(bitnuc_ctx *ctx, const uint64_t *ebuf, size_t n_words, size_t n_bases, uint8_t *out, bitnuc_err *err);
+/* hdist(ebuf1, ebuf2, n_bases) -> Result<u32>  src/utils/functions/hamming/multi.rs:121-160 */
+int bitnuc_hdist(bitnuc_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, size_t n_bases, uint32_t *out, bitnuc_err *err);
+/* Batched as_2bit over `count` k-mers, k-mer j at kmers + j*stride (README.md:52-56
+ * host-loop idiom; stride 1 = every window of a sequence, src/lib.rs:170-173).
+ * k > 32 -> SEQUENCE_TOO_LONG(k).  First invalid examined byte -> INVALID_BASE. */
+int bitnuc_as_2bit_batch(bitnuc_ctx *ctx, const uint8_t *kmers, size_t k, size_t stride, size_t count, uint64_t *out, bitnuc_err *err);
+/* Sliding-window k-mer pack + Hamming distance to a packed query: dist[i] =
+ * hdist_scalar(as_2bit(ref[i..i+k]), query, k) for i in 0..n-k+1
+ * (composition of packing/mod.rs:80-110 and hamming/scalar.rs:11-48). */
+int bitnuc_kmer_hdist_scan(bitnuc_ctx *ctx, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist, bitnuc_err *err);
+
+/* ---- bulk API, device pointers (asynchronous on the context's stream) ------------ */
+/* The roofline entry points: inputs and outputs stay resident in HBM.  d_seq /
+ * d_out may have any alignment (16-byte aligned input is the fast path).
+ * Argument errors are returned immediately; InvalidBase is latched for
+ * bitnuc_ctx_sync(). */
+int bitnuc_encode_dev(bitnuc_ctx *ctx, const uint8_t *d_seq, size_t len, uint64_t *d_out, bitnuc_err *err);
+int bitnuc_decode_dev(bitnuc_ctx *ctx, const uint64_t *d_ebuf, size_t n_words, size_t n_bases, uint8_t *d_out, bitnuc_err *err);
+int bitnuc_as_2bit_batch_dev(bitnuc_ctx *ctx, const uint8_t *d_kmers, size_t k, size_t stride, size_t count, uint64_t *d_out, bitnuc_err *err);
+int bitnuc_kmer_hdist_scan_dev(bitnuc_ctx *ctx, const uint8_t *d_ref, size_t n, size_t k, uint64_t query, uint8_t *d_dist, bitnuc_err *err);
+/* d_result: one uint32 in device memory, overwritten with the distance. */
+int bitnuc_hdist_dev(bitnuc_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, size_t n_bases, uint32_t *d_result, bitnuc_err *err);
+
+/* ---- synthetic input (the reference's tests use nucgen::Sequence::fill_buffer,
+ * src/utils/mod.rs:116-121; its stream is unpinned, so the build ships its own) ---- */
+/* Fill d_out[0..len) with bases first..first+len of the seeded stream
+ * base(i) = "ACGT"[(splitmix64(seed + (i/32+1)*0x9E3779B97F4A7C15) >> 2*(i%32)) & 3];
+ * flags bit0: the benches' cyclic "ACGT"[i%4] pattern (benches/simd_comparison.rs:4-7). */
+int bitnuc_nucgen_dev(bitnuc_ctx *ctx, uint8_t *d_out, size_t len, uint64_t seed, uint64_t first, int flags, bitnuc_err *err);
+
+/* ---- tuning / diagnostics (not part of the drop-in surface) ---------------------- */
+/* Select kernel variants for experiments: key in {"encode","decode"}; returns the
+ * previous value or -1 for an unknown key. */
+int bitnuc_ctx_set_variant(bitnuc_ctx *ctx, const char *key, int value);
+/* Pure streaming kernels used to measure the box's HBM ceiling next to the codec:
+ * mode 0 = read-only sum of `bytes` from d_src; mode 1 = copy d_src -> d_dst;
+ * mode 2 = write-only fill of d_dst. */
+int bitnuc_stream_probe_dev(bitnuc_ctx *ctx, int mode, const void *d_src, void *d_dst, size_t bytes, bitnuc_err *err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BITNUC_HIP_H */
