@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE configs[1]:
+"Gbases/s encode+decode on 10^9-base synthetic; % of HBM3E roofline".
+
+A step = one pass of the hot path over one batch: bulk-encode 10^9 device-resident
+ASCII bases to 2-bit words, then bulk-decode them back (two kernel launches through the
+C ABI's device-pointer entry points).  Weak scaling: every rank (one process per GPU)
+owns its own 10^9-base shard; there is no data-path collective (the optional
+concatenating all-gather of config 4 is timed separately, outside the step).
+
+value = bases pushed through the codec per second, whole job:
+        N_gpus * (10^9 encoded + 10^9 decoded) / step time / 1e9   [Gbases/s]
+        (x 1.25 algorithmic bytes per base = aggregate algorithmic GB/s).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
+BYTES_PER_BASE = 1.25          # encode: 1 read + 0.25 write; decode: 0.25 read + 1 write
+SEED = 0xB17C0DE
+
+
+def cpu_baseline(n_sample, reps, all_cores):
+    """Reference-algorithm restatement (oracle/bitnuc_avx2.c, the reference's AVX2 path as
+    written) timed on this host.  kind = "port": the Rust reference cannot be built here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_py
+    seq = oracle_py.nucgen(n_sample, SEED)
+    enc, dec = [], []
+    for _ in range(reps):
+        e, d = oracle_py.avx2_time_roundtrip(seq)
+        enc.append(e)
+        dec.append(d)
+    e1, d1 = statistics.median(enc), statistics.median(dec)
+    out = {"value": round(2 * n_sample / (e1 + d1) / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
+           "sample": f"{n_sample:.3g} bases of the same seeded stream, encode+decode, median of {reps}",
+           "encode_gbases_s": round(n_sample / e1 / 1e9, 4), "decode_gbases_s": round(n_sample / d1 / 1e9, 4),
+           "what": "C restatement of the reference's AVX2 path as written (oracle/bitnuc_avx2.c); "
+                   "the reference itself is single-threaded Rust and cannot be built in this image"}
+    if all_cores:
+        cores = os.cpu_count() or 1
+        per = (n_sample // cores) // 32 * 32
+        if per > 0:
+            res = [None] * cores
+
+            def work(i):
+                res[i] = oracle_py.avx2_time_roundtrip(seq[i * per:(i + 1) * per])
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            wall = time.perf_counter() - t0
+            out["all_cores"] = {"value": round(2 * per * cores / wall / 1e9, 4), "cores": cores,
+                                "note": "courtesy split at 32-base boundaries over threads; the reference has no threading"}
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["cpu"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bases", type=int, default=10**9, help="bases per GPU per step (BASELINE configs[1]: 1e9)")
+    ap.add_argument("--rotate", type=int, default=3, help="buffer sets rotated so the 256 MiB Infinity Cache cannot serve a step")
+    ap.add_argument("--enc-variant", type=int, default=-1)
+    ap.add_argument("--dec-variant", type=int, default=-1)
+    ap.add_argument("--grid-mult", type=int, default=-1)
+    ap.add_argument("--cpu-sample", type=int, default=250_000_000)
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe", action="store_true", help="also time pure read/copy/fill kernels (the box's own HBM ceiling)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import bitnuc_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.bases
+    nw = (n + 31) // 32
+    stream = torch.cuda.current_stream()
+    ctx = bitnuc_amd.Context(local_rank, stream=stream.cuda_stream)
+    if args.enc_variant >= 0:
+        ctx.set_variant("encode", args.enc_variant)
+    if args.dec_variant >= 0:
+        ctx.set_variant("decode", args.dec_variant)
+    if args.grid_mult >= 0:
+        ctx.set_variant("grid_mult", args.grid_mult)
+
+    R = max(1, args.rotate)
+    seqs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
+    words = [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)]
+    backs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
+    for r in range(R):  # rank-disjoint slices of one seeded stream, generated in place on the device
+        ctx.nucgen_dev(seqs[r], n, SEED + r, first=rank * n)
+    ctx.sync()
+
+    def step(i, ev=None):
+        r = i % R
+        if ev:
+            ev[0].record(stream)
+        ctx.encode_dev(seqs[r], n, words[r])
+        if ev:
+            ev[1].record(stream)
+        ctx.decode_dev(words[r], nw, n, backs[r])
+        if ev:
+            ev[2].record(stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.sync()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    fence()
+    t1 = time.perf_counter()
+    ctx.sync()  # raises if any launch latched an InvalidBase
+
+    # parity guard inside the bench: the last step's round trip must be the identity
+    r_last = (args.steps - 1) % R
+    assert torch.equal(seqs[r_last], backs[r_last]), "decode(encode(x)) != x"
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    sec_per_step = float(elapsed.item()) / args.steps
+    enc_ms = [e[0].elapsed_time(e[1]) for e in events]
+    dec_ms = [e[1].elapsed_time(e[2]) for e in events]
+    enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
+
+    extra = {}
+    if world > 1:  # config 4's concatenation, reported beside the step, never inside it
+        from bitnuc_amd.dist import allgather_packed
+        allgather_packed(words[0])
+        fence()
+        t = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            full = allgather_packed(words[0])
+        fence()
+        ag = (time.perf_counter() - t) / reps
+        del full
+        extra["allgather_packed"] = {"ms": round(ag * 1e3, 3), "bytes_received_per_gpu": nw * 8 * (world - 1),
+                                     "gb_s_per_gpu": round(nw * 8 * (world - 1) / ag / 1e9, 2),
+                                     "note": "RCCL all-gather of the packed u64 buffer over xGMI; fabric-bound, outside the timed step"}
+    if args.probe:
+        probe = {}
+        for name, mode, nbytes in [("read", 0 | 8, n), ("copy", 1 | 8, n), ("fill", 2 | 8, n), ("read_plain", 0, n), ("copy_plain", 1, n)]:
+            ms = []
+            for i in range(10):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                ctx.stream_probe_dev(mode, seqs[i % R], backs[(i + 1) % R], nbytes)
+                b.record(stream)
+                torch.cuda.synchronize()
+                ms.append(a.elapsed_time(b))
+            moved = nbytes * (2 if (mode & 7) == 1 else 1)
+            probe[name] = round(moved / (statistics.median(ms) * 1e-3) / 1e9, 1)
+        extra["stream_probe_gb_s"] = probe
+
+    if rank == 0:
+        total_bases = world * 2 * n  # encoded + decoded, all ranks, per step
+        enc_gbs = n * BYTES_PER_BASE / (enc_avg * 1e-3) / 1e9
+        dec_gbs = n * BYTES_PER_BASE / (dec_avg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/prof_summary.py from a --pmc run
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("encode_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Gbases/s encode+decode on 10^9-base synthetic; % of HBM3E roofline",
+            "value": round(total_bases / sec_per_step / 1e9, 2),
+            "unit": "Gbases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident, bit-exact vs CPU oracle",
+                       "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
+                       "seed": hex(SEED), "rotating_buffer_sets": R,
+                       "encode_variant": ctx.get("encode"), "decode_variant": ctx.get("decode"), "grid_mult": ctx.get("grid_mult"),
+                       "parallelism": f"shard{world}" if world > 1 else "single"},
+            "roofline": {"kernel": "encode_kernel", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(enc_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(enc_avg, 4),
+                         "gbases_s": round(n / (enc_avg * 1e-3) / 1e9, 1)},
+            "roofline_decode": {"kernel": "decode_kernel", "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(dec_avg, 4),
+                                "gbases_s": round(n / (dec_avg * 1e-3) / 1e9, 1)},
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""One-process-per-GPU sharding of the codec (torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" on CPU for tests).
+
+u64 words never share state (the reference's chunk loop has no carry,
+src/utils/packing/avx.rs:138-145), so any partition at a multiple of 32 bases is
+exact: rank r encodes its shard with no communication.  The only exchange the path
+has is the optional final concatenation of the packed buffer (BASELINE config 4):
+one all-gather of the per-rank u64 words.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_bases, rank, world):
+    """Contiguous, 32-base-aligned shard [start, stop) of n_bases for `rank` of `world`.
+    Shards differ by at most one word; the last shard takes the ragged tail."""
+    n_words = (n_bases + 31) // 32
+    base, extra = divmod(n_words, world)
+    w0 = rank * base + min(rank, extra)
+    w1 = w0 + base + (1 if rank < extra else 0)
+    return min(w0 * 32, n_bases), min(w1 * 32, n_bases)
+
+
+def shard_word_counts(n_bases, world):
+    return [(b - a + 31) // 32 for a, b in (shard_range(n_bases, r, world) for r in range(world))]
+
+
+def allgather_packed(local_words, counts=None, group=None):
+    """All-gather per-rank packed words (1-D int64/uint64-as-int64 tensors) into the
+    concatenation every rank holds.  Equal counts use the single-buffer in-place form
+    (rank r's shard already sits at offset r*count of the output: no staging copy);
+    ragged counts pad to the maximum and trim."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if counts is None:
+        counts = [local_words.numel()] * world
+    assert counts[rank] == local_words.numel()
+    if len(set(counts)) == 1:
+        out = torch.empty(world * counts[0], dtype=local_words.dtype, device=local_words.device)
+        out[rank * counts[0]:(rank + 1) * counts[0]].copy_(local_words)
+        dist.all_gather_into_tensor(out, out[rank * counts[0]:(rank + 1) * counts[0]], group=group)
+        return out
+    m = max(counts)
+    padded = torch.zeros(m, dtype=local_words.dtype, device=local_words.device)
+    padded[: counts[rank]].copy_(local_words)
+    gathered = torch.empty(world * m, dtype=local_words.dtype, device=local_words.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    return torch.cat([gathered[r * m: r * m + counts[r]] for r in range(world)])
+
+
+def encode_sharded(encode_fn, seq_shard, n_total, group=None):
+    """Encode this rank's shard with `encode_fn(seq_shard) -> 1-D int64 words` (on GPU:
+    Context.encode_dev into a torch tensor) and all-gather the packed words.
+    `seq_shard` must be the bytes of shard_range(n_total, rank, world)."""
+    world = dist.get_world_size(group)
+    counts = shard_word_counts(n_total, world)
+    words = encode_fn(seq_shard)
+    return allgather_packed(words, counts, group)

@@ -1,0 +1,59 @@
+"""CPU tests of the drop-in boundary: libbitnuc_hip.so loads, exports every symbol
+include/bitnuc_hip.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bitnuc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bitnuc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_reference_surface():
+    syms = declared_symbols()
+    # one entry point per reference function on the path (src/lib.rs:214-220)
+    for name in ["bitnuc_as_2bit", "bitnuc_from_2bit", "bitnuc_encode", "bitnuc_decode",
+                 "bitnuc_hdist_scalar", "bitnuc_hdist", "bitnuc_encode_dev", "bitnuc_decode_dev",
+                 "bitnuc_as_2bit_batch", "bitnuc_kmer_hdist_scan"]:
+        assert name in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from bitnuc_amd import _lib
+    lib = _lib.load()
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/bitnuc_hip.h but not exported"
+    assert set(declared_symbols()) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert b"gfx950" in lib.bitnuc_version()
+
+
+def test_no_oracle_in_product():
+    # the product must not route through the oracle or any CPU fallback
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bitnuc_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle_py" not in src and "bitnuc_oracle" not in src and "orc_" not in src, f
+    hpp = open(os.path.join(ROOT, "include", "bitnuc.hpp")).read()
+    assert "oracle" not in hpp.lower()
+
+
+def test_struct_layout_matches_header():
+    from bitnuc_amd import _lib
+    assert C.sizeof(_lib.BitnucErr) == 32
+    assert _lib.BitnucErr.value.offset == 8 and _lib.BitnucErr.index.offset == 16 and _lib.BitnucErr.byte.offset == 24
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import bitnuc_amd
+    with pytest.raises(bitnuc_amd.BackendError):
+        bitnuc_amd.Context(0)

@@ -1,0 +1,415 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+C ABI, against the CPU oracle on identical inputs, against the reference's golden
+vectors, and -- at BASELINE sizes -- through size-independent properties.
+Bar: bit-exact (integer / byte work)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RNG = np.random.default_rng(0xB17C0DE)
+ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
+ALPHA8 = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+
+
+def rand_seq(n, alpha=ALPHA8):
+    return alpha[RNG.integers(0, len(alpha), size=n)]
+
+
+# ---- golden vectors through the reference-named API -----------------------------------
+def test_golden_as_2bit(ctx, golden):
+    import bitnuc_amd as bn
+    for v in golden["as_2bit"]:
+        assert ctx.as_2bit(v["seq"].encode()) == v["packed"], v["src"]
+    ci = golden["as_2bit_case_insensitive"]
+    assert ctx.as_2bit(ci["lower"].encode()) == ctx.as_2bit(ci["upper"].encode())
+    assert ctx.as_2bit(b"") == 0
+    for v in golden["as_2bit_err"]:
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.as_2bit(v["seq"].encode())
+        assert ei.value.kind == v["status"], v["src"]
+        if "byte" in v:
+            assert ei.value.byte == v["byte"]
+        if "value" in v:
+            assert ei.value.len == v["value"]
+    assert bn.NucleotideError("InvalidBase", byte=ord("N")) == pytest.raises(bn.NucleotideError, ctx.as_2bit, b"ACGN").value
+
+
+def test_golden_from_2bit(ctx, golden):
+    import bitnuc_amd as bn
+    unpacked = bytearray()
+    for v in golden["from_2bit"]:
+        ctx.from_2bit(v["packed"], v["n"], unpacked)
+        assert bytes(unpacked) == v["seq"].encode(), v["src"]
+        unpacked.clear()
+    for v in golden["from_2bit_err"]:
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.from_2bit(v["packed"], v["n"], bytearray())
+        assert ei.value.kind == v["status"] and ei.value.len == v["value"]
+    for v in golden["from_2bit_append"]:  # append semantics, unpacking/avx.rs:185-194
+        p = ctx.as_2bit(v["seq"].encode())
+        obs = bytearray()
+        for _ in range(v["calls"]):
+            ctx.from_2bit(p, v["n"], obs)
+        assert bytes(obs) == v["expected"].encode()
+    rp = golden["roundtrip_prefixes"]
+    for n in range(rp["lens"][0], rp["lens"][1] + 1):
+        b = rp["seq"].encode()[:n]
+        assert ctx.from_2bit_alloc(ctx.as_2bit(b), n) == b
+    for s in golden["roundtrip_strings"]["cases"]:
+        assert ctx.from_2bit_alloc(ctx.as_2bit(s.encode()), len(s)) == s.encode()
+
+
+def test_golden_roundtrip_all_lengths(ctx, golden, oracle):
+    # src/utils/mod.rs:113-133 -- encode/decode round trip for every length 1..=1000
+    lo, hi = golden["roundtrip_lengths"]["lens"]
+    for n in range(lo, hi + 1):
+        s = rand_seq(n, ALPHA)
+        ebuf = [123]  # encode clears the Vec first
+        ctx.encode(s, ebuf)
+        assert len(ebuf) == (n + 31) // 32
+        assert np.array_equal(np.array(ebuf, dtype=np.uint64), oracle.encode(s))
+        dbuf = bytearray(b"xy")  # decode appends
+        ctx.decode(ebuf, n, dbuf)
+        assert bytes(dbuf) == b"xy" + s.tobytes()
+
+
+def test_golden_hdist(ctx, golden, oracle):
+    import bitnuc_amd as bn
+    for v in golden["hdist_scalar"]:
+        assert ctx.hdist_scalar(v["u"], v["v"], v["len"]) == v["d"], v["src"]
+    for a, b, d in golden["hdist_scalar_strings"]["cases"]:
+        assert ctx.hdist_scalar(ctx.as_2bit(a.encode()), ctx.as_2bit(b.encode()), len(a)) == d
+    for v in golden["hdist_scalar_err"]:
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.hdist_scalar(v["u"], v["v"], v["len"])
+        assert ei.value.kind == v["status"] and ei.value.len == v["value"]
+    for v in golden["hdist_err"]:
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.hdist([0] * v["na"], [0] * v["nb"], v["n_bases"])
+        assert ei.value.kind == v["status"] and ei.value.len == v["value"]
+    for v in golden["hdist"]:
+        a, b = ctx.encode_alloc(v["seq1"].encode()), ctx.encode_alloc(v["seq2"].encode())
+        assert ctx.hdist(a, b, len(v["seq1"])) == v["d"], v["src"]
+    lo, hi = golden["hdist_A_vs_T"]["lens"]
+    for n in range(lo, hi + 1):
+        assert ctx.hdist(ctx.encode_alloc(b"A" * n), ctx.encode_alloc(b"T" * n), n) == n
+    for v in golden["hdist_cyclic"]:
+        s1 = np.array([ALPHA[i % v["mod1"]] for i in range(v["l"])], dtype=np.uint8)
+        s2 = np.array([ALPHA[i % v["mod2"]] for i in range(v["l"])], dtype=np.uint8)
+        assert ctx.hdist(ctx.encode_alloc(s1), ctx.encode_alloc(s2), v["l"]) == int((s1 != s2).sum())
+
+
+def test_kmer_count_doc_example(ctx, golden):
+    v = golden["kmer_count"]
+    seq = v["seq"].encode()
+    words = ctx.as_2bit_batch(seq, v["k"], stride=1)
+    assert int((words == ctx.as_2bit(v["kmer"].encode())).sum()) == v["count"]
+
+
+# ---- bulk encode / decode vs oracle, every kernel variant ------------------------------
+SIZES = [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, 4095, 4096, 4097, 16384 * 4 + 5, 1000003, (1 << 22) + 17]
+
+
+@pytest.mark.parametrize("variant", range(14))
+def test_encode_decode_variants_vs_oracle(ctx, oracle, variant):
+    assert ctx.get("num_variants") == 14
+    ctx.set_variant("encode", variant)
+    ctx.set_variant("decode", variant)
+    try:
+        for n in SIZES:
+            s = rand_seq(n)
+            w = ctx.encode_array(s)
+            exp = oracle.encode(s)
+            assert np.array_equal(w, exp), (variant, n)
+            d = ctx.decode_array(w, n)
+            assert np.array_equal(d, oracle.decode(exp, n)), (variant, n)
+            assert bytes(d) == bytes(s).upper()
+    finally:
+        ctx.set_variant("encode", 1)
+        ctx.set_variant("decode", 1)
+
+
+@pytest.mark.parametrize("grid_mult", [0, 1, 8])
+def test_grid_shapes(ctx, oracle, grid_mult):
+    prev = ctx.set_variant("grid_mult", grid_mult)
+    try:
+        for n in [5, 70000, 3000017]:
+            s = rand_seq(n)
+            w = ctx.encode_array(s)
+            assert np.array_equal(w, oracle.encode(s))
+            assert np.array_equal(ctx.decode_array(w, n), oracle.decode(w, n))
+    finally:
+        ctx.set_variant("grid_mult", prev)
+
+
+def test_decode_ignores_bits_above_n(ctx, oracle):
+    w = RNG.integers(0, 1 << 63, size=40, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    for n in [1, 33, 40 * 32 - 1, 40 * 32 - 31, 40 * 32]:
+        assert np.array_equal(ctx.decode_array(w, n), oracle.decode(w, n))
+
+
+def test_invalid_base_first_in_sequence_order(ctx, oracle):
+    import bitnuc_amd as bn
+    for n in [20, 33, 1000, 70001]:
+        for pos in sorted({0, 15, 16, 31, 32, n // 2, n - 17 if n > 17 else 0, n - 1}):
+            for bad in (ord("N"), 0x00, 0xFF, ord("@"), ord("B"), ord("u")):
+                s = rand_seq(n).copy()
+                s[pos] = bad
+                if pos + 40 < n:
+                    s[pos + 40] = ord("X")  # a later invalid byte must not win
+                with pytest.raises(oracle.OracleError) as oe:
+                    oracle.encode(s)
+                ebuf = []
+                with pytest.raises(bn.NucleotideError) as ge:
+                    ctx.encode(s, ebuf)
+                assert (ge.value.kind, ge.value.byte, ge.value.index) == ("InvalidBase", oe.value.byte, oe.value.index) == ("InvalidBase", bad, pos)
+                # the Vec holds the words of the chunks before the failing one (avx.rs:142)
+                assert np.array_equal(np.array(ebuf, dtype=np.uint64), oe.value.words)
+    # a context keeps working after an error
+    assert ctx.as_2bit(b"ACGT") == 0xE4
+
+
+def test_all_256_byte_values(ctx):
+    import bitnuc_amd as bn
+    valid = {b: i for i, ch in enumerate(b"ACGT") for b in (ch, ch | 0x20)}
+    for b in range(256):
+        s = np.full(64, ord("A"), dtype=np.uint8)
+        s[37] = b
+        if b in valid:
+            w = ctx.encode_array(s)
+            assert int(w[1]) == valid[b] << (2 * 5) and int(w[0]) == 0
+        else:
+            with pytest.raises(bn.NucleotideError) as ei:
+                ctx.encode_array(s)
+            assert (ei.value.byte, ei.value.index) == (b, 37)
+
+
+def test_argument_errors(ctx):
+    import bitnuc_amd as bn
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.decode_array(np.zeros(1, np.uint64), 33)  # unpacking/mod.rs:40-45
+    assert ei.value.kind == "InvalidLength" and ei.value.len == 33
+    assert ctx.decode_array(np.zeros(0, np.uint64), 0).size == 0  # n_bases = 0 -> Ok, nothing
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.as_2bit(b"N" * 33)  # length checked before bases
+    assert ei.value.kind == "SequenceTooLong" and ei.value.len == 33
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.as_2bit_batch(b"A" * 100, 33)
+    assert ei.value.kind == "SequenceTooLong"
+    with pytest.raises(RuntimeError):
+        ctx.encode_array(b"")  # the reference panics on empty input
+
+
+# ---- device-pointer path, unaligned pointers, async error latch ---------------------------
+def test_dev_path_unaligned_and_async_errors(ctx, oracle):
+    import torch
+    import bitnuc_amd as bn
+    dev = torch.device("cuda:0")
+    n = 300007
+    s = rand_seq(n)
+    for in_off in (0, 1, 3, 8, 13):
+        for out_off in (0, 5):
+            buf = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+            buf[in_off:in_off + n] = torch.from_numpy(s).to(dev)
+            words = torch.zeros((n + 31) // 32 + 2, dtype=torch.int64, device=dev)
+            back = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ctx.encode_dev(buf.data_ptr() + in_off, n, words.data_ptr() + 8)  # 8-byte aligned only
+            ctx.decode_dev(words.data_ptr() + 8, (n + 31) // 32, n, back.data_ptr() + out_off)
+            ctx.sync()
+            w = words.cpu().numpy().view(np.uint64)
+            assert w[0] == 0 and w[-1] == 0  # no stray writes around the packed buffer
+            assert np.array_equal(w[1:-1], oracle.encode(s))
+            b = back.cpu().numpy()
+            assert bytes(b[out_off:out_off + n]) == bytes(s).upper()
+            assert not b[:out_off].any() and not b[out_off + n:].any()
+    # errors are latched per launch and reported in launch order at sync
+    good = torch.from_numpy(s).to(dev)
+    bad1 = good.clone(); bad1[1234] = ord("N")
+    bad2 = good.clone(); bad2[7] = ord("Z")
+    words = torch.zeros((n + 31) // 32, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.encode_dev(good, n, words)
+    ctx.encode_dev(bad1, n, words)
+    ctx.encode_dev(bad2, n, words)
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.sync()
+    assert (ei.value.byte, ei.value.index) == (ord("N"), 1234)
+    ctx.sync()  # cleared
+
+
+def test_nucgen_matches_host_generator(ctx, oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    for n, first, flags in [(1000, 0, 0), (100003, 32 * 77, 0), (4097, 5, 0), (333, 1 << 40, 0), (1000, 3, 1), (70, 0, 1)]:
+        t = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.nucgen_dev(t, n, 0xB17C0DE, first, flags)
+        ctx.sync()
+        h = t.cpu().numpy()
+        assert np.array_equal(h[:n], oracle.nucgen(n, 0xB17C0DE, first, flags)), (n, first, flags)
+        assert not h[n:].any()
+
+
+# ---- k-mer batch and scan ---------------------------------------------------------------------
+@pytest.mark.parametrize("k,stride", [(31, 31), (31, 32), (32, 32), (1, 1), (4, 1), (21, 21), (31, 1), (16, 50),
+                                      (31, 64), (31, 65), (27, 200), (32, 33), (3, 7)])
+def test_kmer_batch_vs_oracle(ctx, oracle, k, stride):
+    for count in [1, 2, 255, 256, 257, 10007]:
+        s = rand_seq((count - 1) * stride + k)
+        got = ctx.as_2bit_batch(s, k, stride, count)
+        assert np.array_equal(got, oracle.as_2bit_batch(s, k, stride, count)), (k, stride, count)
+
+
+def test_kmer_batch_errors(ctx, oracle):
+    import bitnuc_amd as bn
+    k, stride, count = 31, 40, 3000
+    s = rand_seq((count - 1) * stride + k).copy()
+    s[stride * 100 + 35] = ord("N")   # in a gap between k-mers: not examined
+    assert np.array_equal(ctx.as_2bit_batch(s, k, stride, count), oracle.as_2bit_batch(s, k, stride, count))
+    s[stride * 2000 + 30] = ord("N")
+    s[stride * 1500 + 3] = ord("Q")
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.as_2bit_batch(s, k, stride, count)
+    with pytest.raises(oracle.OracleError) as oe:
+        oracle.as_2bit_batch(s, k, stride, count)
+    assert (ei.value.byte, ei.value.index) == (oe.value.byte, oe.value.index) == (ord("Q"), stride * 1500 + 3)
+    assert np.array_equal(ctx.as_2bit_batch(b"", 0, 1, 5), np.zeros(5, np.uint64))
+
+
+@pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 32])
+def test_scan_vs_oracle(ctx, oracle, k):
+    for n in [k, k + 1, 1000, 1055, 1056, 1057, 2079, 2080, 2081, 5000, 200003]:
+        s = rand_seq(n)
+        q = int(RNG.integers(0, 1 << 62)) | (int(RNG.integers(0, 4)) << 62)
+        got = ctx.kmer_hdist_scan(s, k, q)
+        assert np.array_equal(got, oracle.kmer_hdist_scan(s, k, q)), (k, n)
+
+
+def test_scan_errors_and_bench_invariant(ctx, oracle):
+    import bitnuc_amd as bn
+    s = rand_seq(50000).copy()
+    for pos in (0, 1023, 1024, 1040, 1055, 30000, 49999):
+        t = s.copy()
+        t[pos] = ord("N")
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.kmer_hdist_scan(t, 31, 0)
+        assert (ei.value.byte, ei.value.index) == (ord("N"), pos)
+    assert ctx.kmer_hdist_scan(s[:10], 31, 0).size == 0
+    with pytest.raises(bn.NucleotideError):
+        ctx.kmer_hdist_scan(s, 33, 0)
+    # hdist_benchmark.rs:17-37 shape: cyc-4 reference vs the cyc-3 32-mer as query
+    ref = np.array([ALPHA[i % 4] for i in range(4096)], dtype=np.uint8)
+    qs = np.array([ALPHA[i % 3] for i in range(32)], dtype=np.uint8)
+    d = ctx.kmer_hdist_scan(ref, 32, ctx.as_2bit(qs))
+    for i in range(8):
+        assert d[i] == int((ref[i:i + 32] != qs).sum())
+
+
+def test_hdist_bulk_vs_oracle(ctx, oracle):
+    for n in [1, 31, 32, 33, 127, 128, 129, 100000, 1000003]:
+        a, b = rand_seq(n, ALPHA), rand_seq(n, ALPHA)
+        wa, wb = oracle.encode(a), oracle.encode(b)
+        assert ctx.hdist(wa, wb, n) == oracle.hdist(wa, wb, n) == int((a != b).sum())
+    # bits above n_bases in the last word are ignored (scalar.rs:26-33)
+    wa = np.array([0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+    wb = np.array([0], dtype=np.uint64)
+    for n in range(0, 33):
+        assert ctx.hdist(wa, wb, n) == n == oracle.hdist(wa, wb, n)
+
+
+# ---- BASELINE-size properties (config 2: 10^9 bases on one GPU) ---------------------------
+def test_full_size_roundtrip_and_checksums(ctx, oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    n = 10**9 + 17  # tailed on purpose; BASELINE config 2 is 10^9
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, n, 0xB17C0DE)
+    nw = (n + 31) // 32
+    words = torch.empty(nw, dtype=torch.int64, device=dev)
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.encode_dev(seq, n, words)
+    ctx.decode_dev(words, nw, n, back)
+    ctx.sync()
+    assert torch.equal(seq, back)  # encode -> decode is the identity on uppercase input
+    # generator words ARE the packed words (base i = 2-bit field i of mix(seed, i/32)):
+    # an independent closed form for the whole 250 MB output, checked by 64-bit sums per block
+    idx = torch.arange(1, nw + 1, dtype=torch.int64, device=dev)
+    z = idx * (-7046029254386353131) + 0xB17C0DE  # 0x9E3779B97F4A7C15 as i64, wraps mod 2^64
+
+    def lsr(x, s):  # logical shift right on int64
+        return (x >> s) & ((1 << (64 - s)) - 1)
+    z = (z ^ lsr(z, 30)) * (-4658895280553007687)   # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * (-7723592293110705685)   # 0x94D049BB133111EB
+    z = z ^ lsr(z, 31)
+    z[-1] &= (1 << (2 * (n % 32))) - 1              # last word: 17 bases, zero-padded high
+    assert torch.equal(words, z)
+    # spot-check blocks against the CPU oracle
+    for off in (0, 32 * 1_000_000, (n // 32 - 4096) * 32):
+        m = min(32 * 4096, n - off)
+        h = seq[off:off + m].cpu().numpy()
+        assert np.array_equal(words[off // 32: off // 32 + (m + 31) // 32].cpu().numpy().view(np.uint64), oracle.encode(h))
+    # linearity-style property: encoding two halves separately == encoding the whole
+    half = (n // 64) * 32
+    w2 = torch.empty(nw, dtype=torch.int64, device=dev)
+    ctx.encode_dev(seq, half, w2)
+    ctx.encode_dev(seq.data_ptr() + half, n - half, w2.data_ptr() + half // 4)
+    ctx.sync()
+    assert torch.equal(words, w2)
+    # a single invalid byte deep inside 10^9 bases is found exactly
+    seq[987_654_321] = ord("N")
+    torch.cuda.synchronize()
+    ctx.encode_dev(seq, n, words)
+    import bitnuc_amd as bn
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.sync()
+    assert (ei.value.byte, ei.value.index) == (ord("N"), 987_654_321)
+
+
+def test_kmer_config3_and_scan_config5_properties(ctx, oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    count, k = 10**8, 31
+    seq = torch.empty(count * k, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, count * k, 0xB17C0DE)
+    out = torch.empty(count, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.as_2bit_batch_dev(seq, k, k, count, out)
+    ctx.sync()
+    assert int((out >> 62).abs().max()) == 0  # 31-mers use 62 bits
+    for j0 in (0, 12_345_678, count - 5000):
+        h = seq[j0 * k:(j0 + 5000) * k].cpu().numpy()
+        assert np.array_equal(out[j0:j0 + 5000].cpu().numpy().view(np.uint64), oracle.as_2bit_batch(h, k, k, 5000))
+    # scan over 10^9 bases: spot blocks vs oracle + "distance to itself is 0" at planted sites
+    n = 10**9
+    ref = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(ref, n, 0xB17C0DE)
+    qpos = 777_777_777
+    q = oracle.as_2bit(ref[qpos:qpos + k].cpu().numpy())
+    dist = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.kmer_hdist_scan_dev(ref, n, k, q, dist)
+    ctx.sync()
+    assert int(dist[qpos]) == 0
+    assert int(dist.max()) <= k
+    for off in (0, qpos - 3000, n - k + 1 - 6000):
+        h = ref[off:off + 6000 + k - 1].cpu().numpy()
+        assert np.array_equal(dist[off:off + 6000].cpu().numpy(), oracle.kmer_hdist_scan(h, k, q))
+
+
+def test_cpp_host_layer(ctx):
+    """include/bitnuc.hpp (the compiled mirror of the reference's Rust API) against the
+    reference's own unit-test cases, via tests/cpp/test_bitnuc_hpp.cpp."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "test_bitnuc_hpp")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "test_bitnuc_hpp.cpp"),
+                    "-L", os.path.join(root, "bitnuc_amd"), "-lbitnuc_hip",
+                    "-Wl,-rpath," + os.path.join(root, "bitnuc_amd"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL OK" in out.stdout
