@@ -47,7 +47,8 @@ def cpu_baseline(n_sample, reps, all_cores):
            "what": "C restatement of the reference's AVX2 path as written (oracle/bitnuc_avx2.c); "
                    "the reference itself is single-threaded Rust and cannot be built in this image"}
     if all_cores:
-        cores = os.cpu_count() or 1
+        # a one-GPU box's CPU share is 16 cores (os.cpu_count() reports the whole host)
+        cores = min(len(os.sched_getaffinity(0)), 16)
         per = (n_sample // cores) // 32 * 32
         if per > 0:
             res = [None] * cores

@@ -41,8 +41,8 @@ struct bitnuc_ctx {
     uint8_t *scratch[3] = {nullptr, nullptr, nullptr};
     size_t scratch_cap[3] = {0, 0, 0};
     uint32_t *d_sink = nullptr;
-    int enc_variant = 1, dec_variant = 1;
-    int grid_mult = 8; // blocks per CU for grid-stride launches; 0 = one tile per block
+    int enc_variant = 3, dec_variant = 13; // kDefaultEnc / kDefaultDec
+    int grid_mult = 0;                   // see grid_for()
 };
 
 namespace {
@@ -130,42 +130,72 @@ int take_slot(bitnuc_ctx *c, const uint8_t *src, unsigned long long base, unsign
     return BITNUC_OK;
 }
 
-unsigned grid_for(const bitnuc_ctx *c, unsigned long long tiles) {
+// grid_mult = resident 256-thread workgroups per CU for grid-stride launches (scaled
+// for other block sizes); 0 = one tile per workgroup, the hardware dispatcher walks the
+// tiles (fastest for the streaming codec: no tail imbalance -- profiles/).
+unsigned grid_for(const bitnuc_ctx *c, unsigned long long tiles, int block = kBlock) {
     if (tiles == 0) return 1;
     if (c->grid_mult <= 0) return (unsigned)(tiles < 0x7FFFFFFFull ? tiles : 0x7FFFFFFFull);
-    const unsigned long long cap = (unsigned long long)c->num_cu * c->grid_mult;
+    unsigned long long cap = (unsigned long long)c->num_cu * c->grid_mult * kBlock / block;
+    if (cap == 0) cap = 1;
     return (unsigned)(tiles < cap ? tiles : cap);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- kernel-variant tables -------------------------------------------------------
-struct Variant { int vpl, unroll; bool nt, xpose; };
-constexpr Variant kVariants[] = {
-    {1, 4, false, false}, // 0
-    {1, 4, true, false},  // 1  (default)
-    {1, 8, false, false}, // 2
-    {1, 8, true, false},  // 3
-    {1, 2, true, false},  // 4
-    {2, 2, true, false},  // 5
-    {2, 4, true, false},  // 6
-    {4, 1, true, false},  // 7
-    {4, 2, true, false},  // 8
-    {1, 4, false, true},  // 9  LDS transpose
-    {1, 4, true, true},   // 10 LDS transpose, nt
-    {1, 1, true, false},  // 11
-    {4, 2, false, false}, // 12
-    {2, 4, false, false}, // 13
-};
-constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+//              id  UNROLL BLOCK NTLD   NTST   XPOSE  XCD
+#define BITNUC_VARIANTS(X)                            \
+    X(0, 4, 256, false, false, false, false)          \
+    X(1, 4, 256, true, true, false, false)            \
+    X(2, 2, 256, true, true, false, false)            \
+    X(3, 2, 256, true, false, false, false)           \
+    X(4, 2, 256, false, false, false, false)          \
+    X(5, 4, 256, true, false, false, false)           \
+    X(6, 1, 256, true, false, false, false)           \
+    X(7, 2, 512, true, false, false, false)           \
+    X(8, 2, 1024, true, false, false, false)          \
+    X(9, 4, 256, false, false, true, false)           \
+    X(10, 4, 256, true, true, true, false)            \
+    X(11, 4, 256, true, false, true, false)           \
+    X(12, 2, 256, true, false, false, true)           \
+    X(13, 4, 256, false, false, false, true)          \
+    X(14, 2, 128, true, false, false, false)          \
+    X(15, 8, 256, true, false, false, false)          \
+    X(16, 4, 512, false, false, false, false)         \
+    X(17, 2, 512, false, false, false, false)         \
+    X(18, 4, 256, false, true, false, false)          \
+    X(19, 4, 512, true, false, true, false)           \
+    X(20, 1, 256, false, false, false, false)         \
+    X(21, 1, 512, true, false, false, false)          \
+    X(22, 2, 256, false, true, false, false)          \
+    X(23, 4, 1024, false, false, false, false)        \
+    X(24, 2, 256, false, false, false, true)          \
+    X(25, 4, 256, true, false, false, true)           \
+    X(26, 8, 256, false, false, false, true)          \
+    X(27, 4, 512, false, false, false, true)          \
+    X(28, 4, 256, false, false, true, true)           \
+    X(29, 1, 256, false, false, false, true)
+constexpr int kNumVariants = 30;
+// defaults from the interleaved sweeps in profiles/ (10^9 bases, one tile per workgroup):
+//   encode: nt loads + plain stores, 2 groups in flight per lane   -> 6.76 TB/s algorithmic
+//   decode: plain loads/stores, 4 groups per lane, XCD-contiguous  -> 6.71 TB/s algorithmic
+constexpr int kDefaultEnc = 3, kDefaultDec = 13;
 
-template <int VPL, int UNROLL, bool NT, bool XPOSE>
+struct VariantInfo { int unroll, block; bool ntld, ntst, xpose, xcd; };
+constexpr VariantInfo kVariants[kNumVariants] = {
+#define X(id, U, B, NL, NS, XP, XC) {U, B, NL, NS, XP, XC},
+    BITNUC_VARIANTS(X)
+#undef X
+};
+
+template <int UNROLL, int BLOCK, bool NTLD, bool NTST, bool XPOSE, bool XCD>
 hipError_t launch_encode_t(bitnuc_ctx *c, const uint8_t *seq, uint32_t *out32, unsigned long long len,
                            unsigned long long *slot, bool al) {
-    const unsigned long long tile = (unsigned long long)kBlock * UNROLL * VPL;
-    const unsigned grid = grid_for(c, (len >> 4) / tile + 1);
-    if (al) encode_kernel<VPL, UNROLL, NT, true, XPOSE><<<grid, kBlock, 0, c->stream>>>(seq, out32, len, slot);
-    else if constexpr (!XPOSE) encode_kernel<VPL, UNROLL, NT, false, false><<<grid, kBlock, 0, c->stream>>>(seq, out32, len, slot);
+    const unsigned long long tile = (unsigned long long)BLOCK * UNROLL;
+    const unsigned grid = grid_for(c, (len >> 4) / tile + 1, BLOCK);
+    if (al) encode_kernel<UNROLL, BLOCK, NTLD, NTST, true, XPOSE, XCD><<<grid, BLOCK, 0, c->stream>>>(seq, out32, len, slot);
+    else if constexpr (!XPOSE) encode_kernel<UNROLL, BLOCK, NTLD, NTST, false, false, XCD><<<grid, BLOCK, 0, c->stream>>>(seq, out32, len, slot);
     return hipGetLastError();
 }
 
@@ -173,33 +203,23 @@ hipError_t launch_encode(bitnuc_ctx *c, const uint8_t *seq, uint64_t *out, unsig
     uint32_t *o = reinterpret_cast<uint32_t *>(out);
     const bool in_al = aligned16(seq), out_al = aligned16(out);
     int v = c->enc_variant;
-    // wide packed-side accesses need a 16-byte aligned packed buffer; the LDS
-    // transpose variant also needs aligned input
-    if ((kVariants[v].vpl == 4 && !out_al) || (kVariants[v].xpose && !(in_al && out_al))) v = 1;
+    // the LDS-transpose variant needs 16-byte aligned buffers on both sides
+    if (kVariants[v].xpose && !(in_al && out_al)) v = kDefaultEnc;
     switch (v) {
-    case 0: return launch_encode_t<1, 4, false, false>(c, seq, o, len, slot, in_al);
-    case 1: return launch_encode_t<1, 4, true, false>(c, seq, o, len, slot, in_al);
-    case 2: return launch_encode_t<1, 8, false, false>(c, seq, o, len, slot, in_al);
-    case 3: return launch_encode_t<1, 8, true, false>(c, seq, o, len, slot, in_al);
-    case 4: return launch_encode_t<1, 2, true, false>(c, seq, o, len, slot, in_al);
-    case 5: return launch_encode_t<2, 2, true, false>(c, seq, o, len, slot, in_al);
-    case 6: return launch_encode_t<2, 4, true, false>(c, seq, o, len, slot, in_al);
-    case 7: return launch_encode_t<4, 1, true, false>(c, seq, o, len, slot, in_al);
-    case 8: return launch_encode_t<4, 2, true, false>(c, seq, o, len, slot, in_al);
-    case 9: return launch_encode_t<1, 4, false, true>(c, seq, o, len, slot, true);
-    case 10: return launch_encode_t<1, 4, true, true>(c, seq, o, len, slot, true);
-    case 11: return launch_encode_t<1, 1, true, false>(c, seq, o, len, slot, in_al);
-    case 12: return launch_encode_t<4, 2, false, false>(c, seq, o, len, slot, in_al);
-    default: return launch_encode_t<2, 4, false, false>(c, seq, o, len, slot, in_al);
+#define X(id, U, B, NL, NS, XP, XC) \
+    case id: return launch_encode_t<U, B, NL, NS, XP, XC>(c, seq, o, len, slot, XP ? true : in_al);
+        BITNUC_VARIANTS(X)
+#undef X
+    default: return hipErrorInvalidValue;
     }
 }
 
-template <int VPL, int UNROLL, bool NT, bool XPOSE>
+template <int UNROLL, int BLOCK, bool NTLD, bool NTST, bool XPOSE, bool XCD>
 hipError_t launch_decode_t(bitnuc_ctx *c, const uint32_t *in32, uint8_t *out, unsigned long long n_bases, bool al) {
-    const unsigned long long tile = (unsigned long long)kBlock * UNROLL * VPL;
-    const unsigned grid = grid_for(c, (n_bases >> 4) / tile + 1);
-    if (al) decode_kernel<VPL, UNROLL, NT, true, XPOSE><<<grid, kBlock, 0, c->stream>>>(in32, out, n_bases);
-    else decode_kernel<VPL, UNROLL, NT, false, XPOSE><<<grid, kBlock, 0, c->stream>>>(in32, out, n_bases);
+    const unsigned long long tile = (unsigned long long)BLOCK * UNROLL;
+    const unsigned grid = grid_for(c, (n_bases >> 4) / tile + 1, BLOCK);
+    if (al) decode_kernel<UNROLL, BLOCK, NTLD, NTST, true, XPOSE, XCD><<<grid, BLOCK, 0, c->stream>>>(in32, out, n_bases);
+    else decode_kernel<UNROLL, BLOCK, NTLD, NTST, false, XPOSE, XCD><<<grid, BLOCK, 0, c->stream>>>(in32, out, n_bases);
     return hipGetLastError();
 }
 
@@ -207,22 +227,13 @@ hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsi
     const uint32_t *i = reinterpret_cast<const uint32_t *>(ebuf);
     const bool in_al = aligned16(ebuf), out_al = aligned16(out);
     int v = c->dec_variant;
-    if ((kVariants[v].vpl == 4 || kVariants[v].xpose) && !in_al) v = 1;
+    if (kVariants[v].xpose && !in_al) v = kDefaultDec;
     switch (v) {
-    case 0: return launch_decode_t<1, 4, false, false>(c, i, out, n_bases, out_al);
-    case 1: return launch_decode_t<1, 4, true, false>(c, i, out, n_bases, out_al);
-    case 2: return launch_decode_t<1, 8, false, false>(c, i, out, n_bases, out_al);
-    case 3: return launch_decode_t<1, 8, true, false>(c, i, out, n_bases, out_al);
-    case 4: return launch_decode_t<1, 2, true, false>(c, i, out, n_bases, out_al);
-    case 5: return launch_decode_t<2, 2, true, false>(c, i, out, n_bases, out_al);
-    case 6: return launch_decode_t<2, 4, true, false>(c, i, out, n_bases, out_al);
-    case 7: return launch_decode_t<4, 1, true, false>(c, i, out, n_bases, out_al);
-    case 8: return launch_decode_t<4, 2, true, false>(c, i, out, n_bases, out_al);
-    case 9: return launch_decode_t<1, 4, false, true>(c, i, out, n_bases, out_al);
-    case 10: return launch_decode_t<1, 4, true, true>(c, i, out, n_bases, out_al);
-    case 11: return launch_decode_t<1, 1, true, false>(c, i, out, n_bases, out_al);
-    case 12: return launch_decode_t<4, 2, false, false>(c, i, out, n_bases, out_al);
-    default: return launch_decode_t<2, 4, false, false>(c, i, out, n_bases, out_al);
+#define X(id, U, B, NL, NS, XP, XC) \
+    case id: return launch_decode_t<U, B, NL, NS, XP, XC>(c, i, out, n_bases, out_al);
+        BITNUC_VARIANTS(X)
+#undef X
+    default: return hipErrorInvalidValue;
     }
 }
 

@@ -21,7 +21,10 @@
 //     reference's "first invalid byte in sequence order" (avx.rs:86-91) without
 //     serialising the stream;
 //   * optional wave-private LDS transpose (XPOSE) turns 4 coalesced 4-byte
-//     accesses per lane on the packed side into one 16-byte access.
+//     accesses per lane on the packed side into one 16-byte access;
+//   * strided wide accesses (a lane owning 2 or 4 adjacent groups) were measured and
+//     dropped: 64 B/lane loads ran encode at 4.3 TB/s, 32-64 B/lane stores ran decode
+//     at 1.5-3.0 TB/s, against 6.2 / 6.5 TB/s for the coalesced forms (profiles/).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -141,33 +144,45 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ---------------------------------------------------------------------------------
+// tile -> workgroup mapping
+// ---------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one).  With XCD the
+// first pass gives each XCD one contiguous eighth of the tiles instead of every eighth
+// tile (speed only; any placement is correct).  Bijective for any grid size.
+template <bool XCD>
+__device__ __forceinline__ unsigned long long first_tile(unsigned b, unsigned grid) {
+    if constexpr (!XCD) return b;
+    const unsigned q = grid >> 3, r = grid & 7, x = b & 7;
+    return (unsigned long long)(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// ---------------------------------------------------------------------------------
 // encode
 // ---------------------------------------------------------------------------------
-// Geometry: a tile is kBlock*UNROLL*VPL groups.  Thread t, round u owns the VPL
-// consecutive groups starting at tile + (u*kBlock + t)*VPL, so one round of a wave is
-// one contiguous 64*VPL*16-byte span.  VPL=1: dwordx4 load, dword store.  VPL=2/4:
-// the lane's packed output is one dwordx2/dwordx4 store.  XPOSE (VPL==1, UNROLL==4):
-// loads stay 16 B/lane coalesced, results cross a wave-private LDS strip so each lane
-// stores 16 contiguous packed bytes.
-template <int VPL, int UNROLL, bool NT, bool ALIGNED, bool XPOSE>
-__global__ void __launch_bounds__(kBlock)
+// Geometry: a tile is BLOCK*UNROLL groups.  Thread t, round u owns group
+// tile + u*BLOCK + t, so one round of a wave is one contiguous 1 KiB span of ASCII
+// (dwordx4 per lane) and one 256 B span of packed output (dword per lane).
+// XPOSE (UNROLL==4): the wave's 4 results per lane cross a wave-private LDS strip so
+// each lane stores 16 contiguous packed bytes (one dwordx4) instead of 4 dwords.
+template <int UNROLL, int BLOCK, bool NTLD, bool NTST, bool ALIGNED, bool XPOSE, bool XCD>
+__global__ void __launch_bounds__(BLOCK)
 encode_kernel(const uint8_t *__restrict__ seq, uint32_t *__restrict__ out32, unsigned long long len,
               unsigned long long *__restrict__ slot) {
-    static_assert(!XPOSE || (VPL == 1 && UNROLL == 4), "XPOSE needs VPL=1, UNROLL=4");
-    constexpr unsigned long long TILE = (unsigned long long)kBlock * UNROLL * VPL;
+    static_assert(!XPOSE || UNROLL == 4, "XPOSE needs UNROLL=4");
+    constexpr unsigned long long TILE = (unsigned long long)BLOCK * UNROLL;
     const unsigned long long n16 = len >> 4;
     const unsigned long long full_tiles = n16 / TILE;
     const unsigned t = threadIdx.x;
-    __shared__ uint32_t strip[XPOSE ? kBlock * 4 : 1];
+    __shared__ uint32_t strip[XPOSE ? BLOCK * 4 : 1];
 
-    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+    for (unsigned long long tile = first_tile<XCD>(blockIdx.x, gridDim.x); tile < full_tiles; tile += gridDim.x) {
         const unsigned long long g0 = tile * TILE;
         if constexpr (XPOSE) {
             const unsigned wave = t >> 6, lane = t & 63;
             const unsigned long long gw = g0 + (unsigned long long)wave * 256;
             u32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = load_group<NT, true>(seq + ((gw + u * 64 + lane) << 4));
+            for (int u = 0; u < 4; ++u) v[u] = load_group<NTLD, true>(seq + ((gw + u * 64 + lane) << 4));
             uint32_t bad = 0;
             uint32_t *ws = strip + wave * 256;
 #pragma unroll
@@ -179,43 +194,26 @@ encode_kernel(const uint8_t *__restrict__ seq, uint32_t *__restrict__ out32, uns
             wave_lds_fence();
             const u32x4 r = *reinterpret_cast<const u32x4 *>(ws + 4 * lane);
             wave_lds_fence();
-            store_group<NT, true>(reinterpret_cast<uint8_t *>(out32 + gw + 4 * lane), r);
+            store_group<NTST, true>(reinterpret_cast<uint8_t *>(out32 + gw + 4 * lane), r);
         } else {
-            u32x4 v[UNROLL][VPL];
+            u32x4 v[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-                for (int j = 0; j < VPL; ++j)
-                    v[u][j] = load_group<NT, ALIGNED>(seq + ((g0 + ((unsigned long long)u * kBlock + t) * VPL + j) << 4));
+                v[u] = load_group<NTLD, ALIGNED>(seq + ((g0 + (unsigned long long)u * BLOCK + t) << 4));
             uint32_t bad = 0;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const unsigned long long g = g0 + ((unsigned long long)u * kBlock + t) * VPL;
-                uint32_t r[VPL];
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) r[j] = enc16(v[u][j], bad);
-                if constexpr (VPL == 1) {
-                    store_u32<NT>(out32 + g, r[0]);
-                } else if constexpr (VPL == 2) {
-                    u32x2 o = {r[0], r[1]};
-                    if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(out32 + g));
-                    else *reinterpret_cast<u32x2 *>(out32 + g) = o;
-                } else {
-                    u32x4 o = {r[0], r[1], r[2], r[3]};
-                    store_group<NT, true>(reinterpret_cast<uint8_t *>(out32 + g), o);
-                }
-            }
+            for (int u = 0; u < UNROLL; ++u)
+                store_u32<NTST>(out32 + g0 + (unsigned long long)u * BLOCK + t, enc16(v[u], bad));
             if (__builtin_expect(residue_is_bad(bad), 0)) {
 #pragma unroll 1
-                for (int u = 0; u < UNROLL; ++u)
-                    rescan_bytes(seq, (g0 + ((unsigned long long)u * kBlock + t) * VPL) << 4, 16 * VPL, slot);
+                for (int u = 0; u < UNROLL; ++u) rescan_bytes(seq, (g0 + (unsigned long long)u * BLOCK + t) << 4, 16, slot);
             }
         }
     }
 
     // groups past the last full tile: one block, bounds-checked, plain path
     if (blockIdx.x == (unsigned)(full_tiles % gridDim.x)) {
-        for (unsigned long long g = full_tiles * TILE + t; g < n16; g += kBlock) {
+        for (unsigned long long g = full_tiles * TILE + t; g < n16; g += BLOCK) {
             const u32x4 v = load_group<false, ALIGNED>(seq + (g << 4));
             uint32_t b = 0;
             const uint32_t r = enc16(v, b);
@@ -249,27 +247,27 @@ encode_kernel(const uint8_t *__restrict__ seq, uint32_t *__restrict__ out32, uns
 // ---------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------
-// Same geometry seen from the packed side: thread t, round u owns VPL consecutive
-// u32 half-words and writes VPL consecutive 16-byte ASCII groups.  XPOSE: dwordx4
+// Same geometry seen from the packed side: thread t, round u loads one u32 half-word
+// and writes one 16-byte ASCII group (dwordx4), both fully coalesced.  XPOSE: dwordx4
 // load of 4 consecutive half-words per lane, transposed through a wave-private LDS
-// strip so that each of the 4 ASCII stores of a wave is one contiguous 1 KiB span.
-template <int VPL, int UNROLL, bool NT, bool ALIGNED, bool XPOSE>
-__global__ void __launch_bounds__(kBlock)
+// strip so that each of the 4 ASCII stores of a wave is still one contiguous 1 KiB span.
+template <int UNROLL, int BLOCK, bool NTLD, bool NTST, bool ALIGNED, bool XPOSE, bool XCD>
+__global__ void __launch_bounds__(BLOCK)
 decode_kernel(const uint32_t *__restrict__ in32, uint8_t *__restrict__ out, unsigned long long n_bases) {
-    static_assert(!XPOSE || (VPL == 1 && UNROLL == 4), "XPOSE needs VPL=1, UNROLL=4");
-    constexpr unsigned long long TILE = (unsigned long long)kBlock * UNROLL * VPL;
+    static_assert(!XPOSE || UNROLL == 4, "XPOSE needs UNROLL=4");
+    constexpr unsigned long long TILE = (unsigned long long)BLOCK * UNROLL;
     const unsigned long long n16 = n_bases >> 4;
     const unsigned long long full_tiles = n16 / TILE;
     const unsigned t = threadIdx.x;
-    __shared__ uint32_t strip[XPOSE ? kBlock * 4 : 1];
+    __shared__ uint32_t strip[XPOSE ? BLOCK * 4 : 1];
 
-    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+    for (unsigned long long tile = first_tile<XCD>(blockIdx.x, gridDim.x); tile < full_tiles; tile += gridDim.x) {
         const unsigned long long g0 = tile * TILE;
         if constexpr (XPOSE) {
             const unsigned wave = t >> 6, lane = t & 63;
             const unsigned long long gw = g0 + (unsigned long long)wave * 256;
             uint32_t *ws = strip + wave * 256;
-            const u32x4 w = load_group<NT, true>(reinterpret_cast<const uint8_t *>(in32 + gw + 4 * lane));
+            const u32x4 w = load_group<NTLD, true>(reinterpret_cast<const uint8_t *>(in32 + gw + 4 * lane));
             *reinterpret_cast<u32x4 *>(ws + 4 * lane) = w;
             wave_lds_fence();
             uint32_t h[4];
@@ -277,35 +275,19 @@ decode_kernel(const uint32_t *__restrict__ in32, uint8_t *__restrict__ out, unsi
             for (int u = 0; u < 4; ++u) h[u] = ws[u * 64 + lane];
             wave_lds_fence();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) store_group<NT, ALIGNED>(out + ((gw + u * 64 + lane) << 4), dec16(h[u]));
+            for (int u = 0; u < 4; ++u) store_group<NTST, ALIGNED>(out + ((gw + u * 64 + lane) << 4), dec16(h[u]));
         } else {
-            uint32_t h[UNROLL][VPL];
+            uint32_t h[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const unsigned long long g = g0 + ((unsigned long long)u * kBlock + t) * VPL;
-                if constexpr (VPL == 1) {
-                    h[u][0] = load_u32<NT>(in32 + g);
-                } else if constexpr (VPL == 2) {
-                    u32x2 w;
-                    if constexpr (NT) w = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(in32 + g));
-                    else w = *reinterpret_cast<const u32x2 *>(in32 + g);
-                    h[u][0] = w.x; h[u][1] = w.y;
-                } else {
-                    const u32x4 w = load_group<NT, true>(reinterpret_cast<const uint8_t *>(in32 + g));
-                    h[u][0] = w.x; h[u][1] = w.y; h[u][2] = w.z; h[u][3] = w.w;
-                }
-            }
+            for (int u = 0; u < UNROLL; ++u) h[u] = load_u32<NTLD>(in32 + g0 + (unsigned long long)u * BLOCK + t);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const unsigned long long g = g0 + ((unsigned long long)u * kBlock + t) * VPL;
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) store_group<NT, ALIGNED>(out + ((g + j) << 4), dec16(h[u][j]));
-            }
+            for (int u = 0; u < UNROLL; ++u)
+                store_group<NTST, ALIGNED>(out + ((g0 + (unsigned long long)u * BLOCK + t) << 4), dec16(h[u]));
         }
     }
 
     if (blockIdx.x == (unsigned)(full_tiles % gridDim.x)) {
-        for (unsigned long long g = full_tiles * TILE + t; g < n16; g += kBlock)
+        for (unsigned long long g = full_tiles * TILE + t; g < n16; g += BLOCK)
             store_group<false, ALIGNED>(out + (g << 4), dec16(in32[g]));
         if (t == 0) {
             const unsigned rem = (unsigned)(n_bases & 15);
