@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=250_000_000)
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (k-mer batch) and config-5 (scan) side measurements")
     ap.add_argument("--probe", action="store_true", help="also time pure read/copy/fill kernels (the box's own HBM ceiling)")
     args = ap.parse_args()
 
@@ -176,6 +177,41 @@ def main():
         extra["allgather_packed"] = {"ms": round(ag * 1e3, 3), "bytes_received_per_gpu": nw * 8 * (world - 1),
                                      "gb_s_per_gpu": round(nw * 8 * (world - 1) / ag / 1e9, 2),
                                      "note": "RCCL all-gather of the packed u64 buffer over xGMI; fabric-bound, outside the timed step"}
+    if world == 1 and not args.no_extras:
+        # BASELINE configs[2] and [4], measured beside the headline (never inside the timed step)
+        del backs[1:], seqs[1:], words[1:]
+        torch.cuda.empty_cache()
+
+        def timed(fn, reps=10):
+            ms = []
+            for _ in range(reps + 2):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                fn()
+                b.record(stream)
+                torch.cuda.synchronize()
+                ms.append(a.elapsed_time(b))
+            return statistics.median(ms[2:])
+        count, k = 10**8, 31
+        kseq = torch.empty(count * k, dtype=torch.uint8, device=dev)
+        ctx.nucgen_dev(kseq, count * k, SEED + 100)
+        kout = torch.empty(count, dtype=torch.int64, device=dev)
+        ms = timed(lambda: ctx.as_2bit_batch_dev(kseq, k, k, count, kout))
+        gbs = count * (k + 8) / (ms * 1e-3) / 1e9
+        extra["kmer_batch"] = {"workload": "BASELINE configs[2]: 10^8 dense 31-mers as_2bit -> u64", "gkmers_s": round(count / (ms * 1e-3) / 1e9, 2),
+                               "ms": round(ms, 4), "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": count * (k + 8)}}
+        del kseq, kout
+        dist_out = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
+        q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
+        ms = timed(lambda: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, dist_out))
+        gbs = 2 * (n - k + 1) / (ms * 1e-3) / 1e9
+        extra["kmer_hdist_scan"] = {"workload": "BASELINE configs[4]: sliding 31-mer pack + Hamming distance to one query over 10^9 bases",
+                                    "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4),
+                                    "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 2 * (n - k + 1)}}
+        ctx.sync()
+        backs.append(dist_out)  # reused by the probe below
     if args.probe:
         probe = {}
         for name, mode, nbytes in [("read", 0 | 8, n), ("copy", 1 | 8, n), ("fill", 2 | 8, n), ("read_plain", 0, n), ("copy_plain", 1, n)]:
@@ -183,7 +219,7 @@ def main():
             for i in range(10):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(stream)
-                ctx.stream_probe_dev(mode, seqs[i % R], backs[(i + 1) % R], nbytes)
+                ctx.stream_probe_dev(mode, seqs[i % len(seqs)], backs[(i + 1) % len(backs)], min(nbytes, backs[(i + 1) % len(backs)].numel()))
                 b.record(stream)
                 torch.cuda.synchronize()
                 ms.append(a.elapsed_time(b))

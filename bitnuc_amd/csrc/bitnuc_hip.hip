@@ -41,7 +41,7 @@ struct bitnuc_ctx {
     uint8_t *scratch[3] = {nullptr, nullptr, nullptr};
     size_t scratch_cap[3] = {0, 0, 0};
     uint32_t *d_sink = nullptr;
-    int enc_variant = 3, dec_variant = 13; // kDefaultEnc / kDefaultDec
+    int enc_variant = 3, dec_variant = 1; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
 };
 
@@ -175,12 +175,20 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
     X(26, 8, 256, false, false, false, true)          \
     X(27, 4, 512, false, false, false, true)          \
     X(28, 4, 256, false, false, true, true)           \
-    X(29, 1, 256, false, false, false, true)
-constexpr int kNumVariants = 30;
-// defaults from the interleaved sweeps in profiles/ (10^9 bases, one tile per workgroup):
-//   encode: nt loads + plain stores, 2 groups in flight per lane   -> 6.76 TB/s algorithmic
-//   decode: plain loads/stores, 4 groups per lane, XCD-contiguous  -> 6.71 TB/s algorithmic
-constexpr int kDefaultEnc = 3, kDefaultDec = 13;
+    X(29, 1, 256, false, false, false, true)          \
+    X(30, 2, 256, true, true, false, true)            \
+    X(31, 4, 256, true, true, false, true)            \
+    X(32, 8, 256, true, true, false, false)           \
+    X(33, 4, 512, true, true, false, false)           \
+    X(34, 4, 256, false, true, false, true)           \
+    X(35, 4, 128, true, true, false, false)
+constexpr int kNumVariants = 36;
+// defaults from the sustained (back-to-back) pair sweep in profiles/ (10^9 bases, one tile
+// per workgroup; the pair matters because decode's 1 GB of stores sits dirty in the
+// 256 MiB Infinity Cache when the next encode starts):
+//   encode: nt loads + plain stores, 2 groups in flight per lane -> 6.80 TB/s algorithmic
+//   decode: nt loads + nt stores, 4 groups per lane              -> 6.79 TB/s algorithmic
+constexpr int kDefaultEnc = 3, kDefaultDec = 1;
 
 struct VariantInfo { int unroll, block; bool ntld, ntst, xpose, xcd; };
 constexpr VariantInfo kVariants[kNumVariants] = {
