@@ -43,6 +43,8 @@ struct bitnuc_ctx {
     uint32_t *d_sink = nullptr;
     int enc_variant = 3, dec_variant = 1; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
+    int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
+    int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
 };
 
 namespace {
@@ -247,23 +249,52 @@ hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsi
 
 hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t stride, size_t count, uint64_t *out,
                         unsigned long long *slot) {
-    const unsigned grid = grid_for(c, (count + kBlock - 1) / kBlock);
     unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
+    size_t done = 0;
+    if (stride == k && count >= 64 && c->batch_dense) {
+        // dense layout: whole waves of 64 k-mers go through the bulk-encode-shaped kernel
+        const unsigned long long items = count / 64;
+        const unsigned grid = grid_for(c, (items + kBlock / 64 - 1) / (kBlock / 64));
+        if (!aligned16(kmers)) kmer_dense_kernel<false, false, false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot);
+        else switch (c->dense_policy) { // bit0: nt loads, bit1: nt stores
+        case 0: kmer_dense_kernel<true, false, false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot); break;
+        case 1: kmer_dense_kernel<true, true, false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot); break;
+        case 2: kmer_dense_kernel<true, false, true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot); break;
+        default: kmer_dense_kernel<true, true, true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot); break;
+        }
+        hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+        done = items * 64;
+        if (done == count) return hipSuccess;
+    }
+    // general strides, and the < 64 k-mers a dense batch leaves over.  The error slot holds
+    // byte offsets relative to `kmers`, so the leftover launch passes the offset it starts at.
+    const size_t rest = count - done;
+    const unsigned grid = grid_for(c, (rest + kBlock - 1) / kBlock);
     if (stride <= (size_t)kStagedMaxStride)
-        kmer_batch_kernel<true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, stride, count, o, slot);
+        kmer_batch_kernel<true><<<grid, kBlock, 0, c->stream>>>(kmers + done * stride, (unsigned)k, stride, rest, o + done, slot, done * stride);
     else
-        kmer_batch_kernel<false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, stride, count, o, slot);
+        kmer_batch_kernel<false><<<grid, kBlock, 0, c->stream>>>(kmers + done * stride, (unsigned)k, stride, rest, o + done, slot, done * stride);
     return hipGetLastError();
 }
 
 hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist,
                        unsigned long long *slot) {
-    const unsigned long long rounds = n >= 1056 ? (n - 1056) / 1024 + 1 : 0;
+    const unsigned long long rounds = n >= 1024 ? (n - 1024) / kScanWaveWindows + 1 : 0;
     const unsigned grid = grid_for(c, rounds / (kBlock / 64) + 1);
-    if (aligned16(ref) && aligned16(dist))
-        kmer_scan_kernel<true, true><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot);
-    else
-        kmer_scan_kernel<false, false><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot);
+    uint32_t ql = 0, qh = 0; // de-interleave the packed query into its two bit-planes
+    for (unsigned i = 0; i < k; ++i) {
+        ql |= (uint32_t)((query >> (2 * i)) & 1) << i;
+        qh |= (uint32_t)((query >> (2 * i + 1)) & 1) << i;
+    }
+    if (!(aligned16(ref) && aligned16(dist)))
+        kmer_scan_kernel<false, false, false><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot);
+    else switch (c->scan_policy) { // bit0: nt loads, bit1: nt stores
+    case 0: kmer_scan_kernel<true, false, false><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot); break;
+    case 1: kmer_scan_kernel<true, true, false><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot); break;
+    case 2: kmer_scan_kernel<true, false, true><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot); break;
+    default: kmer_scan_kernel<true, true, true><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot); break;
+    }
     return hipGetLastError();
 }
 
@@ -363,6 +394,9 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     if (!strcmp(key, "encode")) { prev = c->enc_variant; if (value >= 0 && value < kNumVariants) c->enc_variant = value; }
     else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0 && value < kNumVariants) c->dec_variant = value; }
     else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }
+    else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
+    else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
+    else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
     else if (!strcmp(key, "num_variants")) { prev = kNumVariants; }
     else if (!strcmp(key, "num_cu")) { prev = c->num_cu; }
     return prev;

@@ -30,7 +30,7 @@ template <bool STAGED>
 __global__ void __launch_bounds__(kBlock)
 kmer_batch_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long long stride,
                   unsigned long long count, unsigned long long *__restrict__ out,
-                  unsigned long long *__restrict__ slot) {
+                  unsigned long long *__restrict__ slot, unsigned long long index_base) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[STAGED ? kStageBytes : 16];
     const unsigned t = threadIdx.x;
     const unsigned nfull = k >> 2, rem = k & 3;
@@ -87,7 +87,7 @@ kmer_batch_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
         if (__builtin_expect(residue_is_bad(bad), 0)) {
             for (unsigned b = 0; b < k; ++b) {
                 const uint32_t byte = (x[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                if (!valid_base(byte)) { atomicMin(slot, j * stride + b); break; }
+                if (!valid_base(byte)) { atomicMin(slot, index_base + j * stride + b); break; }
             }
         }
         out[j] = ((unsigned long long)hi << 32) | lo;
@@ -95,44 +95,108 @@ kmer_batch_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
 }
 
 // ---------------------------------------------------------------------------------
-// sliding-window k-mer pack + Hamming distance scan
+// batched as_2bit, dense layout (stride == k): BASELINE config 3
 // ---------------------------------------------------------------------------------
-// Fast path: a wave owns 1024 consecutive windows.  Lane l loads the 16 bytes at
-// window 16l with one coalesced dwordx4 and packs them to a 32-bit code stream; the
-// 30-base halo it needs is the next two lanes' streams (two lane shifts) -- only lanes
-// 62/63 take it from a 32-byte wave-uniform halo load.  Window j is the 64-bit field at
-// bit 2j of the 96-bit stream {s2,s1,s0}: two v_alignbit_b32 with a constant shift.  Output: 16 distance bytes per lane, one coalesced dwordx4 store.
-// Needs bytes [wb, wb+1056) in bounds; the (< 2080) windows left over go through the
-// byte-wise tail below.
-template <bool ALIGNED, bool NT>
+// With no gap between k-mers the batch IS a bulk encode whose 2-bit stream is cut every
+// 2k bits instead of every 64: a wave takes 64 k-mers = 64k bytes = 4k whole 16-byte
+// groups (so every wave's span stays 16-byte aligned), lanes load them with coalesced
+// dwordx4 (1 or 2 per lane), pack each group to a u32 of codes into a wave-private LDS
+// strip, and lane j then funnel-shifts its 2k bits out of strip dwords (2kj)>>5 .. +2.
+// 4x less LDS traffic and ~half the VALU work of staging raw bytes (kmer_batch_kernel).
+// Handles whole waves only; the host sends the < 64 leftover k-mers to kmer_batch_kernel.
+template <bool ALIGNED, bool NTLD, bool NTST>
+__global__ void __launch_bounds__(kBlock)
+kmer_dense_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long long nwave_items,
+                  unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
+    __shared__ uint32_t strips[kBlock / 64][132];
+    const unsigned lane = threadIdx.x & 63;
+    uint32_t *ws = strips[threadIdx.x >> 6];
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * kBlock) >> 6;
+    const unsigned ngroups = 4 * k; // 16-byte groups per 64 k-mers
+    const unsigned bit = 2 * k * lane, d = bit >> 5, sh = bit & 31;
+    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const u32x4 pad = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+
+    for (unsigned long long it = wave; it < nwave_items; it += nwaves) {
+        const uint8_t *base = kmers + it * 64ull * k;
+        const bool a0 = lane < ngroups, a1 = lane + 64 < ngroups;
+        const u32x4 v0 = a0 ? load_group<NTLD, ALIGNED>(base + 16 * lane) : pad;
+        const u32x4 v1 = a1 ? load_group<NTLD, ALIGNED>(base + 16 * (lane + 64)) : pad;
+        uint32_t bad = 0;
+        const uint32_t c0 = enc16(v0, bad), c1 = enc16(v1, bad);
+        ws[lane] = c0;
+        ws[lane + 64] = c1;
+        wave_lds_fence();
+        const uint32_t w0 = ws[d], w1 = ws[d + 1], w2 = ws[d + 2];
+        wave_lds_fence();
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+        const unsigned long long word = (((unsigned long long)hi << 32) | lo) & kmask;
+        if constexpr (NTST) __builtin_nontemporal_store(word, out + it * 64 + lane);
+        else out[it * 64 + lane] = word;
+        if (__builtin_expect(residue_is_bad(bad), 0)) {
+            if (a0) rescan_bytes(kmers, it * 64ull * k + 16 * lane, 16, slot);
+            if (a1) rescan_bytes(kmers, it * 64ull * k + 16 * (lane + 64), 16, slot);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// sliding-window k-mer pack + Hamming distance scan: BASELINE config 5
+// ---------------------------------------------------------------------------------
+// dist[i] = hdist_scalar(as_2bit(ref[i..i+k]), query, k).  The distance of two packed
+// words is the number of 2-bit fields that differ (hamming/scalar.rs:33-47); with the
+// codes split into two bit-planes (L = low code bits, H = high code bits, one bit per
+// base) that is popcount(((L>>i ^ qL) | (H>>i ^ qH)) & ones(k)) -- all 32-bit ops.
+//
+// Fast path: a wave reads 1024 consecutive bytes (lane l: the dwordx4 at 16l, coalesced)
+// and produces the 992 windows that start in its first 62 lanes; lanes 62/63 only supply
+// the 30-base halo, so there is no separate halo load and consecutive waves overlap by
+// 32 bytes (3 % re-read, served by L2).  Per lane: 16 bases -> two 16-bit planes
+// (v_perm LUT + validity residue as in enc4, v_dot4 with weights {1,2,4,8} gathers one bit
+// per byte), planes of lanes l+1, l+2 arrive by two lane shifts, window j is a
+// v_alignbit_b32 of each plane pair by j.  16 distance bytes per lane, one dwordx4 store.
+// Needs bytes [wb, wb+1024) in bounds; the leftover windows go through the tail loop.
+constexpr unsigned kScanWaveWindows = 992;
+
+__device__ __forceinline__ void planes4(uint32_t x, uint32_t &bad, uint32_t &lnib, uint32_t &hnib2) {
+    const uint32_t sel = x & 0x07070707u;
+    const uint32_t t = __builtin_amdgcn_perm(0x42040453u, 0x41044004u, sel); // same LUT as enc4
+    const uint32_t dd = t ^ (x & 0xD8D8D8D8u);
+    bad |= dd;
+    lnib = __builtin_amdgcn_udot4(dd & 0x01010101u, 0x08040201u, 0u, false);  // low code bits of 4 bases
+    hnib2 = __builtin_amdgcn_udot4(dd & 0x02020202u, 0x08040201u, 0u, false); // 2 x (high code bits)
+}
+
+template <bool ALIGNED, bool NTLD, bool NTST>
 __global__ void __launch_bounds__(kBlock)
 kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query,
-                 uint8_t *__restrict__ dist, unsigned long long *__restrict__ slot) {
+                 uint32_t ql, uint32_t qh, uint8_t *__restrict__ dist, unsigned long long *__restrict__ slot) {
     const unsigned long long nwin = n - k + 1; // host guarantees 1 <= k <= 32, n >= k
-    const unsigned long long rounds = n >= 1056 ? (n - 1056) / 1024 + 1 : 0;
+    const unsigned long long rounds = n >= 1024 ? (n - 1024) / kScanWaveWindows + 1 : 0;
     const unsigned lane = threadIdx.x & 63;
     const unsigned long long wave = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned long long nwaves = ((unsigned long long)gridDim.x * kBlock) >> 6;
 
-    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    const uint32_t qlo = (uint32_t)(query & kmask), qhi = (uint32_t)((query & kmask) >> 32);
-    const uint32_t mlo = (uint32_t)kmask & 0x55555555u, mhi = (uint32_t)(kmask >> 32) & 0x55555555u;
+    // ql / qh: the query's bit-planes (bit i = low / high code bit of base i), split on the host
+    const uint32_t km = k == 32 ? ~0u : ((1u << k) - 1u);
 
     for (unsigned long long r = wave; r < rounds; r += nwaves) {
-        const unsigned long long wb = r * 1024;
-        const uint8_t *p = ref + wb + 16 * lane;
-        const u32x4 v0 = load_group<NT, ALIGNED>(p);
-        const u32x4 hv = load_group<false, ALIGNED>(ref + wb + 1024 + 16 * (lane & 1)); // 32-byte halo, two addresses per wave
-        // encode once per lane; the halo arrives as the next lanes' 32-bit code
-        // streams.  Every byte is validated by the lane (or tail thread) that owns it.
-        uint32_t bad = 0, hbad = 0;
-        const uint32_t s0 = enc16(v0, bad);
-        const uint32_t hs = enc16(hv, hbad);
-        const uint32_t d1 = __shfl_down(s0, 1), d2 = __shfl_down(s0, 2);
-        const uint32_t h0 = __shfl(hs, 0), h1 = __shfl(hs, 1);
-        const uint32_t s1 = lane < 63 ? d1 : h0;
-        const uint32_t s2 = lane < 62 ? d2 : (lane == 62 ? h0 : h1);
+        const unsigned long long wb = r * kScanWaveWindows;
+        const u32x4 v = load_group<NTLD, ALIGNED>(ref + wb + 16 * lane);
+        uint32_t bad = 0, l0, l1, l2, l3, h0, h1, h2, h3;
+        planes4(v.x, bad, l0, h0);
+        planes4(v.y, bad, l1, h1);
+        planes4(v.z, bad, l2, h2);
+        planes4(v.w, bad, l3, h3);
+        const uint32_t L16 = l0 | (l1 << 4) | (l2 << 8) | (l3 << 12);
+        const uint32_t H16x2 = h0 | (h1 << 4) | (h2 << 8) | (h3 << 12);
+        const uint32_t pl = L16 | (H16x2 << 15); // low half: L plane, high half: H plane (16 bases)
         if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(ref, wb + 16 * lane, 16, slot);
+        const uint32_t n1 = __shfl_down(pl, 1), n2 = __shfl_down(pl, 2);
+        const uint32_t Llo = __builtin_amdgcn_perm(n1, pl, 0x05040100u); // bases 0..31 of this lane's run
+        const uint32_t Hlo = __builtin_amdgcn_perm(n1, pl, 0x07060302u);
+        const uint32_t Lhi = n2 & 0xFFFFu, Hhi = n2 >> 16;               // bases 32..47
         uint32_t o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -140,22 +204,24 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int j = 4 * q + b;
-                const uint32_t lo = j ? __builtin_amdgcn_alignbit(s1, s0, 2 * j) : s0;
-                const uint32_t hi = j ? __builtin_amdgcn_alignbit(s2, s1, 2 * j) : s1;
-                const uint32_t d = __builtin_popcount(mismatch_bits(lo ^ qlo, mlo)) +
-                                   __builtin_popcount(mismatch_bits(hi ^ qhi, mhi));
-                acc |= d << (8 * b);
+                const uint32_t l = j ? __builtin_amdgcn_alignbit(Lhi, Llo, j) : Llo;
+                const uint32_t h = j ? __builtin_amdgcn_alignbit(Hhi, Hlo, j) : Hlo;
+                const uint32_t dcount = __builtin_popcount(((l ^ ql) | (h ^ qh)) & km);
+                acc |= dcount << (8 * b);
             }
             o[q] = acc;
         }
-        const u32x4 ov = {o[0], o[1], o[2], o[3]};
-        store_group<NT, ALIGNED>(dist + wb + 16 * lane, ov);
+        if (lane < 62) {
+            const u32x4 ov = {o[0], o[1], o[2], o[3]};
+            store_group<NTST, ALIGNED>(dist + wb + 16 * lane, ov);
+        }
     }
 
     // tail: one window per thread, byte loads
+    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const unsigned long long gt = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     const unsigned long long nthreads = (unsigned long long)gridDim.x * kBlock;
-    for (unsigned long long i = rounds * 1024 + gt; i < nwin; i += nthreads) {
+    for (unsigned long long i = rounds * kScanWaveWindows + gt; i < nwin; i += nthreads) {
         unsigned long long w = 0;
         bool flagged = false;
         for (unsigned b = 0; b < k; ++b) {

@@ -239,6 +239,54 @@ def test_dev_path_unaligned_and_async_errors(ctx, oracle):
     ctx.sync()  # cleared
 
 
+def test_kmer_dev_paths_unaligned(ctx, oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    for k, stride, count in [(31, 31, 5000), (32, 32, 777), (16, 16, 64), (31, 31, 63), (21, 40, 3000)]:
+        nbytes = (count - 1) * stride + k
+        s = rand_seq(nbytes)
+        for off in (0, 1, 7, 16):
+            buf = torch.zeros(nbytes + 64, dtype=torch.uint8, device=dev)
+            buf[off:off + nbytes] = torch.from_numpy(s).to(dev)
+            out = torch.zeros(count + 2, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            ctx.as_2bit_batch_dev(buf.data_ptr() + off, k, stride, count, out.data_ptr() + 8)
+            ctx.sync()
+            o = out.cpu().numpy().view(np.uint64)
+            assert o[0] == 0 and o[-1] == 0
+            assert np.array_equal(o[1:-1], oracle.as_2bit_batch(s, k, stride, count)), (k, stride, count, off)
+    # dense-kernel switch off == on
+    s = rand_seq(31 * 4096)
+    prev = ctx.set_variant("batch_dense", 0)
+    a = ctx.as_2bit_batch(s, 31, 31, 4096)
+    ctx.set_variant("batch_dense", 1)
+    b = ctx.as_2bit_batch(s, 31, 31, 4096)
+    ctx.set_variant("batch_dense", prev)
+    assert np.array_equal(a, b) and np.array_equal(a, oracle.as_2bit_batch(s, 31, 31, 4096))
+    # scan with unaligned ref / dist pointers
+    n, k = 70001, 31
+    s = rand_seq(n)
+    q = oracle.as_2bit(rand_seq(k))
+    for off, doff in [(0, 0), (3, 0), (0, 5), (9, 2)]:
+        buf = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+        buf[off:off + n] = torch.from_numpy(s).to(dev)
+        d = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.kmer_hdist_scan_dev(buf.data_ptr() + off, n, k, q, d.data_ptr() + doff)
+        ctx.sync()
+        h = d.cpu().numpy()
+        assert np.array_equal(h[doff:doff + n - k + 1], oracle.kmer_hdist_scan(s, k, q)), (off, doff)
+        assert not h[:doff].any() and not h[doff + n - k + 1:].any()
+    # dense batch: invalid byte found in the whole-wave part and in the leftover part
+    import bitnuc_amd as bn
+    for pos in (5, 31 * 64 * 3 + 17, 31 * 4100 + 2):
+        t = rand_seq(31 * 4130).copy()
+        t[pos] = ord("N")
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.as_2bit_batch(t, 31, 31, 4130)
+        assert (ei.value.byte, ei.value.index) == (ord("N"), pos)
+
+
 def test_nucgen_matches_host_generator(ctx, oracle):
     import torch
     dev = torch.device("cuda:0")
@@ -280,7 +328,7 @@ def test_kmer_batch_errors(ctx, oracle):
 
 @pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 32])
 def test_scan_vs_oracle(ctx, oracle, k):
-    for n in [k, k + 1, 1000, 1055, 1056, 1057, 2079, 2080, 2081, 5000, 200003]:
+    for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 2015, 2016, 2017, 2047, 2048, 5000, 200003]:
         s = rand_seq(n)
         q = int(RNG.integers(0, 1 << 62)) | (int(RNG.integers(0, 4)) << 62)
         got = ctx.kmer_hdist_scan(s, k, q)
@@ -290,7 +338,7 @@ def test_scan_vs_oracle(ctx, oracle, k):
 def test_scan_errors_and_bench_invariant(ctx, oracle):
     import bitnuc_amd as bn
     s = rand_seq(50000).copy()
-    for pos in (0, 1023, 1024, 1040, 1055, 30000, 49999):
+    for pos in (0, 991, 992, 1007, 1008, 1023, 1024, 1040, 1055, 30000, 49600, 49999):
         t = s.copy()
         t[pos] = ord("N")
         with pytest.raises(bn.NucleotideError) as ei:
