@@ -1,0 +1,56 @@
+//! `extern "C"` declarations for include/bitnuc_hip.h (one per exported symbol).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const BITNUC_OK: c_int = 0;
+pub const BITNUC_INVALID_BASE: c_int = 1;
+pub const BITNUC_SEQUENCE_TOO_LONG: c_int = 2;
+pub const BITNUC_INVALID_LENGTH: c_int = 3;
+pub const BITNUC_INDEX_OUT_OF_BOUNDS: c_int = 4;
+pub const BITNUC_INVALID_RANGE: c_int = 5;
+pub const BITNUC_UNSUPPORTED: c_int = 6;
+pub const BITNUC_BACKEND_ERROR: c_int = 100;
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct bitnuc_err {
+    pub status: i32,
+    pub backend_code: i32,
+    pub value: u64,
+    pub index: u64,
+    pub byte: u8,
+    pub _pad: [u8; 7],
+}
+
+#[repr(C)]
+pub struct bitnuc_ctx {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn bitnuc_version() -> *const c_char;
+    pub fn bitnuc_ctx_create(device: c_int, out: *mut *mut bitnuc_ctx, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_ctx_create_on_stream(device: c_int, hip_stream: *mut c_void, out: *mut *mut bitnuc_ctx, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_ctx_destroy(ctx: *mut bitnuc_ctx);
+    pub fn bitnuc_ctx_sync(ctx: *mut bitnuc_ctx, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_ctx_stream(ctx: *mut bitnuc_ctx) -> *mut c_void;
+    pub fn bitnuc_ctx_set_variant(ctx: *mut bitnuc_ctx, key: *const c_char, value: c_int) -> c_int;
+
+    pub fn bitnuc_as_2bit(ctx: *mut bitnuc_ctx, seq: *const u8, len: usize, out: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_from_2bit(ctx: *mut bitnuc_ctx, packed: u64, n: usize, out: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_hdist_scalar(ctx: *mut bitnuc_ctx, u: u64, v: u64, len: usize, out: *mut u32, err: *mut bitnuc_err) -> c_int;
+
+    pub fn bitnuc_encode(ctx: *mut bitnuc_ctx, seq: *const u8, len: usize, out: *mut u64, n_words: *mut usize, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_decode(ctx: *mut bitnuc_ctx, ebuf: *const u64, n_words: usize, n_bases: usize, out: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_hdist(ctx: *mut bitnuc_ctx, a: *const u64, na: usize, b: *const u64, nb: usize, n_bases: usize, out: *mut u32, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_as_2bit_batch(ctx: *mut bitnuc_ctx, kmers: *const u8, k: usize, stride: usize, count: usize, out: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_kmer_hdist_scan(ctx: *mut bitnuc_ctx, reference: *const u8, n: usize, k: usize, query: u64, dist: *mut u8, err: *mut bitnuc_err) -> c_int;
+
+    pub fn bitnuc_encode_dev(ctx: *mut bitnuc_ctx, d_seq: *const u8, len: usize, d_out: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_decode_dev(ctx: *mut bitnuc_ctx, d_ebuf: *const u64, n_words: usize, n_bases: usize, d_out: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_as_2bit_batch_dev(ctx: *mut bitnuc_ctx, d_kmers: *const u8, k: usize, stride: usize, count: usize, d_out: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_kmer_hdist_scan_dev(ctx: *mut bitnuc_ctx, d_ref: *const u8, n: usize, k: usize, query: u64, d_dist: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_hdist_dev(ctx: *mut bitnuc_ctx, d_a: *const u64, na: usize, d_b: *const u64, nb: usize, n_bases: usize, d_result: *mut u32, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_nucgen_dev(ctx: *mut bitnuc_ctx, d_out: *mut u8, len: usize, seed: u64, first: u64, flags: c_int, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_stream_probe_dev(ctx: *mut bitnuc_ctx, mode: c_int, d_src: *const c_void, d_dst: *mut c_void, bytes: usize, err: *mut bitnuc_err) -> c_int;
+}
