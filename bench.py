@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (k-mer batch) and config-5 (scan) side measurements")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse the N>1 control flow")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box)")
     ap.add_argument("--probe", action="store_true", help="also time pure read/copy/fill kernels (the box's own HBM ceiling)")
     args = ap.parse_args()
 
@@ -97,11 +99,17 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    on_gpu_collectives = args.backend == "nccl"
 
     n = args.bases
     nw = (n + 31) // 32
@@ -154,7 +162,7 @@ def main():
     r_last = (args.steps - 1) % R
     assert torch.equal(seqs[r_last], backs[r_last]), "decode(encode(x)) != x"
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if on_gpu_collectives else "cpu")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     sec_per_step = float(elapsed.item()) / args.steps
@@ -163,7 +171,7 @@ def main():
     enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
 
     extra = {}
-    if world > 1:  # config 4's concatenation, reported beside the step, never inside it
+    if world > 1 and on_gpu_collectives:  # config 4's concatenation, reported beside the step, never inside it
         from bitnuc_amd.dist import allgather_packed
         allgather_packed(words[0])
         fence()
@@ -210,6 +218,17 @@ def main():
                                     "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4),
                                     "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 2 * (n - k + 1)}}
+        # bulk packed-vs-packed Hamming distance (hdist, hamming/multi.rs:121-160): 16 B per 32-base word pair
+        wa, wb = words[0], torch.empty(nw, dtype=torch.int64, device=dev)
+        ctx.nucgen_dev(backs[0], n, SEED + 200)
+        ctx.encode_dev(backs[0], n, wb)
+        res = torch.zeros(1, dtype=torch.int32, device=dev)
+        ms = timed(lambda: ctx.hdist_dev(wa, nw, wb, nw, n, res))
+        gbs = 16 * nw / (ms * 1e-3) / 1e9
+        extra["hdist_bulk"] = {"workload": "hdist of two 10^9-base packed buffers (SURVEY 8f rank 1)", "ms": round(ms, 4),
+                               "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "distance": int(res.item()) & 0xFFFFFFFF,
+                               "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 16 * nw}}
         ctx.sync()
         backs.append(dist_out)  # reused by the probe below
     if args.probe:

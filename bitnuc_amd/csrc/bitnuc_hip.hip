@@ -45,6 +45,7 @@ struct bitnuc_ctx {
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
+    int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
 };
 
 namespace {
@@ -281,20 +282,33 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
 hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist,
                        unsigned long long *slot) {
     const unsigned long long rounds = n >= 1024 ? (n - 1024) / kScanWaveWindows + 1 : 0;
-    const unsigned grid = grid_for(c, rounds / (kBlock / 64) + 1);
     uint32_t ql = 0, qh = 0; // de-interleave the packed query into its two bit-planes
     for (unsigned i = 0; i < k; ++i) {
         ql |= (uint32_t)((query >> (2 * i)) & 1) << i;
         qh |= (uint32_t)((query >> (2 * i + 1)) & 1) << i;
     }
-    if (!(aligned16(ref) && aligned16(dist)))
-        kmer_scan_kernel<false, false, false><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot);
-    else switch (c->scan_policy) { // bit0: nt loads, bit1: nt stores
-    case 0: kmer_scan_kernel<true, false, false><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot); break;
-    case 1: kmer_scan_kernel<true, true, false><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot); break;
-    case 2: kmer_scan_kernel<true, false, true><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot); break;
-    default: kmer_scan_kernel<true, true, true><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot); break;
+    const int unroll = c->scan_unroll;
+    const unsigned grid = grid_for(c, rounds / ((kBlock / 64) * unroll) + 1);
+#define SCAN_LAUNCH(AL, NL, NS, U) \
+    kmer_scan_kernel<AL, NL, NS, U><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot)
+#define SCAN_POLICY(U)                                             \
+    switch (c->scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    case 0: SCAN_LAUNCH(true, false, false, U); break;             \
+    case 1: SCAN_LAUNCH(true, true, false, U); break;              \
+    case 2: SCAN_LAUNCH(true, false, true, U); break;              \
+    default: SCAN_LAUNCH(true, true, true, U); break;              \
     }
+    if (!(aligned16(ref) && aligned16(dist))) {
+        SCAN_LAUNCH(false, false, false, 1);
+    } else if (unroll == 1) {
+        SCAN_POLICY(1)
+    } else if (unroll == 2) {
+        SCAN_POLICY(2)
+    } else {
+        SCAN_POLICY(4)
+    }
+#undef SCAN_POLICY
+#undef SCAN_LAUNCH
     return hipGetLastError();
 }
 
@@ -397,6 +411,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
     else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
     else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
+    else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
     else if (!strcmp(key, "num_variants")) { prev = kNumVariants; }
     else if (!strcmp(key, "num_cu")) { prev = c->num_cu; }
     return prev;
@@ -468,7 +483,9 @@ int bitnuc_hdist_dev(bitnuc_ctx *c, const uint64_t *d_a, size_t na, const uint64
     HIPCHK(hipMemsetAsync(d_result, 0, sizeof(uint32_t), c->stream));
     if (n_bases == 0) return BITNUC_OK;
     if (!d_a || !d_b) return fail(err, BITNUC_UNSUPPORTED);
-    const unsigned grid = grid_for(c, (n_bases / 32) / (kBlock * 4) + 1);
+    unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1; // resident grid: one atomic per workgroup
+    const unsigned long long cap = (unsigned long long)c->num_cu * 8;
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hdist_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
                                                  reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result);
     HIPCHK(hipGetLastError());

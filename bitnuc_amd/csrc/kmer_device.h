@@ -168,7 +168,7 @@ __device__ __forceinline__ void planes4(uint32_t x, uint32_t &bad, uint32_t &lni
     hnib2 = __builtin_amdgcn_udot4(dd & 0x02020202u, 0x08040201u, 0u, false); // 2 x (high code bits)
 }
 
-template <bool ALIGNED, bool NTLD, bool NTST>
+template <bool ALIGNED, bool NTLD, bool NTST, int UNROLL>
 __global__ void __launch_bounds__(kBlock)
 kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query,
                  uint32_t ql, uint32_t qh, uint8_t *__restrict__ dist, unsigned long long *__restrict__ slot) {
@@ -177,43 +177,52 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
     const unsigned lane = threadIdx.x & 63;
     const unsigned long long wave = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned long long nwaves = ((unsigned long long)gridDim.x * kBlock) >> 6;
-
     // ql / qh: the query's bit-planes (bit i = low / high code bit of base i), split on the host
     const uint32_t km = k == 32 ? ~0u : ((1u << k) - 1u);
 
-    for (unsigned long long r = wave; r < rounds; r += nwaves) {
-        const unsigned long long wb = r * kScanWaveWindows;
-        const u32x4 v = load_group<NTLD, ALIGNED>(ref + wb + 16 * lane);
-        uint32_t bad = 0, l0, l1, l2, l3, h0, h1, h2, h3;
-        planes4(v.x, bad, l0, h0);
-        planes4(v.y, bad, l1, h1);
-        planes4(v.z, bad, l2, h2);
-        planes4(v.w, bad, l3, h3);
-        const uint32_t L16 = l0 | (l1 << 4) | (l2 << 8) | (l3 << 12);
-        const uint32_t H16x2 = h0 | (h1 << 4) | (h2 << 8) | (h3 << 12);
-        const uint32_t pl = L16 | (H16x2 << 15); // low half: L plane, high half: H plane (16 bases)
-        if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(ref, wb + 16 * lane, 16, slot);
-        const uint32_t n1 = __shfl_down(pl, 1), n2 = __shfl_down(pl, 2);
-        const uint32_t Llo = __builtin_amdgcn_perm(n1, pl, 0x05040100u); // bases 0..31 of this lane's run
-        const uint32_t Hlo = __builtin_amdgcn_perm(n1, pl, 0x07060302u);
-        const uint32_t Lhi = n2 & 0xFFFFu, Hhi = n2 >> 16;               // bases 32..47
-        uint32_t o[4];
+    // a wave owns UNROLL consecutive rounds per trip; all their loads are issued first
+    for (unsigned long long r0 = wave * UNROLL; r0 < rounds; r0 += nwaves * UNROLL) {
+        u32x4 v[UNROLL];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int j = 4 * q + b;
-                const uint32_t l = j ? __builtin_amdgcn_alignbit(Lhi, Llo, j) : Llo;
-                const uint32_t h = j ? __builtin_amdgcn_alignbit(Hhi, Hlo, j) : Hlo;
-                const uint32_t dcount = __builtin_popcount(((l ^ ql) | (h ^ qh)) & km);
-                acc |= dcount << (8 * b);
-            }
-            o[q] = acc;
+        for (int u = 0; u < UNROLL; ++u) {
+            const unsigned long long r = r0 + u < rounds ? r0 + u : rounds - 1; // clamp: redundant but in bounds
+            v[u] = load_group<NTLD, ALIGNED>(ref + r * kScanWaveWindows + 16 * lane);
         }
-        if (lane < 62) {
-            const u32x4 ov = {o[0], o[1], o[2], o[3]};
-            store_group<NTST, ALIGNED>(dist + wb + 16 * lane, ov);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (r0 + u >= rounds) break; // wave-uniform
+            const unsigned long long wb = (r0 + u) * kScanWaveWindows;
+            uint32_t bad = 0, l0, l1, l2, l3, h0, h1, h2, h3;
+            planes4(v[u].x, bad, l0, h0);
+            planes4(v[u].y, bad, l1, h1);
+            planes4(v[u].z, bad, l2, h2);
+            planes4(v[u].w, bad, l3, h3);
+            const uint32_t L16 = l0 | (l1 << 4) | (l2 << 8) | (l3 << 12);
+            const uint32_t H16x2 = h0 | (h1 << 4) | (h2 << 8) | (h3 << 12);
+            const uint32_t pl = L16 | (H16x2 << 15); // low half: L plane, high half: H plane (16 bases)
+            if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(ref, wb + 16 * lane, 16, slot);
+            const uint32_t n1 = __shfl_down(pl, 1), n2 = __shfl_down(pl, 2);
+            const uint32_t Llo = __builtin_amdgcn_perm(n1, pl, 0x05040100u); // bases 0..31 of this lane's run
+            const uint32_t Hlo = __builtin_amdgcn_perm(n1, pl, 0x07060302u);
+            const uint32_t Lhi = n2 & 0xFFFFu, Hhi = n2 >> 16;               // bases 32..47
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int j = 4 * q + b;
+                    const uint32_t l = j ? __builtin_amdgcn_alignbit(Lhi, Llo, j) : Llo;
+                    const uint32_t h = j ? __builtin_amdgcn_alignbit(Hhi, Hlo, j) : Hlo;
+                    const uint32_t dcount = __builtin_popcount(((l ^ ql) | (h ^ qh)) & km);
+                    acc |= dcount << (8 * b);
+                }
+                o[q] = acc;
+            }
+            if (lane < 62) {
+                const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                store_group<NTST, ALIGNED>(dist + wb + 16 * lane, ov);
+            }
         }
     }
 
@@ -240,15 +249,31 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
 __global__ void __launch_bounds__(kBlock)
 hdist_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
              unsigned long long n_bases, uint32_t *__restrict__ result) {
+    // 16 B algorithmic per 32-base word pair.  Grid-stride over word PAIRS with dwordx4
+    // loads when both buffers are 16-byte aligned, u64 loads otherwise; a fixed, resident
+    // grid keeps the number of same-address atomics to one per workgroup (~2048).
     const unsigned long long full = n_bases >> 5;
     const unsigned rem = (unsigned)(n_bases & 31);
+    const unsigned long long gt = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * kBlock;
     uint32_t acc = 0;
-    for (unsigned long long w = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; w < full;
-         w += (unsigned long long)gridDim.x * kBlock) {
+    const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    unsigned long long done = 0;
+    if (al) {
+        const unsigned long long pairs = full >> 1;
+        const u32x4 *a4 = reinterpret_cast<const u32x4 *>(a), *b4 = reinterpret_cast<const u32x4 *>(b);
+        for (unsigned long long p = gt; p < pairs; p += nthreads) {
+            const u32x4 x = __builtin_nontemporal_load(a4 + p) ^ __builtin_nontemporal_load(b4 + p);
+            acc += __builtin_popcount(mismatch_bits(x.x, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.y, 0x55555555u)) +
+                   __builtin_popcount(mismatch_bits(x.z, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.w, 0x55555555u));
+        }
+        done = pairs << 1;
+    }
+    for (unsigned long long w = done + gt; w < full; w += nthreads) {
         const unsigned long long x = a[w] ^ b[w];
         acc += (uint32_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);
     }
-    if (rem && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (rem && blockIdx.x == 0 && threadIdx.x == 0) { // scalar.rs:26-33: bits above 2*rem are ignored
         const unsigned long long mask = (1ull << (2 * rem)) - 1;
         const unsigned long long x = (a[full] ^ b[full]) & mask;
         acc += (uint32_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);

@@ -27,9 +27,8 @@ def shard_word_counts(n_bases, world):
 
 def allgather_packed(local_words, counts=None, group=None):
     """All-gather per-rank packed words (1-D int64/uint64-as-int64 tensors) into the
-    concatenation every rank holds.  Equal counts use the single-buffer in-place form
-    (rank r's shard already sits at offset r*count of the output: no staging copy);
-    ragged counts pad to the maximum and trim."""
+    concatenation every rank holds.  Equal counts are one all_gather_into_tensor straight
+    into the output; ragged counts pad to the maximum and trim."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if counts is None:
@@ -37,8 +36,7 @@ def allgather_packed(local_words, counts=None, group=None):
     assert counts[rank] == local_words.numel()
     if len(set(counts)) == 1:
         out = torch.empty(world * counts[0], dtype=local_words.dtype, device=local_words.device)
-        out[rank * counts[0]:(rank + 1) * counts[0]].copy_(local_words)
-        dist.all_gather_into_tensor(out, out[rank * counts[0]:(rank + 1) * counts[0]], group=group)
+        dist.all_gather_into_tensor(out, local_words.contiguous(), group=group)
         return out
     m = max(counts)
     padded = torch.zeros(m, dtype=local_words.dtype, device=local_words.device)

@@ -326,13 +326,16 @@ def test_kmer_batch_errors(ctx, oracle):
     assert np.array_equal(ctx.as_2bit_batch(b"", 0, 1, 5), np.zeros(5, np.uint64))
 
 
+@pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 32])
-def test_scan_vs_oracle(ctx, oracle, k):
+def test_scan_vs_oracle(ctx, oracle, k, unroll):
+    ctx.set_variant("scan_unroll", unroll)
     for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 2015, 2016, 2017, 2047, 2048, 5000, 200003]:
         s = rand_seq(n)
         q = int(RNG.integers(0, 1 << 62)) | (int(RNG.integers(0, 4)) << 62)
         got = ctx.kmer_hdist_scan(s, k, q)
         assert np.array_equal(got, oracle.kmer_hdist_scan(s, k, q)), (k, n)
+    ctx.set_variant("scan_unroll", 4)
 
 
 def test_scan_errors_and_bench_invariant(ctx, oracle):
