@@ -240,6 +240,54 @@ class Context:
             _raise(err)
         return out
 
+    # -- ragged batches of independent sequences ---------------------------------------------
+    def encode_batch(self, seq, offsets):
+        """Encode `count` back-to-back sequences (sequence i = seq[offsets[i]:offsets[i+1]]).
+        -> (words ndarray[uint64], word_offsets ndarray[uint64] of count+1 entries)."""
+        s = _as_u8(seq)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        count = off.size - 1
+        if count < 0:
+            raise ValueError("offsets needs count+1 entries")
+        cap = int((int(off[-1]) - int(off[0])) // 32 + count) if count else 0
+        out = np.empty(cap, dtype=np.uint64)
+        wo = np.zeros(count + 1, dtype=np.uint64)
+        nw = C.c_size_t(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_encode_batch(self._h, _ptr(s), _ptr(off), count, _ptr(out), cap, _ptr(wo), C.byref(nw), C.byref(err)) != L.OK:
+            if err.status == L.INVALID_RANGE:
+                raise NucleotideError("InvalidRange", index=int(err.value))
+            _raise(err)
+        return out[: nw.value], wo
+
+    def decode_batch(self, words, word_offsets, offsets):
+        """Inverse of encode_batch: -> ndarray[uint8] of offsets[-1] bytes, sequence i at
+        [offsets[i], offsets[i+1]) (bytes before offsets[0] are zero)."""
+        w = _as_u64(words)
+        wo = np.ascontiguousarray(word_offsets, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        count = off.size - 1
+        out = np.zeros(int(off[-1]) if count >= 0 and off.size else 0, dtype=np.uint8)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_decode_batch(self._h, _ptr(w), _ptr(wo), _ptr(off), count, _ptr(out), C.byref(err)) != L.OK:
+            if err.status == L.INVALID_RANGE:
+                raise NucleotideError("InvalidRange", index=int(err.value))
+            _raise(err)
+        return out
+
+    def batch_word_offsets_dev(self, d_offsets, count, d_word_offsets):
+        total = C.c_size_t(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_batch_word_offsets_dev(self._h, _dev_ptr(d_offsets), int(count), _dev_ptr(d_word_offsets), C.byref(total), C.byref(err)) != L.OK:
+            _raise(err)
+        return total.value
+
+    def encode_batch_dev(self, d_seq, d_offsets, d_word_offsets, count, total_words, d_out):
+        self._call_dev(self._lib.bitnuc_encode_batch_dev, _dev_ptr(d_seq), _dev_ptr(d_offsets), _dev_ptr(d_word_offsets), int(count), int(total_words), _dev_ptr(d_out))
+
+    def decode_batch_dev(self, d_words, d_word_offsets, d_offsets, count, total_words, d_out):
+        self._call_dev(self._lib.bitnuc_decode_batch_dev, _dev_ptr(d_words), _dev_ptr(d_word_offsets), _dev_ptr(d_offsets), int(count), int(total_words), _dev_ptr(d_out))
+
     # -- device-pointer API (async; data errors surface at sync()) -----------------------
     def _call_dev(self, fn, *args):
         err = L.BitnucErr()

@@ -12,8 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbitnuc_hip.so")
 SOURCES = [os.path.join(CSRC, "bitnuc_hip.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "codec_device.h"), os.path.join(CSRC, "kmer_device.h"),
-                  os.path.join(HERE, "..", "include", "bitnuc_hip.h")]
+import glob
+
+DEPS = SOURCES + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]
 
 
 def hipcc_path():

@@ -1,0 +1,264 @@
+// batch_device.h -- ragged batches of independent sequences (reads, contigs) in one launch.
+//
+// The reference's user loops `encode(seq_i, &mut ebuf_i)` / `decode(&ebuf_i, len_i, &mut dbuf)`
+// over many short sequences (src/utils/mod.rs:22-25,60-62; each call pads its own last word,
+// packing/avx.rs:147-148).  Here the sequences sit back to back in one buffer with an
+// offsets table, and their words back to back with a word-offsets table
+// (word_offsets[i] = sum_{j<i} ceil(len_j/32)); sequence boundaries fall anywhere, so:
+//   * one lane owns one output WORD; a workgroup owns 256 consecutive words, whose bytes are
+//     one contiguous span of at most 8 KiB because sequences and their words are contiguous;
+//   * the span moves between HBM and LDS with coalesced 16-byte accesses; lanes touch their
+//     (unaligned, 1..32-byte) pieces in LDS only;
+//   * word -> sequence lookup: a small pre-kernel finds the owner of every workgroup's first
+//     word (one binary search per workgroup-to-be, all in parallel), then each lane searches
+//     an LDS window of the next offsets (global fallback if a run of empty sequences
+//     overflows the window).
+#pragma once
+#include "codec_device.h"
+
+namespace bitnuc_dev {
+
+constexpr int kBatchWin = 384;                 // offsets window per workgroup (>= 257 + slack for empty sequences)
+constexpr int kBatchStage = kBlock * 32 + 64;  // 8 KiB span + alignment slack
+
+// index of the sequence that owns word w: upper_bound(word_offsets[0..count], w) - 1
+__device__ __forceinline__ unsigned long long owner_of_word(const unsigned long long *__restrict__ wo,
+                                                            unsigned long long count, unsigned long long w) {
+    unsigned long long lo = 0, hi = count + 1;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if (wo[mid] <= w) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+
+struct WordLoc {
+    unsigned long long base; // byte offset of the word's first base in the sequence buffer
+    unsigned nb;             // bases in this word (1..32)
+};
+
+// owner[b] = sequence that owns word 256*b: one thread per workgroup-to-be, so the ~log2(count)
+// dependent loads of the search are paid once, in parallel, instead of by every workgroup.
+__global__ void __launch_bounds__(kBlock)
+block_owner_kernel(const unsigned long long *__restrict__ word_offsets, unsigned long long count,
+                   unsigned long long nblocks, unsigned long long *__restrict__ owner) {
+    const unsigned long long b = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if (b < nblocks) owner[b] = owner_of_word(word_offsets, count, b * kBlock);
+}
+
+// Fills the LDS window for the workgroup that starts at word wb (whose owner is sb) and
+// resolves this lane's word.  The window grows in steps of 128 sequences until it covers
+// the workgroup's last word (150-base reads need 52 entries; 1-word sequences need 257).
+__device__ __forceinline__ WordLoc locate_word(const unsigned long long *__restrict__ offsets,
+                                               const unsigned long long *__restrict__ word_offsets,
+                                               unsigned long long count, unsigned long long sb, unsigned long long wb,
+                                               unsigned long long w, bool active, unsigned long long *win_wo,
+                                               unsigned long long *win_so) {
+    unsigned filled = 0;
+    for (;;) {
+        for (unsigned i = filled + threadIdx.x; i < filled + 128 && i <= (unsigned)kBatchWin; i += kBlock) {
+            const unsigned long long s = sb + i < count ? sb + i : count;
+            win_wo[i] = word_offsets[s];
+            win_so[i] = offsets[s];
+        }
+        filled = filled + 128 <= (unsigned)kBatchWin + 1 ? filled + 128 : kBatchWin + 1;
+        __syncthreads();
+        if (filled > (unsigned)kBatchWin || win_wo[filled - 1] > wb + kBlock - 1) break; // uniform
+    }
+    WordLoc loc{0, 0};
+    if (!active) return loc;
+    unsigned lo = 0, hi = filled; // upper_bound in the window
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (win_wo[mid] <= w) lo = mid + 1; else hi = mid;
+    }
+    unsigned long long w0, s0, s1;
+    if (lo < filled) {
+        w0 = win_wo[lo - 1]; s0 = win_so[lo - 1]; s1 = win_so[lo];
+    } else { // more sequences start inside this workgroup than the window holds
+        const unsigned long long s = owner_of_word(word_offsets, count, w);
+        w0 = word_offsets[s]; s0 = offsets[s]; s1 = offsets[s + 1];
+    }
+    loc.base = s0 + ((w - w0) << 5);
+    const unsigned long long left = s1 - loc.base;
+    loc.nb = left < 32 ? (unsigned)left : 32u;
+    return loc;
+}
+
+// ---------------------------------------------------------------------------------
+// word offsets: exclusive scan of ceil(len_i / 32), three small kernels
+// ---------------------------------------------------------------------------------
+constexpr int kScanItems = 16; // per thread
+__device__ __forceinline__ unsigned long long words_of(const unsigned long long *__restrict__ offsets, unsigned long long i) {
+    return (offsets[i + 1] - offsets[i] + 31) >> 5;
+}
+
+__device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long long v, unsigned long long *total) {
+    // exclusive scan of one value per thread across the workgroup
+    __shared__ unsigned long long wsum[kBlock / 64];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(inc, off);
+        if (lane >= (unsigned)off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+    for (int i = 0; i < kBlock / 64; ++i) {
+        if ((unsigned)i < wave) before += wsum[i];
+        all += wsum[i];
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+word_offsets_block_sums(const unsigned long long *__restrict__ offsets, unsigned long long count,
+                        unsigned long long *__restrict__ block_sums) {
+    const unsigned long long i0 = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) * kScanItems;
+    unsigned long long s = 0;
+    for (int j = 0; j < kScanItems; ++j)
+        if (i0 + j < count) s += words_of(offsets, i0 + j);
+    unsigned long long total;
+    block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kBlock)
+word_offsets_scan_sums(unsigned long long *__restrict__ block_sums, unsigned long long nblocks) {
+    // single workgroup: thread t owns a contiguous chunk of the block sums
+    const unsigned long long per = (nblocks + kBlock - 1) / kBlock;
+    const unsigned long long b0 = threadIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    unsigned long long s = 0;
+    for (unsigned long long b = b0; b < b1; ++b) s += block_sums[b];
+    unsigned long long total;
+    unsigned long long run = block_exclusive_scan(s, &total);
+    for (unsigned long long b = b0; b < b1; ++b) {
+        const unsigned long long v = block_sums[b];
+        block_sums[b] = run;
+        run += v;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned long long count,
+                    const unsigned long long *__restrict__ block_sums, unsigned long long *__restrict__ word_offsets) {
+    const unsigned long long i0 = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) * kScanItems;
+    unsigned long long v[kScanItems], s = 0;
+    for (int j = 0; j < kScanItems; ++j) {
+        v[j] = i0 + j < count ? words_of(offsets, i0 + j) : 0;
+        s += v[j];
+    }
+    unsigned long long total;
+    unsigned long long run = block_sums[blockIdx.x] + block_exclusive_scan(s, &total);
+    for (int j = 0; j < kScanItems; ++j) {
+        if (i0 + j < count) word_offsets[i0 + j] = run;
+        run += v[j];
+        if (i0 + j + 1 == count) word_offsets[count] = run; // total number of words
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// batched encode
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ offsets,
+                    const unsigned long long *__restrict__ word_offsets, unsigned long long count,
+                    unsigned long long total_words, const unsigned long long *__restrict__ owner,
+                    unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
+    __shared__ unsigned long long win_wo[kBatchWin + 1], win_so[kBatchWin + 1];
+    __shared__ unsigned long long span[2];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kBatchStage];
+    const unsigned t = threadIdx.x;
+    for (unsigned long long wb = (unsigned long long)blockIdx.x * kBlock; wb < total_words;
+         wb += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long w = wb + t;
+        const bool active = w < total_words;
+        __syncthreads(); // previous trip's LDS readers are done
+        const WordLoc loc = locate_word(offsets, word_offsets, count, owner[wb / kBlock], wb, w, active, win_wo, win_so);
+        if (t == 0) span[0] = loc.base;
+        if (active && (w + 1 == total_words || t == kBlock - 1)) span[1] = loc.base + loc.nb;
+        __syncthreads();
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(seq) + span[0], hi = reinterpret_cast<uintptr_t>(seq) + span[1];
+        const uintptr_t lo16 = lo & ~(uintptr_t)15;
+        const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
+        for (unsigned c = t; c < nchunk; c += kBlock)
+            *reinterpret_cast<u32x4 *>(stage + 16 * c) = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)c));
+        __syncthreads();
+        if (!active) continue;
+        const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16);
+        const unsigned nfull = loc.nb >> 2, rem = loc.nb & 3;
+        uint32_t bad = 0, wlo = 0, whi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t x = *reinterpret_cast<const u32_u *>(stage + off + 4 * i); // unaligned LDS dword (gfx950: supported)
+            if ((unsigned)i == nfull) { // partial dword: bytes past the sequence end become 'A' (code 0, valid)
+                const uint32_t keep = rem ? ((1u << (8 * rem)) - 1u) : 0u;
+                x = (x & keep) | (0x41414141u & ~keep);
+            } else if ((unsigned)i > nfull) {
+                x = 0x41414141u;
+            }
+            const uint32_t r = enc4(x, bad);
+            if (i < 4) wlo |= r << (8 * i); else whi |= r << (8 * (i - 4));
+        }
+        out[w] = ((unsigned long long)whi << 32) | wlo;
+        if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, loc.base, loc.nb, slot);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// batched decode: sequence i's bases go to out[offsets[i] .. offsets[i+1])
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ word_offsets,
+                    const unsigned long long *__restrict__ offsets, unsigned long long count,
+                    unsigned long long total_words, const unsigned long long *__restrict__ owner,
+                    uint8_t *__restrict__ out) {
+    __shared__ unsigned long long win_wo[kBatchWin + 1], win_so[kBatchWin + 1];
+    __shared__ unsigned long long span[2];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kBatchStage];
+    const unsigned t = threadIdx.x;
+    for (unsigned long long wb = (unsigned long long)blockIdx.x * kBlock; wb < total_words;
+         wb += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long w = wb + t;
+        const bool active = w < total_words;
+        const unsigned long long word = active ? __builtin_nontemporal_load(words + w) : 0ull;
+        __syncthreads();
+        const WordLoc loc = locate_word(offsets, word_offsets, count, owner[wb / kBlock], wb, w, active, win_wo, win_so);
+        if (t == 0) span[0] = loc.base;
+        if (active && (w + 1 == total_words || t == kBlock - 1)) span[1] = loc.base + loc.nb;
+        __syncthreads();
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + span[0], hi = reinterpret_cast<uintptr_t>(out) + span[1];
+        const uintptr_t lo16 = lo & ~(uintptr_t)15;
+        if (active) {
+            const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(out) + loc.base - lo16);
+            const u32x4 a = dec16((uint32_t)word), b = dec16((uint32_t)(word >> 32));
+            const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const unsigned nfull = loc.nb >> 2, rem = loc.nb & 3;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if ((unsigned)i < nfull) *reinterpret_cast<u32_u *>(stage + off + 4 * i) = d[i];
+                else if ((unsigned)i == nfull)
+                    for (unsigned j = 0; j < rem; ++j) stage[off + 4 * i + j] = (uint8_t)(d[i] >> (8 * j));
+            }
+        }
+        __syncthreads();
+        // coalesced write-out; the first/last 16-byte chunk may be shared with a neighbouring
+        // workgroup's span, so only this span's bytes are written there
+        const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
+        for (unsigned c = t; c < nchunk; c += kBlock) {
+            const uintptr_t g = lo16 + 16 * (uintptr_t)c;
+            if (g >= lo && g + 16 <= hi) {
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(stage + 16 * c), reinterpret_cast<u32x4 *>(g));
+            } else {
+                for (unsigned j = 0; j < 16; ++j)
+                    if (g + j >= lo && g + j < hi) *reinterpret_cast<uint8_t *>(g + j) = stage[16 * c + j];
+            }
+        }
+    }
+}
+
+} // namespace bitnuc_dev

@@ -8,6 +8,7 @@
 #include "../../include/bitnuc_hip.h"
 #include "codec_device.h"
 #include "kmer_device.h"
+#include "batch_device.h"
 
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -38,8 +39,8 @@ struct bitnuc_ctx {
     int n_pending = 0;
     bool have_deferred = false; // an error found by an implicit drain, reported at next sync
     bitnuc_err deferred;
-    uint8_t *scratch[3] = {nullptr, nullptr, nullptr};
-    size_t scratch_cap[3] = {0, 0, 0};
+    uint8_t *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_cap[6] = {0, 0, 0, 0, 0, 0};
     uint32_t *d_sink = nullptr;
     int enc_variant = 3, dec_variant = 1; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
@@ -375,7 +376,7 @@ void bitnuc_ctx_destroy(bitnuc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 6; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->h_slots) (void)hipHostFree(c->h_slots);
@@ -677,6 +678,150 @@ int bitnuc_hdist(bitnuc_ctx *c, const uint64_t *a, size_t na, const uint64_t *b,
         total += part; // u32 wrap-around like the reference's accumulator (multi.rs:130)
     }
     *out = total;
+    return BITNUC_OK;
+}
+
+// ---- ragged batches ---------------------------------------------------------------------------
+// owner[b] of every 256-word workgroup, into context scratch (enqueued on the stream)
+static int batch_owners(bitnuc_ctx *c, const uint64_t *d_word_offsets, size_t count, size_t total_words,
+                        const unsigned long long **owner, bitnuc_err *err) {
+    const size_t nblocks = (total_words + kBlock - 1) / kBlock;
+    if (int st = ensure_scratch(c, 3, nblocks * sizeof(uint64_t), err)) return st;
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(c->scratch[3]);
+    block_owner_kernel<<<(unsigned)((nblocks + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(
+        reinterpret_cast<const unsigned long long *>(d_word_offsets), count, nblocks, o);
+    HIPCHK(hipGetLastError());
+    *owner = o;
+    return BITNUC_OK;
+}
+
+static int check_offsets(const uint64_t *offsets, size_t count, bitnuc_err *err) {
+    for (size_t i = 0; i < count; ++i)
+        if (offsets[i + 1] < offsets[i]) { // argument check only (not codec arithmetic)
+            if (err) { memset(err, 0, sizeof *err); err->status = BITNUC_INVALID_RANGE; err->value = i + 1; }
+            return BITNUC_INVALID_RANGE;
+        }
+    return BITNUC_OK;
+}
+
+int bitnuc_batch_word_offsets_dev(bitnuc_ctx *c, const uint64_t *d_offsets, size_t count, uint64_t *d_word_offsets, size_t *total_words, bitnuc_err *err) {
+    clear_err(err);
+    if (total_words) *total_words = 0;
+    if (int st = check_ctx(c, err)) return st;
+    if (!d_word_offsets || (count && !d_offsets)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (count == 0) {
+        HIPCHK(hipMemsetAsync(d_word_offsets, 0, sizeof(uint64_t), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return BITNUC_OK;
+    }
+    const size_t per_block = (size_t)kBlock * kScanItems;
+    const size_t nblocks = (count + per_block - 1) / per_block;
+    if (int st = ensure_scratch(c, 3, nblocks * sizeof(uint64_t), err)) return st;
+    unsigned long long *sums = reinterpret_cast<unsigned long long *>(c->scratch[3]);
+    const unsigned long long *off = reinterpret_cast<const unsigned long long *>(d_offsets);
+    unsigned long long *wo = reinterpret_cast<unsigned long long *>(d_word_offsets);
+    word_offsets_block_sums<<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums);
+    word_offsets_scan_sums<<<1, kBlock, 0, c->stream>>>(sums, nblocks);
+    word_offsets_finish<<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums, wo);
+    HIPCHK(hipGetLastError());
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_word_offsets + count, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (total_words) *total_words = (size_t)total;
+    return BITNUC_OK;
+}
+
+int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, const uint64_t *d_word_offsets, size_t count, size_t total_words, uint64_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0 || total_words == 0) return BITNUC_OK;
+    if (!d_seq || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const unsigned long long *owner;
+    if (int st = batch_owners(c, d_word_offsets, count, total_words, &owner, err)) return st;
+    unsigned long long *slot;
+    if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
+    const unsigned grid = grid_for(c, (total_words + kBlock - 1) / kBlock);
+    encode_batch_kernel<<<grid, kBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
+                                                        reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, owner,
+                                                        reinterpret_cast<unsigned long long *>(d_out), slot);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64_t *d_word_offsets, const uint64_t *d_offsets, size_t count, size_t total_words, uint8_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0 || total_words == 0) return BITNUC_OK;
+    if (!d_words || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const unsigned long long *owner;
+    if (int st = batch_owners(c, d_word_offsets, count, total_words, &owner, err)) return st;
+    const unsigned grid = grid_for(c, (total_words + kBlock - 1) / kBlock);
+    decode_batch_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words),
+                                                        reinterpret_cast<const unsigned long long *>(d_word_offsets),
+                                                        reinterpret_cast<const unsigned long long *>(d_offsets), count, total_words, owner, d_out);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_encode_batch(bitnuc_ctx *c, const uint8_t *seq, const uint64_t *offsets, size_t count, uint64_t *out, size_t out_cap_words, uint64_t *word_offsets, size_t *n_words, bitnuc_err *err) {
+    clear_err(err);
+    if (n_words) *n_words = 0;
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0) { if (word_offsets) word_offsets[0] = 0; return BITNUC_OK; }
+    if (!offsets || !word_offsets) return fail(err, BITNUC_UNSUPPORTED);
+    if (int st = check_offsets(offsets, count, err)) return st;
+    DeviceGuard g(c->device);
+    { bitnuc_err e; int st = bitnuc_ctx_sync(c, &e); if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; } }
+    const uint64_t b0 = offsets[0], nbytes = offsets[count] - b0;
+    if (int st = ensure_scratch(c, 0, nbytes + 16, err)) return st;
+    if (int st = ensure_scratch(c, 4, (count + 1) * 8, err)) return st;
+    if (int st = ensure_scratch(c, 5, (count + 1) * 8, err)) return st;
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(c->scratch[4]), *d_wo = reinterpret_cast<uint64_t *>(c->scratch[5]);
+    if (nbytes && !seq) return fail(err, BITNUC_UNSUPPORTED);
+    if (nbytes) HIPCHK(hipMemcpyAsync(c->scratch[0], seq + b0, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_off, offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    size_t total = 0;
+    if (int st = bitnuc_batch_word_offsets_dev(c, d_off, count, d_wo, &total, err)) return st;
+    HIPCHK(hipMemcpyAsync(word_offsets, d_wo, (count + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (total > out_cap_words || (total && !out)) { HIPCHK(hipStreamSynchronize(c->stream)); return fail(err, BITNUC_INVALID_LENGTH, total); }
+    if (int st = ensure_scratch(c, 1, total * 8 + 16, err)) return st;
+    // the kernel indexes the sequence buffer with the caller's offsets: rebase the device pointer
+    const uint8_t *d_seq = c->scratch[0] - b0;
+    if (total) {
+        if (int st = bitnuc_encode_batch_dev(c, d_seq, d_off, d_wo, count, total, reinterpret_cast<uint64_t *>(c->scratch[1]), err)) return st;
+        HIPCHK(hipMemcpyAsync(out, c->scratch[1], total * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    bitnuc_err e;
+    int st = drain(c, &e);
+    if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    if (n_words) *n_words = total;
+    return BITNUC_OK;
+}
+
+int bitnuc_decode_batch(bitnuc_ctx *c, const uint64_t *words, const uint64_t *word_offsets, const uint64_t *offsets, size_t count, uint8_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0) return BITNUC_OK;
+    if (!offsets || !word_offsets) return fail(err, BITNUC_UNSUPPORTED);
+    if (int st = check_offsets(offsets, count, err)) return st;
+    const uint64_t b0 = offsets[0], nbytes = offsets[count] - b0, total = word_offsets[count];
+    if (total == 0) return BITNUC_OK;
+    if (!words || !out) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (int st = ensure_scratch(c, 0, nbytes + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, total * 8 + 16, err)) return st;
+    if (int st = ensure_scratch(c, 4, (count + 1) * 8, err)) return st;
+    if (int st = ensure_scratch(c, 5, (count + 1) * 8, err)) return st;
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(c->scratch[4]), *d_wo = reinterpret_cast<uint64_t *>(c->scratch[5]);
+    HIPCHK(hipMemcpyAsync(c->scratch[1], words, total * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_off, offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_wo, word_offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (int st = bitnuc_decode_batch_dev(c, reinterpret_cast<const uint64_t *>(c->scratch[1]), d_wo, d_off, count, total, c->scratch[0] - b0, err)) return st;
+    HIPCHK(hipMemcpyAsync(out + b0, c->scratch[0], nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return BITNUC_OK;
 }
 

@@ -119,6 +119,27 @@ int bitnuc_kmer_hdist_scan_dev(bitnuc_ctx *ctx, const uint8_t *d_ref, size_t n, 
 /* d_result: one uint32 in device memory, overwritten with the distance. */
 int bitnuc_hdist_dev(bitnuc_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, size_t n_bases, uint32_t *d_result, bitnuc_err *err);
 
+/* ---- ragged batches of independent sequences (reads, contigs) ----------------------------- */
+/* The reference's idiom is a host loop `for s in seqs { encode(s, &mut ebuf)? }` /
+ * `decode(&ebuf, len, &mut dbuf)?` (src/utils/mod.rs:22-25,60-62), each sequence padding its
+ * own last word (packing/avx.rs:147-148).  Here the `count` sequences sit back to back:
+ * sequence i = seq[offsets[i] .. offsets[i+1]) (offsets has count+1 non-decreasing entries)
+ * and its ceil(len_i/32) words start at out[word_offsets[i]], where
+ * word_offsets[i] = sum_{j<i} ceil(len_j/32) and word_offsets[count] = total words.
+ * Zero-length sequences produce no words (the reference panics on them).  The first
+ * invalid byte in buffer order -> INVALID_BASE{byte, index = byte offset in seq}. */
+/* Compute word_offsets (count+1 entries, device memory) from device offsets; synchronous;
+ * *total_words = word_offsets[count]. */
+int bitnuc_batch_word_offsets_dev(bitnuc_ctx *ctx, const uint64_t *d_offsets, size_t count, uint64_t *d_word_offsets, size_t *total_words, bitnuc_err *err);
+int bitnuc_encode_batch_dev(bitnuc_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, const uint64_t *d_word_offsets, size_t count, size_t total_words, uint64_t *d_out, bitnuc_err *err);
+/* Writes sequence i's bases at d_out[offsets[i] .. offsets[i+1]) (the layout encode_batch read). */
+int bitnuc_decode_batch_dev(bitnuc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_word_offsets, const uint64_t *d_offsets, size_t count, size_t total_words, uint8_t *d_out, bitnuc_err *err);
+/* Host-pointer forms (synchronous).  encode: out must hold sum ceil(len_i/32) words
+ * (<= (offsets[count]-offsets[0])/32 + count); word_offsets (count+1 entries) is an output.
+ * offsets that decrease -> INVALID_RANGE{value = index of the offending entry}. */
+int bitnuc_encode_batch(bitnuc_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, size_t count, uint64_t *out, size_t out_cap_words, uint64_t *word_offsets, size_t *n_words, bitnuc_err *err);
+int bitnuc_decode_batch(bitnuc_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets, const uint64_t *offsets, size_t count, uint8_t *out, bitnuc_err *err);
+
 /* ---- synthetic input (the reference's tests use nucgen::Sequence::fill_buffer,
  * src/utils/mod.rs:116-121; its stream is unpinned, so the build ships its own) ---- */
 /* Fill d_out[0..len) with bases first..first+len of the seeded stream

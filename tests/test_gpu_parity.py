@@ -358,6 +358,100 @@ def test_scan_errors_and_bench_invariant(ctx, oracle):
         assert d[i] == int((ref[i:i + 32] != qs).sum())
 
 
+# ---- ragged batches of independent sequences ----------------------------------------------------
+def _ragged(lengths, alpha=ALPHA8):
+    off = np.zeros(len(lengths) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lengths)
+    return rand_seq(int(off[-1]), alpha), off
+
+
+def _oracle_batch(oracle, seq, off):
+    words, wo = [], [0]
+    for i in range(len(off) - 1):
+        s = seq[int(off[i]):int(off[i + 1])]
+        w = oracle.encode(s) if len(s) else np.zeros(0, np.uint64)  # host loop of encode(), one call per sequence
+        words.append(w)
+        wo.append(wo[-1] + len(w))
+    return (np.concatenate(words) if words else np.zeros(0, np.uint64)), np.array(wo, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("shape", ["reads150", "tiny", "mixed", "with_empties", "one_long", "many_empties"])
+def test_batch_encode_decode_vs_oracle_loop(ctx, oracle, shape):
+    lengths = {
+        "reads150": [150] * 3000,
+        "tiny": list(RNG.integers(1, 5, size=5000)),
+        "mixed": list(RNG.integers(1, 400, size=2000)) + [100000, 31, 32, 33, 64, 1],
+        "with_empties": [0, 0, 5, 0, 37, 0, 0, 0, 64, 0] * 200,
+        "one_long": [1000003],
+        "many_empties": [0] * 1000 + [40] + [0] * 2000 + [7, 0, 0, 33] + [0] * 500,
+    }[shape]
+    seq, off = _ragged(lengths)
+    ew, ewo = _oracle_batch(oracle, seq, off)
+    w, wo = ctx.encode_batch(seq, off)
+    assert np.array_equal(wo, ewo), shape
+    assert np.array_equal(w, ew), shape
+    back = ctx.decode_batch(w, wo, off)
+    assert bytes(back) == bytes(seq).upper(), shape
+
+
+def test_batch_offsets_base_and_errors(ctx, oracle):
+    import bitnuc_amd as bn
+    lengths = list(RNG.integers(1, 300, size=1500))
+    seq, off = _ragged(lengths)
+    # a batch that starts in the middle of the buffer (offsets[0] != 0), unaligned
+    pre = 37
+    buf = np.concatenate([np.full(pre, ord("N"), np.uint8), seq, np.full(11, ord("N"), np.uint8)])
+    off2 = off + np.uint64(pre)
+    w, wo = ctx.encode_batch(buf, off2)
+    ew, ewo = _oracle_batch(oracle, seq, off)
+    assert np.array_equal(w, ew) and np.array_equal(wo, ewo)
+    back = ctx.decode_batch(w, wo, off2)
+    assert bytes(back[pre:pre + len(seq)]) == bytes(seq).upper() and not back[:pre].any()
+    # first invalid byte in buffer order, reported with its byte offset
+    bad = seq.copy()
+    p1, p2 = int(off[700]) + 3, int(off[900])
+    bad[p1], bad[p2] = ord("N"), ord("X")
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.encode_batch(bad, off)
+    assert (ei.value.kind, ei.value.byte, ei.value.index) == ("InvalidBase", ord("N"), p1)
+    # decreasing offsets
+    off_bad = off.copy()
+    off_bad[10] = off_bad[9] - np.uint64(1)
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.encode_batch(seq, off_bad)
+    assert ei.value.kind == "InvalidRange"
+    # empty batch
+    w, wo = ctx.encode_batch(b"", np.zeros(1, np.uint64))
+    assert w.size == 0 and list(wo) == [0]
+
+
+def test_batch_full_scale_reads(ctx, oracle):
+    """~6.7 M reads of 150 bases (10^9 bases): device path, spot-checked against the oracle loop."""
+    import torch
+    dev = torch.device("cuda:0")
+    L, count = 150, 6_666_666
+    n = L * count
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, n, 0xB17C0DE)
+    off = torch.arange(0, count + 1, dtype=torch.int64, device=dev) * L
+    wo = torch.empty(count + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    total = ctx.batch_word_offsets_dev(off, count, wo)
+    assert total == count * 5
+    assert torch.equal(wo, torch.arange(0, count + 1, dtype=torch.int64, device=dev) * 5)
+    words = torch.empty(total, dtype=torch.int64, device=dev)
+    back = torch.zeros(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.encode_batch_dev(seq, off, wo, count, total, words)
+    ctx.decode_batch_dev(words, wo, off, count, total, back)
+    ctx.sync()
+    assert torch.equal(seq, back)
+    for r0 in (0, 1_234_567, count - 2000):
+        h = seq[r0 * L:(r0 + 2000) * L].cpu().numpy()
+        exp = np.concatenate([oracle.encode(h[i * L:(i + 1) * L]) for i in range(2000)])
+        assert np.array_equal(words[r0 * 5:(r0 + 2000) * 5].cpu().numpy().view(np.uint64), exp)
+
+
 def test_hdist_bulk_vs_oracle(ctx, oracle):
     for n in [1, 31, 32, 33, 127, 128, 129, 100000, 1000003]:
         a, b = rand_seq(n, ALPHA), rand_seq(n, ALPHA)
