@@ -68,14 +68,15 @@ int fail_hip(bitnuc_err *e, hipError_t rc) {
         if (rc__ != hipSuccess) return fail_hip(err, rc__); \
     } while (0)
 
-struct DeviceGuard { // hipSetDevice is per-thread state: make every entry point self-contained
+struct DeviceGuard { // hipSetDevice is per-thread state: every entry point selects the context's device and restores the caller's
     int prev = -1;
-    bool ok;
+    bool changed = false;
     explicit DeviceGuard(int dev) {
-        ok = hipGetDevice(&prev) == hipSuccess;
-        if (ok && prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
     }
-    ~DeviceGuard() {}
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
 };
 
 int ensure_scratch(bitnuc_ctx *c, int which, size_t bytes, bitnuc_err *err) {
@@ -118,6 +119,17 @@ int drain(bitnuc_ctx *c, bitnuc_err *err) {
     c->n_pending = 0;
     if (err) *err = found;
     return found.status;
+}
+
+// Host-pointer (synchronous) calls start from an empty slot ring so that the error they
+// return is their own; an InvalidBase latched by earlier asynchronous launches is kept for
+// the next bitnuc_ctx_sync().
+int flush_pending(bitnuc_ctx *c, bitnuc_err *err) {
+    bitnuc_err e;
+    const int st = drain(c, &e);
+    if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
+    if (st != BITNUC_OK && !c->have_deferred) { c->have_deferred = true; c->deferred = e; }
+    return BITNUC_OK;
 }
 
 // Reserve the error slot of the next launch (drains implicitly when the ring is full).
@@ -543,7 +555,7 @@ int bitnuc_encode(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, 
     if (len == 0) return BITNUC_OK;
     if (!seq || !out) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    { bitnuc_err e; int st = bitnuc_ctx_sync(c, &e); if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; } }
+    if (int st = flush_pending(c, err)) return st;
     const size_t chunk = len < kHostChunk ? len : kHostChunk;
     if (int st = ensure_scratch(c, 0, chunk + 16, err)) return st;
     if (int st = ensure_scratch(c, 1, ((chunk + 31) / 32) * 8 + 16, err)) return st;
@@ -598,7 +610,7 @@ int bitnuc_as_2bit_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t s
     if (k == 0) { memset(out, 0, sizeof(uint64_t) * count); return BITNUC_OK; }
     if (!kmers) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    { bitnuc_err e; int st = bitnuc_ctx_sync(c, &e); if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; } }
+    if (int st = flush_pending(c, err)) return st;
     // chunk by k-mers so a staged chunk stays <= kHostChunk bytes
     size_t per = kHostChunk / stride;
     if (per == 0) per = 1;
@@ -627,7 +639,7 @@ int bitnuc_kmer_hdist_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k
     if (k == 0 || n < k) return BITNUC_OK;
     if (!ref || !dist) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    { bitnuc_err e; int st = bitnuc_ctx_sync(c, &e); if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; } }
+    if (int st = flush_pending(c, err)) return st;
     const size_t nwin = n - k + 1;
     const size_t chunk = nwin < kHostChunk ? nwin : kHostChunk; // windows per staged chunk
     if (int st = ensure_scratch(c, 0, chunk + k + 16, err)) return st;
@@ -774,7 +786,7 @@ int bitnuc_encode_batch(bitnuc_ctx *c, const uint8_t *seq, const uint64_t *offse
     if (!offsets || !word_offsets) return fail(err, BITNUC_UNSUPPORTED);
     if (int st = check_offsets(offsets, count, err)) return st;
     DeviceGuard g(c->device);
-    { bitnuc_err e; int st = bitnuc_ctx_sync(c, &e); if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; } }
+    if (int st = flush_pending(c, err)) return st;
     const uint64_t b0 = offsets[0], nbytes = offsets[count] - b0;
     if (int st = ensure_scratch(c, 0, nbytes + 16, err)) return st;
     if (int st = ensure_scratch(c, 4, (count + 1) * 8, err)) return st;

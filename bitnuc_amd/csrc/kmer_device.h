@@ -159,6 +159,11 @@ kmer_dense_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
 // Needs bytes [wb, wb+1024) in bounds; the leftover windows go through the tail loop.
 constexpr unsigned kScanWaveWindows = 992;
 
+// lane i <- lane i+1 across the whole wave64 (gfx9 DPP wave_shl:1); lane 63 gets 0
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+}
+
 __device__ __forceinline__ void planes4(uint32_t x, uint32_t &bad, uint32_t &lnib, uint32_t &hnib2) {
     const uint32_t sel = x & 0x07070707u;
     const uint32_t t = __builtin_amdgcn_perm(0x42040453u, 0x41044004u, sel); // same LUT as enc4
@@ -201,7 +206,8 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
             const uint32_t H16x2 = h0 | (h1 << 4) | (h2 << 8) | (h3 << 12);
             const uint32_t pl = L16 | (H16x2 << 15); // low half: L plane, high half: H plane (16 bases)
             if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(ref, wb + 16 * lane, 16, slot);
-            const uint32_t n1 = __shfl_down(pl, 1), n2 = __shfl_down(pl, 2);
+            // planes of lanes l+1 and l+2: whole-wave DPP shifts (v_mov_b32 wave_shl:1), no LDS round trip
+            const uint32_t n1 = wave_shl1(pl), n2 = wave_shl1(n1);
             const uint32_t Llo = __builtin_amdgcn_perm(n1, pl, 0x05040100u); // bases 0..31 of this lane's run
             const uint32_t Hlo = __builtin_amdgcn_perm(n1, pl, 0x07060302u);
             const uint32_t Lhi = n2 & 0xFFFFu, Hhi = n2 >> 16;               // bases 32..47

@@ -213,6 +213,32 @@ class Context {
         return out;
     }
 
+    // Ragged batch: `for s in seqs { encode(s, &mut ebuf)? }` in one launch.  Sequence i =
+    // seq[offsets[i] .. offsets[i+1]); returns the concatenated words and fills word_offsets
+    // (count+1 entries, word_offsets[i] = first word of sequence i).
+    Result<std::vector<uint64_t>> encode_batch(Bytes seq, const std::vector<uint64_t> &offsets,
+                                               std::vector<uint64_t> &word_offsets) const {
+        const size_t count = offsets.empty() ? 0 : offsets.size() - 1;
+        word_offsets.assign(count + 1, 0);
+        std::vector<uint64_t> out(count ? (size_t)((offsets[count] - offsets[0]) / 32 + count) : 0);
+        size_t nw = 0;
+        bitnuc_err e;
+        int st = bitnuc_encode_batch(ctx_, seq.ptr, offsets.data(), count, out.data(), out.size(), word_offsets.data(), &nw, &e);
+        if (st != BITNUC_OK) return NucleotideError::from_c(e);
+        out.resize(nw);
+        return out;
+    }
+    // Inverse: sequence i's bases are written at out[offsets[i] .. offsets[i+1]).
+    Result<std::vector<uint8_t>> decode_batch(Words words, const std::vector<uint64_t> &word_offsets,
+                                              const std::vector<uint64_t> &offsets) const {
+        const size_t count = offsets.empty() ? 0 : offsets.size() - 1;
+        std::vector<uint8_t> out(count ? (size_t)offsets[count] : 0);
+        bitnuc_err e;
+        if (bitnuc_decode_batch(ctx_, words.ptr, word_offsets.data(), offsets.data(), count, out.data(), &e) != BITNUC_OK)
+            return NucleotideError::from_c(e);
+        return out;
+    }
+
   private:
     bitnuc_ctx *ctx_ = nullptr;
 };

@@ -51,6 +51,11 @@ extern "C" {
     pub fn bitnuc_as_2bit_batch_dev(ctx: *mut bitnuc_ctx, d_kmers: *const u8, k: usize, stride: usize, count: usize, d_out: *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_kmer_hdist_scan_dev(ctx: *mut bitnuc_ctx, d_ref: *const u8, n: usize, k: usize, query: u64, d_dist: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_hdist_dev(ctx: *mut bitnuc_ctx, d_a: *const u64, na: usize, d_b: *const u64, nb: usize, n_bases: usize, d_result: *mut u32, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_batch_word_offsets_dev(ctx: *mut bitnuc_ctx, d_offsets: *const u64, count: usize, d_word_offsets: *mut u64, total_words: *mut usize, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_encode_batch_dev(ctx: *mut bitnuc_ctx, d_seq: *const u8, d_offsets: *const u64, d_word_offsets: *const u64, count: usize, total_words: usize, d_out: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_decode_batch_dev(ctx: *mut bitnuc_ctx, d_words: *const u64, d_word_offsets: *const u64, d_offsets: *const u64, count: usize, total_words: usize, d_out: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_encode_batch(ctx: *mut bitnuc_ctx, seq: *const u8, offsets: *const u64, count: usize, out: *mut u64, out_cap_words: usize, word_offsets: *mut u64, n_words: *mut usize, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_decode_batch(ctx: *mut bitnuc_ctx, words: *const u64, word_offsets: *const u64, offsets: *const u64, count: usize, out: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_nucgen_dev(ctx: *mut bitnuc_ctx, d_out: *mut u8, len: usize, seed: u64, first: u64, flags: c_int, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_stream_probe_dev(ctx: *mut bitnuc_ctx, mode: c_int, d_src: *const c_void, d_dst: *mut c_void, bytes: usize, err: *mut bitnuc_err) -> c_int;
 }

@@ -190,6 +190,37 @@ pub fn kmer_hdist_scan(reference: &[u8], k: usize, query: u64) -> Result<Vec<u8>
     if st == ffi::BITNUC_OK { Ok(out) } else { Err(to_err(&e)) }
 }
 
+/// `for s in seqs { encode(s, &mut ebuf)? }` in one launch: sequence i =
+/// `seq[offsets[i]..offsets[i+1]]`; returns (concatenated words, word_offsets).
+pub fn encode_batch(seq: &[u8], offsets: &[u64]) -> Result<(Vec<u64>, Vec<u64>), NucleotideError> {
+    let count = offsets.len().saturating_sub(1);
+    let cap = if count > 0 { ((offsets[count] - offsets[0]) / 32) as usize + count } else { 0 };
+    let mut out = vec![0u64; cap];
+    let mut word_offsets = vec![0u64; count + 1];
+    let mut n_words = 0usize;
+    let mut e = ffi::bitnuc_err::default();
+    let st = with_ctx(|c| unsafe {
+        ffi::bitnuc_encode_batch(c, seq.as_ptr(), offsets.as_ptr(), count, out.as_mut_ptr(), cap,
+                                 word_offsets.as_mut_ptr(), &mut n_words, &mut e)
+    });
+    if st != ffi::BITNUC_OK {
+        return Err(to_err(&e));
+    }
+    out.truncate(n_words);
+    Ok((out, word_offsets))
+}
+
+/// Inverse of `encode_batch`: sequence i's bases land at `out[offsets[i]..offsets[i+1]]`.
+pub fn decode_batch(words: &[u64], word_offsets: &[u64], offsets: &[u64]) -> Result<Vec<u8>, NucleotideError> {
+    let count = offsets.len().saturating_sub(1);
+    let mut out = vec![0u8; if count > 0 { offsets[count] as usize } else { 0 }];
+    let mut e = ffi::bitnuc_err::default();
+    let st = with_ctx(|c| unsafe {
+        ffi::bitnuc_decode_batch(c, words.as_ptr(), word_offsets.as_ptr(), offsets.as_ptr(), count, out.as_mut_ptr(), &mut e)
+    });
+    if st == ffi::BITNUC_OK { Ok(out) } else { Err(to_err(&e)) }
+}
+
 #[cfg(test)]
 mod testing {
     // the reference's own unit tests (src/utils/packing/mod.rs:144-198 etc.) run unchanged

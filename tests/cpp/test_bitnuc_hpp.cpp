@@ -125,6 +125,29 @@ static void test_hdist() {
     }
 }
 
+static void test_batch_equals_loop() {
+    std::mt19937_64 rng(7);
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> offsets{0};
+    for (int i = 0; i < 500; ++i) {
+        size_t len = 1 + rng() % 200;
+        for (size_t j = 0; j < len; ++j) seq.push_back("ACGTacgt"[rng() & 7]);
+        offsets.push_back(seq.size());
+    }
+    std::vector<uint64_t> word_offsets;
+    auto words = default_context().encode_batch(seq, offsets, word_offsets).unwrap();
+    std::vector<uint64_t> expect;
+    for (size_t i = 0; i + 1 < offsets.size(); ++i) { // the reference's idiom: one encode() per sequence
+        CHECK(word_offsets[i] == expect.size());
+        auto w = encode_alloc(Bytes(seq.data() + offsets[i], offsets[i + 1] - offsets[i])).unwrap();
+        expect.insert(expect.end(), w.begin(), w.end());
+    }
+    CHECK(words == expect && word_offsets.back() == expect.size());
+    auto back = default_context().decode_batch(words, word_offsets, offsets).unwrap();
+    CHECK(back.size() == seq.size());
+    for (size_t i = 0; i < seq.size(); ++i) CHECK(back[i] == (seq[i] & 0xDF));
+}
+
 int main() {
 #define RUN(t) do { t(); std::printf("ok %s\n", #t); } while (0)
     RUN(test_as_2bit_valid_sequence);
@@ -140,6 +163,7 @@ int main() {
     RUN(test_large_sequence_round_trip);
     RUN(test_encode_error_keeps_prefix_words);
     RUN(test_hdist);
+    RUN(test_batch_equals_loop);
     std::printf("ALL OK\n");
     return 0;
 }

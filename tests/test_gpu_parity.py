@@ -237,6 +237,15 @@ def test_dev_path_unaligned_and_async_errors(ctx, oracle):
         ctx.sync()
     assert (ei.value.byte, ei.value.index) == (ord("N"), 1234)
     ctx.sync()  # cleared
+    # a synchronous host-pointer call between an async error and its sync reports only its
+    # own result; the latched async error is kept for the next sync
+    ctx.encode_dev(bad2, n, words)
+    assert ctx.as_2bit(b"ACGT") == 0xE4
+    assert np.array_equal(ctx.encode_array(s[:1000]), oracle.encode(s[:1000]))
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.sync()
+    assert (ei.value.byte, ei.value.index) == (ord("Z"), 7)
+    ctx.sync()
 
 
 def test_kmer_dev_paths_unaligned(ctx, oracle):
@@ -511,6 +520,72 @@ def test_full_size_roundtrip_and_checksums(ctx, oracle):
     with pytest.raises(bn.NucleotideError) as ei:
         ctx.sync()
     assert (ei.value.byte, ei.value.index) == (ord("N"), 987_654_321)
+
+
+def test_beyond_4gib_indexing(ctx, oracle):
+    """2^32 + 12345 bases: byte offsets and group indices past 32 bits (encode, decode, scan, error index)."""
+    import torch
+    import bitnuc_amd as bn
+    dev = torch.device("cuda:0")
+    n = (1 << 32) + 12345
+    nw = (n + 31) // 32
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, n, 0xB17C0DE)
+    words = torch.empty(nw, dtype=torch.int64, device=dev)
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.encode_dev(seq, n, words)
+    ctx.decode_dev(words, nw, n, back)
+    ctx.sync()
+    assert torch.equal(seq, back)
+    for off in (0, (1 << 32) - 64 * 1000, n - 64 * 1000 - (n % 32)):
+        m = min(64 * 1000 + 32, n - off)
+        h = seq[off:off + m].cpu().numpy()
+        assert np.array_equal(h, oracle.nucgen(m, 0xB17C0DE, first=off))
+        assert np.array_equal(words[off // 32: off // 32 + (m + 31) // 32].cpu().numpy().view(np.uint64), oracle.encode(h))
+    del back
+    k = 31
+    q = oracle.as_2bit(seq[n - 500:n - 500 + k].cpu().numpy())
+    dist = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
+    ctx.kmer_hdist_scan_dev(seq, n, k, q, dist)
+    ctx.sync()
+    assert int(dist[n - 500]) == 0
+    off = (1 << 32) - 3000
+    h = seq[off:off + 6000 + k - 1].cpu().numpy()
+    assert np.array_equal(dist[off:off + 6000].cpu().numpy(), oracle.kmer_hdist_scan(h, k, q))
+    tail = seq[n - 4000:].cpu().numpy()
+    assert np.array_equal(dist[n - 4000:].cpu().numpy(), oracle.kmer_hdist_scan(tail, k, q))
+    del dist
+    pos = (1 << 32) + 77
+    seq[pos] = ord("N")
+    torch.cuda.synchronize()
+    ctx.encode_dev(seq, n, words)
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.sync()
+    assert (ei.value.byte, ei.value.index) == (ord("N"), pos)
+
+
+def test_two_contexts_interleaved(oracle):
+    import threading
+    import bitnuc_amd as bn
+    errs = []
+
+    def work(seed):
+        try:
+            c = bn.Context(0)
+            rng = np.random.default_rng(seed)
+            for _ in range(20):
+                n = int(rng.integers(1, 200000))
+                s = ALPHA8[rng.integers(0, 8, size=n)]
+                w = c.encode_array(s)
+                assert np.array_equal(w, oracle.encode(s))
+                assert bytes(c.decode_array(w, n)) == bytes(s).upper()
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
 
 
 def test_kmer_config3_and_scan_config5_properties(ctx, oracle):

@@ -6,7 +6,7 @@ TAG=${1:-r00}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $PWD/bench.py --no-cpu-baseline"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"

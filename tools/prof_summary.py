@@ -21,7 +21,7 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_md = os.path.join(root, "profiles", f"{tag}_summary.md")
-    lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`",
+    lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline`",
              "(PMC passes: same command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separately; no trace domains combined with --pmc.)", "",
              "## kernel stats (--kernel-trace --stats)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
     stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
