@@ -52,6 +52,12 @@ SIGNATURES = {
     "bitnuc_decode_batch_dev": (C.c_int, [_P, _P, _P, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_encode_batch": (C.c_int, [_P, _P, _P, _SZ, _P, _SZ, _P, C.POINTER(_SZ), _ERR]),
     "bitnuc_decode_batch": (C.c_int, [_P, _P, _P, _P, _SZ, _P, _ERR]),
+    "bitnuc_base_counts": (C.c_int, [_P, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_base_counts_dev": (C.c_int, [_P, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_hdist_pairs_dev": (C.c_int, [_P, _P, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_hdist_query_dev": (C.c_int, [_P, _U64, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_hdist_pairs": (C.c_int, [_P, _P, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_hdist_query": (C.c_int, [_P, _U64, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_nucgen_dev": (C.c_int, [_P, _P, _SZ, _U64, _U64, C.c_int, _ERR]),
     "bitnuc_stream_probe_dev": (C.c_int, [_P, C.c_int, _P, _P, _SZ, _ERR]),
 }

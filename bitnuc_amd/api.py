@@ -240,6 +240,52 @@ class Context:
             _raise(err)
         return out
 
+    # -- analysis on packed words (src/utils/analysis.rs, hamming/scalar.rs) ------------------
+    def base_counts(self, words, n_bases):
+        """[A, C, G, T] counts of a packed sequence (BaseCount::base_counts, analysis.rs:23-39)."""
+        w = _as_u64(words)
+        out = np.zeros(4, dtype=np.uint64)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_base_counts(self._h, _ptr(w), w.size, int(n_bases), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return [int(x) for x in out]
+
+    def gc_content(self, words, n_bases):
+        """GCContent::gc_content (analysis.rs:7-16): percent, 0.0 for an empty sequence."""
+        if n_bases == 0:
+            return 0.0
+        c = self.base_counts(words, n_bases)
+        return (float(c[1] + c[2]) / float(n_bases)) * 100.0
+
+    def hdist_pairs(self, a, b, length):
+        a, b = _as_u64(a), _as_u64(b)
+        if a.size != b.size:
+            raise ValueError("a and b must hold the same number of words")
+        out = np.empty(a.size, dtype=np.uint8)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_hdist_pairs(self._h, _ptr(a), _ptr(b), a.size, int(length), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out
+
+    def hdist_query(self, query, targets, length):
+        t = _as_u64(targets)
+        out = np.empty(t.size, dtype=np.uint8)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_hdist_query(self._h, C.c_uint64(query), _ptr(t), t.size, int(length), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out
+
+    def base_counts_dev(self, d_words, n_words, n_bases, d_counts):
+        self._call_dev(self._lib.bitnuc_base_counts_dev, _dev_ptr(d_words), int(n_words), int(n_bases), _dev_ptr(d_counts))
+
+    def hdist_pairs_dev(self, d_a, d_b, count, length, d_dist):
+        self._call_dev(self._lib.bitnuc_hdist_pairs_dev, _dev_ptr(d_a), _dev_ptr(d_b), int(count), int(length), _dev_ptr(d_dist))
+
+    def hdist_query_dev(self, query, d_targets, count, length, d_dist):
+        err = L.BitnucErr()
+        if self._lib.bitnuc_hdist_query_dev(self._h, C.c_uint64(query), _dev_ptr(d_targets), int(count), int(length), _dev_ptr(d_dist), C.byref(err)) != L.OK:
+            _raise(err)
+
     # -- ragged batches of independent sequences ---------------------------------------------
     def encode_batch(self, seq, offsets):
         """Encode `count` back-to-back sequences (sequence i = seq[offsets[i]:offsets[i+1]]).

@@ -9,6 +9,7 @@
 #include "codec_device.h"
 #include "kmer_device.h"
 #include "batch_device.h"
+#include "analysis_device.h"
 
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -835,6 +836,99 @@ int bitnuc_decode_batch(bitnuc_ctx *c, const uint64_t *words, const uint64_t *wo
     HIPCHK(hipMemcpyAsync(out + b0, c->scratch[0], nbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return BITNUC_OK;
+}
+
+// ---- analysis on packed words --------------------------------------------------------------
+int bitnuc_base_counts_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t n_words, size_t n_bases, uint64_t *d_counts, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (n_words < (n_bases + 31) / 32) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (!d_counts || (n_bases && (!d_words || (reinterpret_cast<uintptr_t>(d_words) & 7)))) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    HIPCHK(hipMemsetAsync(d_counts, 0, 4 * sizeof(uint64_t), c->stream));
+    if (n_bases == 0) return BITNUC_OK;
+    const unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1, cap = (unsigned long long)c->num_cu * 8;
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap); // resident grid: 3 atomics per workgroup
+    base_counts_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words), n_bases,
+                                                       reinterpret_cast<unsigned long long *>(d_counts));
+    base_counts_finish<<<1, 1, 0, c->stream>>>(reinterpret_cast<unsigned long long *>(d_counts));
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_base_counts(bitnuc_ctx *c, const uint64_t *words, size_t n_words, size_t n_bases, uint64_t counts[4], bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    const size_t need = (n_bases + 31) / 32;
+    if (n_words < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (!counts || (n_bases && !words)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (int st = ensure_scratch(c, 1, need * 8 + 16, err)) return st;
+    if (int st = ensure_scratch(c, 2, 64, err)) return st;
+    if (need) HIPCHK(hipMemcpyAsync(c->scratch[1], words, need * 8, hipMemcpyHostToDevice, c->stream));
+    if (int st = bitnuc_base_counts_dev(c, reinterpret_cast<const uint64_t *>(c->scratch[1]), need, n_bases,
+                                        reinterpret_cast<uint64_t *>(c->scratch[2]), err)) return st;
+    HIPCHK(hipMemcpyAsync(counts, c->scratch[2], 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BITNUC_OK;
+}
+
+static int hdist_words_launch(bitnuc_ctx *c, bool query_mode, const uint64_t *d_a, const uint64_t *d_b, uint64_t query,
+                              size_t count, size_t len, uint8_t *d_dist, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (len > 32) return fail(err, BITNUC_INVALID_LENGTH, len); // hamming/scalar.rs:13-15
+    if (count == 0) return BITNUC_OK;
+    if (!d_a || (!query_mode && !d_b) || !d_dist || (reinterpret_cast<uintptr_t>(d_a) & 7) ||
+        (!query_mode && (reinterpret_cast<uintptr_t>(d_b) & 7))) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const unsigned grid = grid_for(c, (count / 4 + kBlock - 1) / kBlock + 1);
+    const unsigned long long *a = reinterpret_cast<const unsigned long long *>(d_a), *b = reinterpret_cast<const unsigned long long *>(d_b);
+    if (query_mode) hdist_words_kernel<true><<<grid, kBlock, 0, c->stream>>>(a, nullptr, query, count, (unsigned)len, d_dist);
+    else hdist_words_kernel<false><<<grid, kBlock, 0, c->stream>>>(a, b, 0, count, (unsigned)len, d_dist);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_hdist_pairs_dev(bitnuc_ctx *c, const uint64_t *d_a, const uint64_t *d_b, size_t count, size_t len, uint8_t *d_dist, bitnuc_err *err) {
+    return hdist_words_launch(c, false, d_a, d_b, 0, count, len, d_dist, err);
+}
+
+int bitnuc_hdist_query_dev(bitnuc_ctx *c, uint64_t query, const uint64_t *d_targets, size_t count, size_t len, uint8_t *d_dist, bitnuc_err *err) {
+    return hdist_words_launch(c, true, d_targets, nullptr, query, count, len, d_dist, err);
+}
+
+static int hdist_words_host(bitnuc_ctx *c, bool query_mode, const uint64_t *a, const uint64_t *b, uint64_t query, size_t count,
+                            size_t len, uint8_t *dist, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (len > 32) return fail(err, BITNUC_INVALID_LENGTH, len);
+    if (count == 0) return BITNUC_OK;
+    if (!a || (!query_mode && !b) || !dist) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const size_t per = kHostChunk / 8;
+    const size_t m0 = count < per ? count : per;
+    if (int st = ensure_scratch(c, 0, m0 * 8, err)) return st;
+    if (!query_mode) if (int st = ensure_scratch(c, 1, m0 * 8, err)) return st;
+    if (int st = ensure_scratch(c, 2, m0 + 16, err)) return st;
+    for (size_t i0 = 0; i0 < count; i0 += per) {
+        const size_t m = count - i0 < per ? count - i0 : per;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], a + i0, m * 8, hipMemcpyHostToDevice, c->stream));
+        if (!query_mode) HIPCHK(hipMemcpyAsync(c->scratch[1], b + i0, m * 8, hipMemcpyHostToDevice, c->stream));
+        if (int st = hdist_words_launch(c, query_mode, reinterpret_cast<const uint64_t *>(c->scratch[0]),
+                                        reinterpret_cast<const uint64_t *>(c->scratch[1]), query, m, len, c->scratch[2], err)) return st;
+        HIPCHK(hipMemcpyAsync(dist + i0, c->scratch[2], m, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return BITNUC_OK;
+}
+
+int bitnuc_hdist_pairs(bitnuc_ctx *c, const uint64_t *a, const uint64_t *b, size_t count, size_t len, uint8_t *dist, bitnuc_err *err) {
+    return hdist_words_host(c, false, a, b, 0, count, len, dist, err);
+}
+
+int bitnuc_hdist_query(bitnuc_ctx *c, uint64_t query, const uint64_t *targets, size_t count, size_t len, uint8_t *dist, bitnuc_err *err) {
+    return hdist_words_host(c, true, targets, nullptr, query, count, len, dist, err);
 }
 
 // ---- single-word API: batches of one on the device ---------------------------------------------

@@ -140,6 +140,21 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *ctx, const uint64_t *d_words, const uint
 int bitnuc_encode_batch(bitnuc_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, size_t count, uint64_t *out, size_t out_cap_words, uint64_t *word_offsets, size_t *n_words, bitnuc_err *err);
 int bitnuc_decode_batch(bitnuc_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets, const uint64_t *offsets, size_t count, uint8_t *out, bitnuc_err *err);
 
+/* ---- analysis on packed words (the callers just above the codec) ------ */
+/* BaseCount::base_counts / GCContent::gc_content of a packed sequence
+ * (src/utils/analysis.rs:7-39: the reference decodes to ASCII, then counts bytes): counts[] =
+ * {A, C, G, T} of the first n_bases bases.  n_words < ceil(n_bases/32) -> INVALID_LENGTH.
+ * gc_content = (counts[1] + counts[2]) as f64 / n_bases as f64 * 100.0 is left to the caller. */
+int bitnuc_base_counts(bitnuc_ctx *ctx, const uint64_t *words, size_t n_words, size_t n_bases, uint64_t counts[4], bitnuc_err *err);
+int bitnuc_base_counts_dev(bitnuc_ctx *ctx, const uint64_t *d_words, size_t n_words, size_t n_bases, uint64_t *d_counts /* 4, device */, bitnuc_err *err);
+/* Many-pair / one-query Hamming distance of packed <=32-mers: dist[i] = hdist_scalar(a[i], b[i], len)
+ * or hdist_scalar(query, targets[i], len) (src/utils/functions/hamming/scalar.rs:11-48).
+ * len > 32 -> INVALID_LENGTH(len). */
+int bitnuc_hdist_pairs_dev(bitnuc_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t count, size_t len, uint8_t *d_dist, bitnuc_err *err);
+int bitnuc_hdist_query_dev(bitnuc_ctx *ctx, uint64_t query, const uint64_t *d_targets, size_t count, size_t len, uint8_t *d_dist, bitnuc_err *err);
+int bitnuc_hdist_pairs(bitnuc_ctx *ctx, const uint64_t *a, const uint64_t *b, size_t count, size_t len, uint8_t *dist, bitnuc_err *err);
+int bitnuc_hdist_query(bitnuc_ctx *ctx, uint64_t query, const uint64_t *targets, size_t count, size_t len, uint8_t *dist, bitnuc_err *err);
+
 /* ---- synthetic input (the reference's tests use nucgen::Sequence::fill_buffer,
  * src/utils/mod.rs:116-121; its stream is unpinned, so the build ships its own) ---- */
 /* Fill d_out[0..len) with bases first..first+len of the seeded stream

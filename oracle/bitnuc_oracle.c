@@ -194,6 +194,44 @@ int orc_kmer_hdist_scan(const uint8_t *ref, size_t n, size_t k, uint64_t query,
     return ORC_OK;
 }
 
+int orc_base_counts(const uint64_t *words, size_t n_words, size_t n_bases, uint64_t counts[4], orc_err *err) {
+    set_err(err, ORC_OK, 0, 0, 0);
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    if (n_words < (n_bases + 31) / 32) {
+        set_err(err, ORC_INVALID_LENGTH, 0, n_bases, 0);
+        return ORC_INVALID_LENGTH;
+    }
+    for (size_t i = 0; i < n_bases; i++) { /* to_vec() = get(i) per base (sequence.rs:116-135), then analysis.rs:27-36 */
+        uint8_t base;
+        orc_from_2bit(words[i / 32] >> (2 * (i % 32)), 1, &base, NULL);
+        switch (base) {
+        case 'A': counts[0]++; break;
+        case 'C': counts[1]++; break;
+        case 'G': counts[2]++; break;
+        case 'T': counts[3]++; break;
+        default: break;
+        }
+    }
+    return ORC_OK;
+}
+
+double orc_gc_content(const uint64_t *words, size_t n_words, size_t n_bases) {
+    uint64_t c[4];
+    if (n_bases == 0 || orc_base_counts(words, n_words, n_bases, c, NULL) != ORC_OK) return 0.0; /* analysis.rs:10-11 */
+    return ((double)(c[1] + c[2]) / (double)n_bases) * 100.0;                                   /* analysis.rs:13-14 */
+}
+
+int orc_hdist_pairs(const uint64_t *a, const uint64_t *b, size_t count, size_t len, uint8_t *dist, orc_err *err) {
+    set_err(err, ORC_OK, 0, 0, 0);
+    for (size_t i = 0; i < count; i++) {
+        uint32_t d;
+        int st = orc_hdist_scalar(a[i], b[i], len, &d, err);
+        if (st != ORC_OK) return st;
+        dist[i] = (uint8_t)d;
+    }
+    return ORC_OK;
+}
+
 static uint64_t mix64(uint64_t z) { /* splitmix64 finaliser */
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;

@@ -82,6 +82,14 @@ int orc_as_2bit_batch(const uint8_t *kmers, size_t k, size_t stride,
 int orc_kmer_hdist_scan(const uint8_t *ref, size_t n, size_t k, uint64_t query,
                         uint8_t *dist, orc_err *err);
 
+/* src/utils/analysis.rs:23-39 on PackedSequence::to_vec(): counts = {A,C,G,T} of the first
+ * n_bases bases (decode, then count bytes). */
+int orc_base_counts(const uint64_t *words, size_t n_words, size_t n_bases, uint64_t counts[4], orc_err *err);
+/* src/utils/analysis.rs:7-16 */
+double orc_gc_content(const uint64_t *words, size_t n_words, size_t n_bases);
+/* loop of hdist_scalar over word pairs / one query (hamming/scalar.rs:11-48) */
+int orc_hdist_pairs(const uint64_t *a, const uint64_t *b, size_t count, size_t len, uint8_t *dist, orc_err *err);
+
 /* Synthetic "nucgen-like" generator shared with the device generator:
  * base i = "ACGT"[(mix(seed, i/32) >> 2*(i%32)) & 3], mix = splitmix64
  * finaliser of seed + (i/32+1)*0x9E3779B97F4A7C15. `first` = absolute index of

@@ -56,6 +56,12 @@ extern "C" {
     pub fn bitnuc_decode_batch_dev(ctx: *mut bitnuc_ctx, d_words: *const u64, d_word_offsets: *const u64, d_offsets: *const u64, count: usize, total_words: usize, d_out: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_encode_batch(ctx: *mut bitnuc_ctx, seq: *const u8, offsets: *const u64, count: usize, out: *mut u64, out_cap_words: usize, word_offsets: *mut u64, n_words: *mut usize, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_decode_batch(ctx: *mut bitnuc_ctx, words: *const u64, word_offsets: *const u64, offsets: *const u64, count: usize, out: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_base_counts(ctx: *mut bitnuc_ctx, words: *const u64, n_words: usize, n_bases: usize, counts: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_base_counts_dev(ctx: *mut bitnuc_ctx, d_words: *const u64, n_words: usize, n_bases: usize, d_counts: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_hdist_pairs(ctx: *mut bitnuc_ctx, a: *const u64, b: *const u64, count: usize, len: usize, dist: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_hdist_query(ctx: *mut bitnuc_ctx, query: u64, targets: *const u64, count: usize, len: usize, dist: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_hdist_pairs_dev(ctx: *mut bitnuc_ctx, d_a: *const u64, d_b: *const u64, count: usize, len: usize, d_dist: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_hdist_query_dev(ctx: *mut bitnuc_ctx, query: u64, d_targets: *const u64, count: usize, len: usize, d_dist: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_nucgen_dev(ctx: *mut bitnuc_ctx, d_out: *mut u8, len: usize, seed: u64, first: u64, flags: c_int, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_stream_probe_dev(ctx: *mut bitnuc_ctx, mode: c_int, d_src: *const c_void, d_dst: *mut c_void, bytes: usize, err: *mut bitnuc_err) -> c_int;
 }

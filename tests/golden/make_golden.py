@@ -94,6 +94,14 @@ V["hdist_cyclic"] = [{"l": 32, "mod1": 4, "mod2": 3, "src": "benches/hdist_bench
 # k-mer counting doc example: windows(4) of ACGTACGT, count of ACGT == 2
 V["kmer_count"] = {"seq": "ACGTACGT", "k": 4, "kmer": "ACGT", "count": 2, "src": "src/lib.rs:170-178"}
 
+# --- analysis on packed sequences -------------------------------------------
+V["gc_content"] = [{"seq": s_, "gc": g_, "src": "src/utils/analysis.rs:48-54"} for s_, g_ in
+                   [("ACGT", 50.0), ("AAAA", 0.0), ("CCCC", 100.0), ("AACG", 50.0), ("ACGTA", 40.0)]]
+V["base_counts"] = [{"seq": s_, "counts": c_, "src": "src/utils/analysis.rs:64-70"} for s_, c_ in
+                    [("ACGT", [1, 1, 1, 1]), ("AAAA", [4, 0, 0, 0]), ("CCCC", [0, 4, 0, 0]), ("AACG", [2, 1, 1, 0]),
+                     ("ACGTA", [2, 1, 1, 1])]]
+V["empty_sequence_analysis"] = {"gc": 0.0, "counts": [0, 0, 0, 0], "src": "src/utils/analysis.rs:79-83"}
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json")
     with open(out, "w") as f:

@@ -53,6 +53,10 @@ def lib():
         L.orc_hdist.argtypes = [P, SZ, P, SZ, SZ, C.POINTER(C.c_uint32), E]
         L.orc_as_2bit_batch.argtypes = [P, SZ, SZ, SZ, P, E]
         L.orc_kmer_hdist_scan.argtypes = [P, SZ, SZ, U64, P, E]
+        L.orc_base_counts.argtypes = [P, SZ, SZ, P, E]
+        L.orc_gc_content.argtypes = [P, SZ, SZ]
+        L.orc_gc_content.restype = C.c_double
+        L.orc_hdist_pairs.argtypes = [P, P, SZ, SZ, P, E]
         L.orc_nucgen.argtypes = [P, SZ, U64, U64, C.c_int]
         L.orc_nucgen.restype = None
         L.orc_avx2_encode.argtypes = [P, SZ, C.POINTER(P), C.POINTER(SZ), E]
@@ -154,6 +158,28 @@ def kmer_hdist_scan(ref, k, query):
     nwin = s.size - k + 1 if (s.size >= k and k > 0) else 0
     out, err = np.zeros(nwin, dtype=np.uint8), OrcErr()
     if lib().orc_kmer_hdist_scan(_p(s), s.size, k, C.c_uint64(query), _p(out), C.byref(err)):
+        raise OracleError(err)
+    return out
+
+
+def base_counts(words, n_bases):
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    out, err = np.zeros(4, dtype=np.uint64), OrcErr()
+    if lib().orc_base_counts(_p(w), w.size, n_bases, _p(out), C.byref(err)):
+        raise OracleError(err)
+    return [int(x) for x in out]
+
+
+def gc_content(words, n_bases):
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    return float(lib().orc_gc_content(_p(w), w.size, n_bases))
+
+
+def hdist_pairs(a, b, length):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out, err = np.zeros(a.size, dtype=np.uint8), OrcErr()
+    if lib().orc_hdist_pairs(_p(a), _p(b), a.size, length, _p(out), C.byref(err)):
         raise OracleError(err)
     return out
 

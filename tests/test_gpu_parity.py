@@ -634,3 +634,67 @@ def test_cpp_host_layer(ctx):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ALL OK" in out.stdout
+
+
+# ---- analysis on packed words -----------------------------------------------
+def test_analysis_golden_and_oracle(ctx, golden, oracle):
+    import bitnuc_amd as bn
+    for v in golden["gc_content"]:
+        s = v["seq"].encode()
+        assert ctx.gc_content(ctx.encode_alloc(s), len(s)) == v["gc"], v["src"]
+    for v in golden["base_counts"]:
+        s = v["seq"].encode()
+        assert ctx.base_counts(ctx.encode_alloc(s), len(s)) == v["counts"], v["src"]
+    e = golden["empty_sequence_analysis"]
+    assert ctx.gc_content([], 0) == e["gc"] and ctx.base_counts([], 0) == e["counts"]
+    for n in [1, 31, 32, 33, 63, 64, 65, 1000, 100003, 3000001]:
+        s = rand_seq(n)
+        w = oracle.encode(s)
+        assert ctx.base_counts(w, n) == oracle.base_counts(w, n), n
+        assert ctx.gc_content(w, n) == oracle.gc_content(w, n), n
+        # bits above n_bases in the last word are ignored
+        w2 = w.copy()
+        if n % 32:
+            w2[-1] |= np.uint64(0xFFFFFFFFFFFFFFFF) << np.uint64(2 * (n % 32))
+        assert ctx.base_counts(w2, n) == oracle.base_counts(w, n), n
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.base_counts(np.zeros(1, np.uint64), 33)
+    assert ei.value.kind == "InvalidLength"
+
+
+def test_hdist_pairs_and_query(ctx, oracle):
+    import bitnuc_amd as bn
+    for count in [1, 3, 4, 5, 1023, 1024, 100003]:
+        a = RNG.integers(0, 1 << 63, size=count, dtype=np.uint64) * np.uint64(2) + RNG.integers(0, 2, size=count, dtype=np.uint64)
+        b = RNG.integers(0, 1 << 63, size=count, dtype=np.uint64) * np.uint64(2) + RNG.integers(0, 2, size=count, dtype=np.uint64)
+        for length in (0, 1, 15, 16, 17, 31, 32):
+            assert np.array_equal(ctx.hdist_pairs(a, b, length), oracle.hdist_pairs(a, b, length)), (count, length)
+            q = int(b[0])
+            assert np.array_equal(ctx.hdist_query(q, a, length), oracle.hdist_pairs(a, np.full(count, q, np.uint64), length)), (count, length)
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.hdist_pairs([0], [0], 33)
+    assert ei.value.kind == "InvalidLength" and ei.value.len == 33
+
+
+def test_analysis_full_scale(ctx, oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    n = 10**9 + 17
+    nw = (n + 31) // 32
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, n, 0xB17C0DE)
+    words = torch.empty(nw, dtype=torch.int64, device=dev)
+    ctx.encode_dev(seq, n, words)
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    ctx.base_counts_dev(words, nw, n, counts)
+    ctx.sync()
+    expect = [int((seq == ord(c)).sum()) for c in "ACGT"]  # independent: counted on the ASCII side by torch
+    assert counts.tolist() == expect and sum(expect) == n
+    # one query against 3.1e7 packed 32-mers
+    dist = torch.empty(nw, dtype=torch.uint8, device=dev)
+    q = int(words[12345].item()) & 0xFFFFFFFFFFFFFFFF
+    ctx.hdist_query_dev(q, words, nw - 1, 32, dist)
+    ctx.sync()
+    assert int(dist[12345]) == 0
+    h = words[:5000].cpu().numpy().view(np.uint64)
+    assert np.array_equal(dist[:5000].cpu().numpy(), oracle.hdist_pairs(h, np.full(5000, q, np.uint64), 32))

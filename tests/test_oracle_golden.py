@@ -176,3 +176,21 @@ def test_nucgen_properties(oracle):
     # not degenerate
     counts = np.bincount(oracle.nucgen(1 << 16, 7), minlength=128)[ALPHA]
     assert counts.min() > (1 << 16) / 4 * 0.95
+
+
+def test_analysis_vectors(oracle, golden):
+    for v in golden["gc_content"]:
+        s = v["seq"].encode()
+        assert oracle.gc_content(oracle.encode(s), len(s)) == v["gc"], v["src"]
+    for v in golden["base_counts"]:
+        s = v["seq"].encode()
+        assert oracle.base_counts(oracle.encode(s), len(s)) == v["counts"], v["src"]
+    e = golden["empty_sequence_analysis"]
+    assert oracle.gc_content(np.zeros(0, np.uint64), 0) == e["gc"]
+    assert oracle.base_counts(np.zeros(0, np.uint64), 0) == e["counts"]
+    s = rand_seq(1000)
+    w = oracle.encode(s)
+    assert oracle.base_counts(w, 1000) == [int((s == ord(c)).sum()) for c in "ACGT"]
+    a, b = RNG.integers(0, 1 << 63, size=100, dtype=np.uint64), RNG.integers(0, 1 << 63, size=100, dtype=np.uint64)
+    d = oracle.hdist_pairs(a, b, 31)
+    assert all(int(d[i]) == oracle.hdist_scalar(int(a[i]), int(b[i]), 31) for i in range(100))
