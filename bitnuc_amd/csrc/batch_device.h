@@ -5,8 +5,8 @@
 // packing/avx.rs:147-148).  Here the sequences sit back to back in one buffer with an
 // offsets table, and their words back to back with a word-offsets table
 // (word_offsets[i] = sum_{j<i} ceil(len_j/32)); sequence boundaries fall anywhere, so:
-//   * one lane owns one output WORD; a workgroup owns 256 consecutive words, whose bytes are
-//     one contiguous span of at most 8 KiB because sequences and their words are contiguous;
+//   * one lane owns one output WORD; a workgroup owns 128 consecutive words, whose bytes are
+//     one contiguous span of at most 4 KiB because sequences and their words are contiguous;
 //   * the span moves between HBM and LDS with coalesced 16-byte accesses; lanes touch their
 //     (unaligned, 1..32-byte) pieces in LDS only;
 //   * word -> sequence lookup: a small pre-kernel finds the owner of every workgroup's first
@@ -18,8 +18,11 @@
 
 namespace bitnuc_dev {
 
-constexpr int kBatchWin = 384;                 // offsets window per workgroup (>= 257 + slack for empty sequences)
-constexpr int kBatchStage = kBlock * 32 + 64;  // 8 KiB span + alignment slack
+constexpr int kBatchBlock = 128;                    // words (= lanes) per workgroup: small, so many independent
+                                                    // owner -> window -> data load chains are in flight per CU
+constexpr int kBatchWinStep = 64;
+constexpr int kBatchWin = 192;                      // offsets window per workgroup (>= kBatchBlock + 1, + slack for empty sequences)
+constexpr int kBatchStage = kBatchBlock * 32 + 64;  // 4 KiB span + alignment slack
 
 // index of the sequence that owns word w: upper_bound(word_offsets[0..count], w) - 1
 __device__ __forceinline__ unsigned long long owner_of_word(const unsigned long long *__restrict__ wo,
@@ -43,12 +46,12 @@ __global__ void __launch_bounds__(kBlock)
 block_owner_kernel(const unsigned long long *__restrict__ word_offsets, unsigned long long count,
                    unsigned long long nblocks, unsigned long long *__restrict__ owner) {
     const unsigned long long b = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    if (b < nblocks) owner[b] = owner_of_word(word_offsets, count, b * kBlock);
+    if (b < nblocks) owner[b] = owner_of_word(word_offsets, count, b * kBatchBlock);
 }
 
 // Fills the LDS window for the workgroup that starts at word wb (whose owner is sb) and
-// resolves this lane's word.  The window grows in steps of 128 sequences until it covers
-// the workgroup's last word (150-base reads need 52 entries; 1-word sequences need 257).
+// resolves this lane's word.  The window grows in steps of 64 sequences until it covers
+// the workgroup's last word (150-base reads need 27 entries; 1-word sequences need 129).
 __device__ __forceinline__ WordLoc locate_word(const unsigned long long *__restrict__ offsets,
                                                const unsigned long long *__restrict__ word_offsets,
                                                unsigned long long count, unsigned long long sb, unsigned long long wb,
@@ -56,14 +59,14 @@ __device__ __forceinline__ WordLoc locate_word(const unsigned long long *__restr
                                                unsigned long long *win_so) {
     unsigned filled = 0;
     for (;;) {
-        for (unsigned i = filled + threadIdx.x; i < filled + 128 && i <= (unsigned)kBatchWin; i += kBlock) {
+        for (unsigned i = filled + threadIdx.x; i < filled + kBatchWinStep && i <= (unsigned)kBatchWin; i += kBatchBlock) {
             const unsigned long long s = sb + i < count ? sb + i : count;
             win_wo[i] = word_offsets[s];
             win_so[i] = offsets[s];
         }
-        filled = filled + 128 <= (unsigned)kBatchWin + 1 ? filled + 128 : kBatchWin + 1;
+        filled = filled + kBatchWinStep <= (unsigned)kBatchWin + 1 ? filled + kBatchWinStep : kBatchWin + 1;
         __syncthreads();
-        if (filled > (unsigned)kBatchWin || win_wo[filled - 1] > wb + kBlock - 1) break; // uniform
+        if (filled > (unsigned)kBatchWin || win_wo[filled - 1] > wb + kBatchBlock - 1) break; // uniform
     }
     WordLoc loc{0, 0};
     if (!active) return loc;
@@ -164,7 +167,7 @@ word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned lon
 // ---------------------------------------------------------------------------------
 // batched encode
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBatchBlock)
 encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ offsets,
                     const unsigned long long *__restrict__ word_offsets, unsigned long long count,
                     unsigned long long total_words, const unsigned long long *__restrict__ owner,
@@ -173,28 +176,36 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
     __shared__ unsigned long long span[2];
     __shared__ __attribute__((aligned(16))) uint8_t stage[kBatchStage];
     const unsigned t = threadIdx.x;
-    for (unsigned long long wb = (unsigned long long)blockIdx.x * kBlock; wb < total_words;
-         wb += (unsigned long long)gridDim.x * kBlock) {
+    for (unsigned long long wb = (unsigned long long)blockIdx.x * kBatchBlock; wb < total_words;
+         wb += (unsigned long long)gridDim.x * kBatchBlock) {
         const unsigned long long w = wb + t;
         const bool active = w < total_words;
         __syncthreads(); // previous trip's LDS readers are done
-        const WordLoc loc = locate_word(offsets, word_offsets, count, owner[wb / kBlock], wb, w, active, win_wo, win_so);
+        const WordLoc loc = locate_word(offsets, word_offsets, count, owner[wb / kBatchBlock], wb, w, active, win_wo, win_so);
         if (t == 0) span[0] = loc.base;
-        if (active && (w + 1 == total_words || t == kBlock - 1)) span[1] = loc.base + loc.nb;
+        if (active && (w + 1 == total_words || t == kBatchBlock - 1)) span[1] = loc.base + loc.nb;
         __syncthreads();
         const uintptr_t lo = reinterpret_cast<uintptr_t>(seq) + span[0], hi = reinterpret_cast<uintptr_t>(seq) + span[1];
         const uintptr_t lo16 = lo & ~(uintptr_t)15;
         const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
-        for (unsigned c = t; c < nchunk; c += kBlock)
+        for (unsigned c = t; c < nchunk; c += kBatchBlock)
             *reinterpret_cast<u32x4 *>(stage + 16 * c) = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)c));
         __syncthreads();
         if (!active) continue;
         const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16);
         const unsigned nfull = loc.nb >> 2, rem = loc.nb & 3;
+        // the word's bytes start at any byte offset: read the <= 9 ALIGNED LDS dwords that cover
+        // them and funnel-shift (misaligned ds_read_b32 works on gfx950 but runs ~2x slower)
+        const unsigned sh = off & 3, nd = (sh + loc.nb + 3) >> 2;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(stage + (off & ~3u));
+        uint32_t a[10];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] = (unsigned)i < nd ? src[i] : 0u;
+        a[9] = 0;
         uint32_t bad = 0, wlo = 0, whi = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            uint32_t x = *reinterpret_cast<const u32_u *>(stage + off + 4 * i); // unaligned LDS dword (gfx950: supported)
+            uint32_t x = __builtin_amdgcn_alignbyte(a[i + 1], a[i], sh);
             if ((unsigned)i == nfull) { // partial dword: bytes past the sequence end become 'A' (code 0, valid)
                 const uint32_t keep = rem ? ((1u << (8 * rem)) - 1u) : 0u;
                 x = (x & keep) | (0x41414141u & ~keep);
@@ -212,7 +223,7 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
 // ---------------------------------------------------------------------------------
 // batched decode: sequence i's bases go to out[offsets[i] .. offsets[i+1])
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBatchBlock)
 decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ word_offsets,
                     const unsigned long long *__restrict__ offsets, unsigned long long count,
                     unsigned long long total_words, const unsigned long long *__restrict__ owner,
@@ -221,35 +232,43 @@ decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned
     __shared__ unsigned long long span[2];
     __shared__ __attribute__((aligned(16))) uint8_t stage[kBatchStage];
     const unsigned t = threadIdx.x;
-    for (unsigned long long wb = (unsigned long long)blockIdx.x * kBlock; wb < total_words;
-         wb += (unsigned long long)gridDim.x * kBlock) {
+    for (unsigned long long wb = (unsigned long long)blockIdx.x * kBatchBlock; wb < total_words;
+         wb += (unsigned long long)gridDim.x * kBatchBlock) {
         const unsigned long long w = wb + t;
         const bool active = w < total_words;
         const unsigned long long word = active ? __builtin_nontemporal_load(words + w) : 0ull;
         __syncthreads();
-        const WordLoc loc = locate_word(offsets, word_offsets, count, owner[wb / kBlock], wb, w, active, win_wo, win_so);
+        const WordLoc loc = locate_word(offsets, word_offsets, count, owner[wb / kBatchBlock], wb, w, active, win_wo, win_so);
         if (t == 0) span[0] = loc.base;
-        if (active && (w + 1 == total_words || t == kBlock - 1)) span[1] = loc.base + loc.nb;
+        if (active && (w + 1 == total_words || t == kBatchBlock - 1)) span[1] = loc.base + loc.nb;
         __syncthreads();
         const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + span[0], hi = reinterpret_cast<uintptr_t>(out) + span[1];
         const uintptr_t lo16 = lo & ~(uintptr_t)15;
         if (active) {
             const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(out) + loc.base - lo16);
             const u32x4 a = dec16((uint32_t)word), b = dec16((uint32_t)(word >> 32));
-            const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            const unsigned nfull = loc.nb >> 2, rem = loc.nb & 3;
+            const uint32_t d[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0u};
+            // write the lane's nb bytes at byte offset `off`: <= 3 head bytes up to the next
+            // 4-byte boundary, then ALIGNED dwords re-cut from d[] with v_alignbyte, then <= 3
+            // tail bytes (misaligned ds_write_b32 works on gfx950 but runs ~2x slower)
+            const unsigned head = (4u - (off & 3u)) & 3u;          // bytes before the first aligned dword
+            const unsigned hb = head < loc.nb ? head : loc.nb;
+            for (unsigned j = 0; j < hb; ++j) stage[off + j] = (uint8_t)(d[0] >> (8 * j));
+            const unsigned body = loc.nb - hb, ndw = body >> 2, tb = body & 3;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(stage + off + hb);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if ((unsigned)i < nfull) *reinterpret_cast<u32_u *>(stage + off + 4 * i) = d[i];
-                else if ((unsigned)i == nfull)
-                    for (unsigned j = 0; j < rem; ++j) stage[off + 4 * i + j] = (uint8_t)(d[i] >> (8 * j));
+            for (int m = 0; m < 8; ++m) {
+                const uint32_t v = __builtin_amdgcn_alignbyte(d[m + 1], d[m], head); // lane bytes [head+4m, head+4m+4)
+                if ((unsigned)m < ndw) dst[m] = v;
+                else if ((unsigned)m == ndw)
+                    for (unsigned j = 0; j < tb; ++j) stage[off + hb + 4 * m + j] = (uint8_t)(v >> (8 * j));
             }
         }
         __syncthreads();
         // coalesced write-out; the first/last 16-byte chunk may be shared with a neighbouring
         // workgroup's span, so only this span's bytes are written there
         const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
-        for (unsigned c = t; c < nchunk; c += kBlock) {
+        for (unsigned c = t; c < nchunk; c += kBatchBlock) {
             const uintptr_t g = lo16 + 16 * (uintptr_t)c;
             if (g >= lo && g + 16 <= hi) {
                 __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(stage + 16 * c), reinterpret_cast<u32x4 *>(g));

@@ -698,7 +698,7 @@ int bitnuc_hdist(bitnuc_ctx *c, const uint64_t *a, size_t na, const uint64_t *b,
 // owner[b] of every 256-word workgroup, into context scratch (enqueued on the stream)
 static int batch_owners(bitnuc_ctx *c, const uint64_t *d_word_offsets, size_t count, size_t total_words,
                         const unsigned long long **owner, bitnuc_err *err) {
-    const size_t nblocks = (total_words + kBlock - 1) / kBlock;
+    const size_t nblocks = (total_words + kBatchBlock - 1) / kBatchBlock;
     if (int st = ensure_scratch(c, 3, nblocks * sizeof(uint64_t), err)) return st;
     unsigned long long *o = reinterpret_cast<unsigned long long *>(c->scratch[3]);
     block_owner_kernel<<<(unsigned)((nblocks + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(
@@ -755,8 +755,8 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t 
     if (int st = batch_owners(c, d_word_offsets, count, total_words, &owner, err)) return st;
     unsigned long long *slot;
     if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
-    const unsigned grid = grid_for(c, (total_words + kBlock - 1) / kBlock);
-    encode_batch_kernel<<<grid, kBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
+    const unsigned grid = grid_for(c, (total_words + kBatchBlock - 1) / kBatchBlock, kBatchBlock);
+    encode_batch_kernel<<<grid, kBatchBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
                                                         reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, owner,
                                                         reinterpret_cast<unsigned long long *>(d_out), slot);
     HIPCHK(hipGetLastError());
@@ -771,8 +771,8 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64
     DeviceGuard g(c->device);
     const unsigned long long *owner;
     if (int st = batch_owners(c, d_word_offsets, count, total_words, &owner, err)) return st;
-    const unsigned grid = grid_for(c, (total_words + kBlock - 1) / kBlock);
-    decode_batch_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words),
+    const unsigned grid = grid_for(c, (total_words + kBatchBlock - 1) / kBatchBlock, kBatchBlock);
+    decode_batch_kernel<<<grid, kBatchBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words),
                                                         reinterpret_cast<const unsigned long long *>(d_word_offsets),
                                                         reinterpret_cast<const unsigned long long *>(d_offsets), count, total_words, owner, d_out);
     HIPCHK(hipGetLastError());
