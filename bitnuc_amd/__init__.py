@@ -11,6 +11,8 @@ from .api import (BackendError, Context, NucleotideError, as_2bit, as_2bit_batch
                   default_context, encode, encode_alloc, from_2bit, from_2bit_alloc, hdist,
                   hdist_scalar, kmer_hdist_scan)
 
-__all__ = ["BackendError", "Context", "NucleotideError", "as_2bit", "as_2bit_batch", "decode",
+from .sequence import PackedSequence
+
+__all__ = ["PackedSequence", "BackendError", "Context", "NucleotideError", "as_2bit", "as_2bit_batch", "decode",
            "default_context", "encode", "encode_alloc", "from_2bit", "from_2bit_alloc", "hdist",
            "hdist_scalar", "kmer_hdist_scan"]

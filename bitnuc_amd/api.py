@@ -38,14 +38,20 @@ class NucleotideError(Exception):
             return f"Sequence length {p['len']} exceeds maximum"
         if self.kind == "InvalidLength":
             return f"Invalid length: {p['len']}"
+        if self.kind == "IndexOutOfBounds":
+            return f"Index {p['index']} out of bounds for sequence of length {p['length']}"
+        if self.kind == "InvalidRange" and "start" in p:
+            return f"Invalid range {p['start']}..{p['end']} for sequence of length {p['length']}"
         if self.kind == "Unsupported":
             return "Unsupported architecture"
         return self.kind
 
     def __eq__(self, other):  # derive(PartialEq, Eq), src/error.rs:3
         return isinstance(other, NucleotideError) and self.kind == other.kind and \
-            {k: v for k, v in self.payload.items() if k != "index"} == \
-            {k: v for k, v in other.payload.items() if k != "index"}
+            self._cmp_payload() == other._cmp_payload()
+
+    def _cmp_payload(self):  # InvalidBase carries an extra byte index that Rust's variant does not have
+        return {k: v for k, v in self.payload.items() if not (self.kind == "InvalidBase" and k == "index")}
 
     __hash__ = Exception.__hash__
 

@@ -20,6 +20,7 @@
 
 #include "bitnuc_hip.h"
 
+#include <array>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -37,6 +38,7 @@ struct NucleotideError {
     size_t len = 0;         // SequenceTooLong(usize) / InvalidLength(usize)
     uint64_t index = 0;     // extra: absolute index of the invalid base
     int backend_code = 0;   // extra: hipError_t for Backend
+    size_t start = 0, end = 0, length = 0, oob_index = 0; // IndexOutOfBounds{index,length} / InvalidRange{start,end,length}
 
     static NucleotideError invalid_base(uint8_t b) { NucleotideError e; e.kind = InvalidBase; e.base = b; return e; }
     static NucleotideError sequence_too_long(size_t n) { NucleotideError e; e.kind = SequenceTooLong; e.len = n; return e; }
@@ -47,6 +49,8 @@ struct NucleotideError {
         if (kind != o.kind) return false;
         if (kind == InvalidBase) return base == o.base;
         if (kind == SequenceTooLong || kind == InvalidLength) return len == o.len;
+        if (kind == IndexOutOfBounds) return oob_index == o.oob_index && length == o.length;
+        if (kind == InvalidRange) return start == o.start && end == o.end && length == o.length;
         return true;
     }
     bool operator!=(const NucleotideError &o) const { return !(*this == o); }
@@ -56,6 +60,8 @@ struct NucleotideError {
         case InvalidBase: return "Invalid nucleotide base: " + std::to_string(base);
         case SequenceTooLong: return "Sequence length " + std::to_string(len) + " exceeds maximum";
         case InvalidLength: return "Invalid length: " + std::to_string(len);
+        case IndexOutOfBounds: return "Index " + std::to_string(oob_index) + " out of bounds for sequence of length " + std::to_string(length);
+        case InvalidRange: return "Invalid range " + std::to_string(start) + ".." + std::to_string(end) + " for sequence of length " + std::to_string(length);
         case Unsupported: return "Unsupported architecture";
         case Backend: return "HIP backend error " + std::to_string(backend_code);
         default: return "NucleotideError";
@@ -248,6 +254,69 @@ inline Context &default_context() {
     thread_local Context ctx(0);
     return ctx;
 }
+
+// PackedSequence (src/sequence.rs:5-262) over GPU-encoded data, with the GCContent / BaseCount
+// traits of src/utils/analysis.rs:3-39.  `new_` encodes on the GPU; slice / to_vec / get decode
+// only the words the range touches, on the GPU; the traits count on the packed words.
+class PackedSequence {
+  public:
+    static Result<PackedSequence> new_(Bytes seq) { // sequence.rs:40-52
+        PackedSequence p;
+        if (seq.len != 0) { // sequence.rs:42-44: skip encoding for empty sequences
+            Result<void> r = default_context().encode(seq, p.data_);
+            if (r.is_err()) return r.unwrap_err();
+        }
+        p.length_ = seq.len;
+        return p;
+    }
+    size_t len() const { return length_; }
+    bool is_empty() const { return length_ == 0; }
+    const std::vector<uint64_t> &data() const { return data_; }
+    Result<uint8_t> get(size_t index) const { // sequence.rs:116-135
+        if (index >= length_) {
+            NucleotideError e; e.kind = NucleotideError::IndexOutOfBounds; e.oob_index = index; e.length = length_;
+            return e;
+        }
+        auto r = default_context().from_2bit_alloc(data_[index / 32] >> (2 * (index % 32)), 1);
+        if (r.is_err()) return r.unwrap_err();
+        return r.unwrap()[0];
+    }
+    Result<std::vector<uint8_t>> slice(size_t start, size_t end) const { // sequence.rs:198-212
+        if (start > end || end > length_) {
+            NucleotideError e; e.kind = NucleotideError::InvalidRange; e.start = start; e.end = end; e.length = length_;
+            return e;
+        }
+        std::vector<uint8_t> out;
+        if (start == end) return out;
+        const size_t w0 = start / 32, w1 = (end + 31) / 32;
+        const size_t n = (length_ < w1 * 32 ? length_ : w1 * 32) - w0 * 32;
+        std::vector<uint8_t> chunk;
+        Result<void> r = default_context().decode(Words(data_.data() + w0, w1 - w0), n, chunk);
+        if (r.is_err()) return r.unwrap_err();
+        out.assign(chunk.begin() + (start - w0 * 32), chunk.begin() + (end - w0 * 32));
+        return out;
+    }
+    Result<std::vector<uint8_t>> to_vec() const { return slice(0, length_); } // sequence.rs:260-262
+    bool operator==(const PackedSequence &o) const { return length_ == o.length_ && data_ == o.data_; }
+    bool operator!=(const PackedSequence &o) const { return !(*this == o); }
+    // traits (analysis.rs)
+    std::array<size_t, 4> base_counts() const {
+        uint64_t c[4] = {0, 0, 0, 0};
+        bitnuc_err e;
+        if (bitnuc_base_counts(default_context().raw(), data_.data(), data_.size(), length_, c, &e) != BITNUC_OK)
+            throw std::runtime_error("bitnuc: base_counts failed: " + NucleotideError::from_c(e).to_string());
+        return {(size_t)c[0], (size_t)c[1], (size_t)c[2], (size_t)c[3]};
+    }
+    double gc_content() const { // analysis.rs:7-16
+        if (length_ == 0) return 0.0;
+        const auto c = base_counts();
+        return ((double)(c[1] + c[2]) / (double)length_) * 100.0;
+    }
+
+  private:
+    std::vector<uint64_t> data_;
+    size_t length_ = 0;
+};
 inline Result<uint64_t> as_2bit(Bytes seq) { return default_context().as_2bit(seq); }
 inline Result<void> from_2bit(uint64_t packed, size_t n, std::vector<uint8_t> &sequence) { return default_context().from_2bit(packed, n, sequence); }
 inline Result<std::vector<uint8_t>> from_2bit_alloc(uint64_t packed, size_t n) { return default_context().from_2bit_alloc(packed, n); }

@@ -221,6 +221,79 @@ pub fn decode_batch(words: &[u64], word_offsets: &[u64], offsets: &[u64]) -> Res
     if st == ffi::BITNUC_OK { Ok(out) } else { Err(to_err(&e)) }
 }
 
+/// `bitnuc::PackedSequence` (src/sequence.rs:5-262) over GPU-encoded data.
+#[derive(Debug, PartialEq, Eq, Clone, Hash)]
+pub struct PackedSequence {
+    data: Vec<u64>,
+    length: usize,
+}
+
+impl PackedSequence {
+    pub fn new(seq: &[u8]) -> Result<Self, NucleotideError> {
+        let mut data = Vec::new();
+        if !seq.is_empty() {
+            encode(seq, &mut data)?;
+        }
+        Ok(Self { data, length: seq.len() })
+    }
+    pub fn len(&self) -> usize {
+        self.length
+    }
+    pub fn is_empty(&self) -> bool {
+        self.length == 0
+    }
+    pub fn get(&self, index: usize) -> Result<u8, NucleotideError> {
+        if index >= self.length {
+            return Err(NucleotideError::IndexOutOfBounds { index, length: self.length });
+        }
+        Ok(from_2bit_alloc(self.data[index / 32] >> ((index % 32) * 2), 1)?[0])
+    }
+    pub fn slice(&self, range: std::ops::Range<usize>) -> Result<Vec<u8>, NucleotideError> {
+        if range.start > range.end || range.end > self.length {
+            return Err(NucleotideError::InvalidRange { start: range.start, end: range.end, length: self.length });
+        }
+        if range.start == range.end {
+            return Ok(Vec::new());
+        }
+        let (w0, w1) = (range.start / 32, range.end.div_ceil(32));
+        let n = self.length.min(w1 * 32) - w0 * 32;
+        let mut chunk = Vec::with_capacity(n);
+        decode(&self.data[w0..w1], n, &mut chunk)?; // only the words the range touches
+        Ok(chunk[range.start - w0 * 32..range.end - w0 * 32].to_vec())
+    }
+    pub fn to_vec(&self) -> Result<Vec<u8>, NucleotideError> {
+        self.slice(0..self.length)
+    }
+}
+
+/// src/utils/analysis.rs:3-39, evaluated on the packed words on the GPU.
+pub trait GCContent {
+    fn gc_content(&self) -> f64;
+}
+pub trait BaseCount {
+    fn base_counts(&self) -> [usize; 4];
+}
+impl BaseCount for PackedSequence {
+    fn base_counts(&self) -> [usize; 4] {
+        let mut c = [0u64; 4];
+        let mut e = ffi::bitnuc_err::default();
+        let st = with_ctx(|ctx| unsafe {
+            ffi::bitnuc_base_counts(ctx, self.data.as_ptr(), self.data.len(), self.length, c.as_mut_ptr(), &mut e)
+        });
+        assert!(st == ffi::BITNUC_OK);
+        [c[0] as usize, c[1] as usize, c[2] as usize, c[3] as usize]
+    }
+}
+impl GCContent for PackedSequence {
+    fn gc_content(&self) -> f64 {
+        if self.length == 0 {
+            return 0.0;
+        }
+        let c = self.base_counts();
+        ((c[1] + c[2]) as f64 / self.length as f64) * 100.0
+    }
+}
+
 #[cfg(test)]
 mod testing {
     // the reference's own unit tests (src/utils/packing/mod.rs:144-198 etc.) run unchanged

@@ -148,6 +148,28 @@ static void test_batch_equals_loop() {
     for (size_t i = 0; i < seq.size(); ++i) CHECK(back[i] == (seq[i] & 0xDF));
 }
 
+static void test_packed_sequence() { // src/sequence.rs:266-338, src/utils/analysis.rs:41-84
+    auto seq = PackedSequence::new_("ACGT").unwrap();
+    CHECK(seq.len() == 4);
+    auto v = seq.to_vec().unwrap();
+    CHECK(std::string(v.begin(), v.end()) == "ACGT");
+    CHECK(seq.get(0).unwrap() == 'A' && seq.get(1).unwrap() == 'C' && seq.get(2).unwrap() == 'G' && seq.get(3).unwrap() == 'T');
+    auto oob = seq.get(4);
+    CHECK(oob.is_err() && oob.unwrap_err().kind == NucleotideError::IndexOutOfBounds && oob.unwrap_err().oob_index == 4 && oob.unwrap_err().length == 4);
+    auto s8 = PackedSequence::new_("ACGTACGT").unwrap();
+    auto sl = s8.slice(1, 5).unwrap();
+    CHECK(std::string(sl.begin(), sl.end()) == "CGTA");
+    CHECK(s8.slice(2, 2).unwrap().empty());
+    auto bad = seq.slice(3, 2);
+    CHECK(bad.is_err() && bad.unwrap_err().kind == NucleotideError::InvalidRange && bad.unwrap_err().start == 3 && bad.unwrap_err().end == 2 && bad.unwrap_err().length == 4);
+    CHECK(PackedSequence::new_("ACGT").unwrap() == seq && PackedSequence::new_("TGCA").unwrap() != seq);
+    CHECK(PackedSequence::new_("ACGN").is_err());
+    auto empty = PackedSequence::new_("").unwrap();
+    CHECK(empty.is_empty() && empty.gc_content() == 0.0 && empty.base_counts() == (std::array<size_t, 4>{0, 0, 0, 0}));
+    CHECK(PackedSequence::new_("ACGTA").unwrap().gc_content() == 40.0);
+    CHECK(PackedSequence::new_("AACG").unwrap().base_counts() == (std::array<size_t, 4>{2, 1, 1, 0}));
+}
+
 int main() {
 #define RUN(t) do { t(); std::printf("ok %s\n", #t); } while (0)
     RUN(test_as_2bit_valid_sequence);
@@ -164,6 +186,7 @@ int main() {
     RUN(test_encode_error_keeps_prefix_words);
     RUN(test_hdist);
     RUN(test_batch_equals_loop);
+    RUN(test_packed_sequence);
     std::printf("ALL OK\n");
     return 0;
 }

@@ -102,6 +102,21 @@ V["base_counts"] = [{"seq": s_, "counts": c_, "src": "src/utils/analysis.rs:64-7
                      ("ACGTA", [2, 1, 1, 1])]]
 V["empty_sequence_analysis"] = {"gc": 0.0, "counts": [0, 0, 0, 0], "src": "src/utils/analysis.rs:79-83"}
 
+# --- PackedSequence ---------------------------------------------------------
+V["packed_sequence"] = {
+    "new": {"seq": "ACGT", "len": 4, "to_vec": "ACGT", "src": "src/sequence.rs:271-275"},
+    "get": {"seq": "ACGT", "bases": ["A", "C", "G", "T"], "src": "src/sequence.rs:278-284"},
+    "get_oob": {"seq": "ACGT", "index": 4, "length": 4, "src": "src/sequence.rs:287-296"},
+    "slices": [{"seq": "ACGTACGT", "start": 1, "end": 5, "out": "CGTA", "src": "src/sequence.rs:299-302,151"},
+               {"seq": "ACGTACGT", "start": 0, "end": 3, "out": "ACG", "src": "src/sequence.rs:154"},
+               {"seq": "ACGTACGT", "start": 5, "end": 8, "out": "CGT", "src": "src/sequence.rs:157"},
+               {"seq": "ACGTACGT", "start": 2, "end": 2, "out": "", "src": "src/sequence.rs:168"}],
+    "invalid_slice": {"seq": "ACGT", "start": 3, "end": 2, "length": 4, "src": "src/sequence.rs:306-316"},
+    "equality": {"same": ["ACGT", "ACGT"], "different": ["ACGT", "TGCA"], "src": "src/sequence.rs:319-338"},
+    "invalid": {"seq": "ACGN", "src": "src/sequence.rs:36-37"},
+    "empty": {"seq": "", "len": 0, "to_vec": "", "src": "src/sequence.rs:42-46,80,250"},
+}
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json")
     with open(out, "w") as f:

@@ -698,3 +698,42 @@ def test_analysis_full_scale(ctx, oracle):
     assert int(dist[12345]) == 0
     h = words[:5000].cpu().numpy().view(np.uint64)
     assert np.array_equal(dist[:5000].cpu().numpy(), oracle.hdist_pairs(h, np.full(5000, q, np.uint64), 32))
+
+
+# ---- PackedSequence: the reference's own tests, src/sequence.rs:266-338 --------
+def test_packed_sequence_golden(ctx, golden, oracle):
+    import bitnuc_amd as bn
+    g = golden["packed_sequence"]
+    seq = bn.PackedSequence.new(g["new"]["seq"].encode(), ctx)
+    assert seq.len() == g["new"]["len"] and len(seq) == g["new"]["len"] and seq.to_vec() == g["new"]["to_vec"].encode()
+    seq = bn.PackedSequence(g["get"]["seq"].encode(), ctx)
+    assert [chr(seq.get(i)) for i in range(4)] == g["get"]["bases"]
+    with pytest.raises(bn.NucleotideError) as ei:
+        seq.get(g["get_oob"]["index"])
+    assert ei.value == bn.NucleotideError("IndexOutOfBounds", index=4, length=4)
+    for v in g["slices"]:
+        assert bn.PackedSequence(v["seq"].encode(), ctx).slice(v["start"], v["end"]) == v["out"].encode(), v["src"]
+    v = g["invalid_slice"]
+    with pytest.raises(bn.NucleotideError) as ei:
+        bn.PackedSequence(v["seq"].encode(), ctx).slice(v["start"], v["end"])
+    assert ei.value == bn.NucleotideError("InvalidRange", start=3, end=2, length=4)
+    a, b = (bn.PackedSequence(s.encode(), ctx) for s in g["equality"]["same"])
+    c = bn.PackedSequence(g["equality"]["different"][1].encode(), ctx)
+    assert a == b and a != c and b in {a} and c not in {a}
+    with pytest.raises(bn.NucleotideError):
+        bn.PackedSequence(g["invalid"]["seq"].encode(), ctx)
+    e = bn.PackedSequence(b"", ctx)
+    assert e.is_empty() and e.len() == 0 and e.to_vec() == b"" and e.gc_content() == 0.0 and e.base_counts() == [0, 0, 0, 0]
+    for v in golden["gc_content"]:
+        assert bn.PackedSequence(v["seq"].encode(), ctx).gc_content() == v["gc"]
+    for v in golden["base_counts"]:
+        assert bn.PackedSequence(v["seq"].encode(), ctx).base_counts() == v["counts"]
+    # random slices against the ASCII original
+    s = rand_seq(5000)
+    up = bytes(s).upper()
+    p = bn.PackedSequence(s, ctx)
+    assert p.to_vec() == up
+    for _ in range(50):
+        i, j = sorted(int(x) for x in RNG.integers(0, 5001, size=2))
+        assert p.slice(i, j) == up[i:j]
+    assert all(p.get(i) == up[i] for i in (0, 1, 31, 32, 33, 4999))
