@@ -172,98 +172,104 @@ def main():
 
     extra = {}
     if world > 1 and on_gpu_collectives:  # config 4's concatenation, reported beside the step, never inside it
-        from bitnuc_amd.dist import allgather_packed
-        allgather_packed(words[0])
-        fence()
-        t = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            full = allgather_packed(words[0])
-        fence()
-        ag = (time.perf_counter() - t) / reps
-        del full
-        extra["allgather_packed"] = {"ms": round(ag * 1e3, 3), "bytes_received_per_gpu": nw * 8 * (world - 1),
-                                     "gb_s_per_gpu": round(nw * 8 * (world - 1) / ag / 1e9, 2),
-                                     "note": "RCCL all-gather of the packed u64 buffer over xGMI; fabric-bound, outside the timed step"}
+        try:
+            from bitnuc_amd.dist import allgather_packed
+            allgather_packed(words[0])
+            fence()
+            t = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                full = allgather_packed(words[0])
+            fence()
+            ag = (time.perf_counter() - t) / reps
+            del full
+            extra["allgather_packed"] = {"ms": round(ag * 1e3, 3), "bytes_received_per_gpu": nw * 8 * (world - 1),
+                                         "gb_s_per_gpu": round(nw * 8 * (world - 1) / ag / 1e9, 2),
+                                         "note": "RCCL all-gather of the packed u64 buffer over xGMI; fabric-bound, outside the timed step"}
+        except Exception as e:  # noqa: BLE001 -- a side measurement must never cost the headline line
+            extra["allgather_packed"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_extras:
-        # BASELINE configs[2] and [4], measured beside the headline (never inside the timed step)
-        del backs[1:], seqs[1:], words[1:]
-        torch.cuda.empty_cache()
+        try:
+            # BASELINE configs[2] and [4], measured beside the headline (never inside the timed step)
+            del backs[1:], seqs[1:], words[1:]
+            torch.cuda.empty_cache()
 
-        def timed(fn, reps=10):
-            ms = []
-            for _ in range(reps + 2):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-                fn()
-                b.record(stream)
-                torch.cuda.synchronize()
-                ms.append(a.elapsed_time(b))
-            return statistics.median(ms[2:])
-        count, k = 10**8, 31
-        kseq = torch.empty(count * k, dtype=torch.uint8, device=dev)
-        ctx.nucgen_dev(kseq, count * k, SEED + 100)
-        kout = torch.empty(count, dtype=torch.int64, device=dev)
-        ms = timed(lambda: ctx.as_2bit_batch_dev(kseq, k, k, count, kout))
-        gbs = count * (k + 8) / (ms * 1e-3) / 1e9
-        extra["kmer_batch"] = {"workload": "BASELINE configs[2]: 10^8 dense 31-mers as_2bit -> u64", "gkmers_s": round(count / (ms * 1e-3) / 1e9, 2),
-                               "ms": round(ms, 4), "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                                "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": count * (k + 8)}}
-        del kseq, kout
-        dist_out = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
-        q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
-        ms = timed(lambda: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, dist_out))
-        gbs = 2 * (n - k + 1) / (ms * 1e-3) / 1e9
-        extra["kmer_hdist_scan"] = {"workload": "BASELINE configs[4]: sliding 31-mer pack + Hamming distance to one query over 10^9 bases",
-                                    "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4),
+            def timed(fn, reps=10):
+                ms = []
+                for _ in range(reps + 2):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    fn()
+                    b.record(stream)
+                    torch.cuda.synchronize()
+                    ms.append(a.elapsed_time(b))
+                return statistics.median(ms[2:])
+            count, k = 10**8, 31
+            kseq = torch.empty(count * k, dtype=torch.uint8, device=dev)
+            ctx.nucgen_dev(kseq, count * k, SEED + 100)
+            kout = torch.empty(count, dtype=torch.int64, device=dev)
+            ms = timed(lambda: ctx.as_2bit_batch_dev(kseq, k, k, count, kout))
+            gbs = count * (k + 8) / (ms * 1e-3) / 1e9
+            extra["kmer_batch"] = {"workload": "BASELINE configs[2]: 10^8 dense 31-mers as_2bit -> u64", "gkmers_s": round(count / (ms * 1e-3) / 1e9, 2),
+                                   "ms": round(ms, 4), "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                    "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": count * (k + 8)}}
+            del kseq, kout
+            dist_out = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
+            q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
+            ms = timed(lambda: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, dist_out))
+            gbs = 2 * (n - k + 1) / (ms * 1e-3) / 1e9
+            extra["kmer_hdist_scan"] = {"workload": "BASELINE configs[4]: sliding 31-mer pack + Hamming distance to one query over 10^9 bases",
+                                        "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4),
+                                        "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 2 * (n - k + 1)}}
+            # bulk packed-vs-packed Hamming distance (hdist, hamming/multi.rs:121-160): 16 B per 32-base word pair
+            wa, wb = words[0], torch.empty(nw, dtype=torch.int64, device=dev)
+            ctx.nucgen_dev(backs[0], n, SEED + 200)
+            ctx.encode_dev(backs[0], n, wb)
+            res = torch.zeros(1, dtype=torch.int32, device=dev)
+            ms = timed(lambda: ctx.hdist_dev(wa, nw, wb, nw, n, res))
+            gbs = 16 * nw / (ms * 1e-3) / 1e9
+            extra["hdist_bulk"] = {"workload": "hdist of two 10^9-base packed buffers (SURVEY 8f rank 1)", "ms": round(ms, 4),
+                                   "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "distance": int(res.item()) & 0xFFFFFFFF,
+                                   "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 16 * nw}}
+            # analysis directly on packed words
+            cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+            ms = timed(lambda: ctx.base_counts_dev(wa, nw, n, cnt))
+            gbs = 8 * nw / (ms * 1e-3) / 1e9
+            extra["base_counts"] = {"workload": "A/C/G/T counts of 10^9 packed bases (analysis.rs:23-39 without the decode)", "ms": round(ms, 4),
+                                    "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "counts": cnt.tolist(),
                                     "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 2 * (n - k + 1)}}
-        # bulk packed-vs-packed Hamming distance (hdist, hamming/multi.rs:121-160): 16 B per 32-base word pair
-        wa, wb = words[0], torch.empty(nw, dtype=torch.int64, device=dev)
-        ctx.nucgen_dev(backs[0], n, SEED + 200)
-        ctx.encode_dev(backs[0], n, wb)
-        res = torch.zeros(1, dtype=torch.int32, device=dev)
-        ms = timed(lambda: ctx.hdist_dev(wa, nw, wb, nw, n, res))
-        gbs = 16 * nw / (ms * 1e-3) / 1e9
-        extra["hdist_bulk"] = {"workload": "hdist of two 10^9-base packed buffers (SURVEY 8f rank 1)", "ms": round(ms, 4),
-                               "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "distance": int(res.item()) & 0xFFFFFFFF,
-                               "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 16 * nw}}
-        # analysis directly on packed words
-        cnt = torch.zeros(4, dtype=torch.int64, device=dev)
-        ms = timed(lambda: ctx.base_counts_dev(wa, nw, n, cnt))
-        gbs = 8 * nw / (ms * 1e-3) / 1e9
-        extra["base_counts"] = {"workload": "A/C/G/T counts of 10^9 packed bases (analysis.rs:23-39 without the decode)", "ms": round(ms, 4),
-                                "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "counts": cnt.tolist(),
-                                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 8 * nw}}
-        qd = torch.empty(nw, dtype=torch.uint8, device=dev)
-        ms = timed(lambda: ctx.hdist_query_dev(0x1B1B1B1B1B1B1B1B, wa, nw, 32, qd))
-        gbs = 9 * nw / (ms * 1e-3) / 1e9
-        extra["hdist_query"] = {"workload": "one packed 32-mer against 3.1e7 packed 32-mers -> u8 distances", "ms": round(ms, 4),
-                                "gwords_s": round(nw / (ms * 1e-3) / 1e9, 2),
-                                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 9 * nw}}
-        del qd
-        # ragged batch of independent sequences: 150-base reads (each read pads its own last word)
-        L, rcount = 150, n // 150
-        roff = torch.arange(0, rcount + 1, dtype=torch.int64, device=dev) * L
-        rwo = torch.empty(rcount + 1, dtype=torch.int64, device=dev)
-        torch.cuda.synchronize()
-        rtotal = ctx.batch_word_offsets_dev(roff, rcount, rwo)
-        rwords = torch.empty(rtotal, dtype=torch.int64, device=dev)
-        ms_e = timed(lambda: ctx.encode_batch_dev(seqs[0], roff, rwo, rcount, rtotal, rwords))
-        ms_d = timed(lambda: ctx.decode_batch_dev(rwords, rwo, roff, rcount, rtotal, backs[0]))
-        rb = L * rcount
-        alg = rb + 8 * rtotal  # bases + packed words (offset tables: +16 B per read, not counted)
-        extra["reads_batch"] = {"workload": f"{rcount} independent 150-base reads, encode_batch / decode_batch (each read pads its own last word)",
-                                "encode_ms": round(ms_e, 4), "decode_ms": round(ms_d, 4),
-                                "encode_gbases_s": round(rb / (ms_e * 1e-3) / 1e9, 1), "decode_gbases_s": round(rb / (ms_d * 1e-3) / 1e9, 1),
-                                "encode_gb_s": round(alg / (ms_e * 1e-3) / 1e9, 1), "decode_gb_s": round(alg / (ms_d * 1e-3) / 1e9, 1),
-                                "algorithmic_bytes_per_launch": alg}
-        del rwords, roff, rwo
-        ctx.sync()
-        backs.append(dist_out)  # reused by the probe below
+                                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 8 * nw}}
+            qd = torch.empty(nw, dtype=torch.uint8, device=dev)
+            ms = timed(lambda: ctx.hdist_query_dev(0x1B1B1B1B1B1B1B1B, wa, nw, 32, qd))
+            gbs = 9 * nw / (ms * 1e-3) / 1e9
+            extra["hdist_query"] = {"workload": "one packed 32-mer against 3.1e7 packed 32-mers -> u8 distances", "ms": round(ms, 4),
+                                    "gwords_s": round(nw / (ms * 1e-3) / 1e9, 2),
+                                    "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 9 * nw}}
+            del qd
+            # ragged batch of independent sequences: 150-base reads (each read pads its own last word)
+            L, rcount = 150, n // 150
+            roff = torch.arange(0, rcount + 1, dtype=torch.int64, device=dev) * L
+            rwo = torch.empty(rcount + 1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            rtotal = ctx.batch_word_offsets_dev(roff, rcount, rwo)
+            rwords = torch.empty(rtotal, dtype=torch.int64, device=dev)
+            ms_e = timed(lambda: ctx.encode_batch_dev(seqs[0], roff, rwo, rcount, rtotal, rwords))
+            ms_d = timed(lambda: ctx.decode_batch_dev(rwords, rwo, roff, rcount, rtotal, backs[0]))
+            rb = L * rcount
+            alg = rb + 8 * rtotal  # bases + packed words (offset tables: +16 B per read, not counted)
+            extra["reads_batch"] = {"workload": f"{rcount} independent 150-base reads, encode_batch / decode_batch (each read pads its own last word)",
+                                    "encode_ms": round(ms_e, 4), "decode_ms": round(ms_d, 4),
+                                    "encode_gbases_s": round(rb / (ms_e * 1e-3) / 1e9, 1), "decode_gbases_s": round(rb / (ms_d * 1e-3) / 1e9, 1),
+                                    "encode_gb_s": round(alg / (ms_e * 1e-3) / 1e9, 1), "decode_gb_s": round(alg / (ms_d * 1e-3) / 1e9, 1),
+                                    "algorithmic_bytes_per_launch": alg}
+            del rwords, roff, rwo
+            ctx.sync()
+            backs.append(dist_out)  # reused by the probe below
+        except Exception as e:  # noqa: BLE001 -- side measurements must never cost the headline line
+            extra["extras_error"] = repr(e)[:300]
     if args.probe:
         probe = {}
         for name, mode, nbytes in [("read", 0 | 8, n), ("copy", 1 | 8, n), ("fill", 2 | 8, n), ("read_plain", 0, n), ("copy_plain", 1, n)]:
@@ -314,7 +320,10 @@ def main():
         }
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(e)[:300]}
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
