@@ -737,3 +737,42 @@ def test_packed_sequence_golden(ctx, golden, oracle):
         i, j = sorted(int(x) for x in RNG.integers(0, 5001, size=2))
         assert p.slice(i, j) == up[i:j]
     assert all(p.get(i) == up[i] for i in (0, 1, 31, 32, 33, 4999))
+
+
+def test_hip_graph_capture_of_a_step(oracle):
+    """The _dev entry points allocate nothing and never synchronise, so an encode+decode step
+    can be captured into a hipGraph and replayed on new data (launch-bound pipelines)."""
+    import torch
+    import bitnuc_amd as bn
+    dev = torch.device("cuda:0")
+    n = 1_000_003
+    nw = (n + 31) // 32
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        c = bn.Context(0, stream=s.cuda_stream)
+        seq = torch.empty(n, dtype=torch.uint8, device=dev)
+        words = torch.empty(nw, dtype=torch.int64, device=dev)
+        back = torch.empty(n, dtype=torch.uint8, device=dev)
+        c.nucgen_dev(seq, n, 1)
+        c.encode_dev(seq, n, words)
+        c.decode_dev(words, nw, n, back)
+        c.sync()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            c.encode_dev(seq, n, words)
+            c.decode_dev(words, nw, n, back)
+        for seed in (2, 3, 4):
+            c.nucgen_dev(seq, n, seed)
+            back.zero_()
+            g.replay()
+            s.synchronize()
+            assert torch.equal(seq, back)
+            h = seq[:64000].cpu().numpy()
+            assert np.array_equal(words[:2000].cpu().numpy().view(np.uint64), oracle.encode(h))
+        # a replay on invalid data latches the error in the captured launch's slot
+        seq[777] = ord("N")
+        g.replay()
+        with pytest.raises(bn.NucleotideError) as ei:
+            c.sync()
+        assert (ei.value.byte, ei.value.index) == (ord("N"), 777)
+        c.close()
