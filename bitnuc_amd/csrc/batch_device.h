@@ -118,13 +118,40 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long
     return before + inc - v;
 }
 
+// A workgroup owns kBlock*kScanItems consecutive sequences.  Global accesses are coalesced
+// (sequence t + kBlock*j in round j); the per-thread serial part (16 consecutive sequences
+// per thread, needed for the scan order) runs on an LDS copy of the word counts.
+constexpr int kScanTile = kBlock * kScanItems;
+
+__device__ __forceinline__ void load_counts_to_lds(const unsigned long long *__restrict__ offsets, unsigned long long count,
+                                                   unsigned long long i0, uint32_t *cnt /* [kScanTile] */) {
+    for (int j = 0; j < kScanItems; ++j) {
+        const unsigned long long i = i0 + (unsigned long long)j * kBlock + threadIdx.x;
+        // ceil(len/32) of one sequence fits u32 for sequences < 2^37 bases; longer ones saturate the
+        // u32 and are re-read exactly in the serial part below
+        unsigned long long w = i < count ? words_of(offsets, i) : 0ull;
+        cnt[j * kBlock + threadIdx.x] = w > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)w;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ unsigned long long count_at(const unsigned long long *__restrict__ offsets, unsigned long long i,
+                                                       const uint32_t *cnt, unsigned local) {
+    const uint32_t c = cnt[local];
+    return c == 0xFFFFFFFFu ? words_of(offsets, i) : c;
+}
+
 __global__ void __launch_bounds__(kBlock)
 word_offsets_block_sums(const unsigned long long *__restrict__ offsets, unsigned long long count,
                         unsigned long long *__restrict__ block_sums) {
-    const unsigned long long i0 = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) * kScanItems;
+    __shared__ uint32_t cnt[kScanTile];
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * kScanTile;
+    load_counts_to_lds(offsets, count, i0, cnt);
     unsigned long long s = 0;
-    for (int j = 0; j < kScanItems; ++j)
-        if (i0 + j < count) s += words_of(offsets, i0 + j);
+    for (int j = 0; j < kScanItems; ++j) {
+        const unsigned local = threadIdx.x * kScanItems + j;
+        if (i0 + local < count) s += count_at(offsets, i0 + local, cnt, local);
+    }
     unsigned long long total;
     block_exclusive_scan(s, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -149,19 +176,29 @@ word_offsets_scan_sums(unsigned long long *__restrict__ block_sums, unsigned lon
 __global__ void __launch_bounds__(kBlock)
 word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned long long count,
                     const unsigned long long *__restrict__ block_sums, unsigned long long *__restrict__ word_offsets) {
-    const unsigned long long i0 = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) * kScanItems;
+    __shared__ uint32_t cnt[kScanTile];
+    __shared__ unsigned long long res[kScanTile];
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * kScanTile;
+    load_counts_to_lds(offsets, count, i0, cnt);
     unsigned long long v[kScanItems], s = 0;
     for (int j = 0; j < kScanItems; ++j) {
-        v[j] = i0 + j < count ? words_of(offsets, i0 + j) : 0;
+        const unsigned local = threadIdx.x * kScanItems + j;
+        v[j] = i0 + local < count ? count_at(offsets, i0 + local, cnt, local) : 0;
         s += v[j];
     }
     unsigned long long total;
     unsigned long long run = block_sums[blockIdx.x] + block_exclusive_scan(s, &total);
     for (int j = 0; j < kScanItems; ++j) {
-        if (i0 + j < count) word_offsets[i0 + j] = run;
+        res[threadIdx.x * kScanItems + j] = run;
         run += v[j];
-        if (i0 + j + 1 == count) word_offsets[count] = run; // total number of words
     }
+    __syncthreads();
+    for (int j = 0; j < kScanItems; ++j) { // coalesced write-out
+        const unsigned local = j * kBlock + threadIdx.x;
+        if (i0 + local < count) word_offsets[i0 + local] = res[local];
+    }
+    // total number of words: written by the workgroup that holds the last sequence
+    if (threadIdx.x == kBlock - 1 && i0 + kScanTile >= count) word_offsets[count] = block_sums[blockIdx.x] + total;
 }
 
 // ---------------------------------------------------------------------------------

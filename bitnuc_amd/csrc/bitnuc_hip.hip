@@ -728,7 +728,7 @@ int bitnuc_batch_word_offsets_dev(bitnuc_ctx *c, const uint64_t *d_offsets, size
         HIPCHK(hipStreamSynchronize(c->stream));
         return BITNUC_OK;
     }
-    const size_t per_block = (size_t)kBlock * kScanItems;
+    const size_t per_block = (size_t)kScanTile;
     const size_t nblocks = (count + per_block - 1) / per_block;
     if (int st = ensure_scratch(c, 3, nblocks * sizeof(uint64_t), err)) return st;
     unsigned long long *sums = reinterpret_cast<unsigned long long *>(c->scratch[3]);

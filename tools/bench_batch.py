@@ -34,7 +34,12 @@ for L in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "32,
     off = torch.arange(0, count + 1, dtype=torch.int64, device=dev) * L
     wo = torch.empty(count + 1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
+    import time
     total = ctx.batch_word_offsets_dev(off, count, wo)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        total = ctx.batch_word_offsets_dev(off, count, wo)
+    t_off = (time.perf_counter() - t0) / 5 * 1e3
     words = torch.empty(total, dtype=torch.int64, device=dev)
     e = timed(lambda: ctx.encode_batch_dev(seq, off, wo, count, total, words))
     d = timed(lambda: ctx.decode_batch_dev(words, wo, off, count, total, back))
@@ -42,4 +47,4 @@ for L in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "32,
     nb = L * count
     ok = bool(torch.equal(seq[:nb], back[:nb]))
     alg = nb + 8 * total
-    print(f"L={L:8d} count={count:9d} encode {e:.4f} ms {alg/e/1e6:6.0f} GB/s | decode {d:.4f} ms {alg/d/1e6:6.0f} GB/s | roundtrip {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"L={L:8d} count={count:9d} encode {e:.4f} ms {alg/e/1e6:6.0f} GB/s | decode {d:.4f} ms {alg/d/1e6:6.0f} GB/s | word_offsets {t_off:.3f} ms (host-synchronous) | roundtrip {'ok' if ok else 'MISMATCH'}", flush=True)
