@@ -58,6 +58,15 @@ SIGNATURES = {
     "bitnuc_hdist_query_dev": (C.c_int, [_P, _U64, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_hdist_pairs": (C.c_int, [_P, _P, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_hdist_query": (C.c_int, [_P, _U64, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_comm_get_unique_id": (C.c_int, [_P, _ERR]),
+    "bitnuc_comm_init_rank": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(_P), _ERR]),
+    "bitnuc_comm_init_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), _ERR]),
+    "bitnuc_comm_destroy": (None, [_P]),
+    "bitnuc_comm_nranks": (C.c_int, [_P]),
+    "bitnuc_comm_rank": (C.c_int, [_P]),
+    "bitnuc_allgather_words_dev": (C.c_int, [_P, _P, _P, _SZ, _P, _ERR]),
+    "bitnuc_encode_sharded_allgather_dev": (C.c_int, [_P, _P, _P, _SZ, _P, _ERR]),
+    "bitnuc_encode_sharded_allgather_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, C.POINTER(_P), _ERR]),
     "bitnuc_nucgen_dev": (C.c_int, [_P, _P, _SZ, _U64, _U64, C.c_int, _ERR]),
     "bitnuc_stream_probe_dev": (C.c_int, [_P, C.c_int, _P, _P, _SZ, _ERR]),
 }

@@ -368,6 +368,56 @@ class Context:
         self._call_dev(self._lib.bitnuc_stream_probe_dev, int(mode), _dev_ptr(d_src), _dev_ptr(d_dst), int(nbytes))
 
 
+class Comm:
+    """One rank of an RCCL communicator bound to a Context (config 4's concatenation).
+    One process per GPU: rank 0 makes `Comm.unique_id()`, shares the 128 bytes, every rank
+    calls `Comm(ctx, nranks, rank, uid)`."""
+
+    def __init__(self, ctx, nranks, rank, uid):
+        self._lib = L.load()
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(uid))
+        err = L.BitnucErr()
+        if self._lib.bitnuc_comm_init_rank(ctx._h, int(nranks), int(rank), buf, C.byref(self._h), C.byref(err)) != L.OK:
+            self._h = C.c_void_p()
+            _raise(err)
+
+    @staticmethod
+    def unique_id():
+        lib = L.load()
+        buf = (C.c_uint8 * 128)()
+        err = L.BitnucErr()
+        if lib.bitnuc_comm_get_unique_id(buf, C.byref(err)) != L.OK:
+            _raise(err)
+        return bytes(buf)
+
+    @property
+    def nranks(self):
+        return self._lib.bitnuc_comm_nranks(self._h)
+
+    @property
+    def rank(self):
+        return self._lib.bitnuc_comm_rank(self._h)
+
+    def allgather_words_dev(self, d_local, count, d_all):
+        err = L.BitnucErr()
+        if self._lib.bitnuc_allgather_words_dev(self._ctx._h, self._h, _dev_ptr(d_local), int(count), _dev_ptr(d_all), C.byref(err)) != L.OK:
+            _raise(err)
+
+    def encode_sharded_allgather_dev(self, d_seq_shard, shard_len, d_all):
+        err = L.BitnucErr()
+        if self._lib.bitnuc_encode_sharded_allgather_dev(self._ctx._h, self._h, _dev_ptr(d_seq_shard), int(shard_len), _dev_ptr(d_all), C.byref(err)) != L.OK:
+            _raise(err)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.bitnuc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
 # ---- module-level functions with the reference's names (default context, device 0) ----------
 _default = None
 

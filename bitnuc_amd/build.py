@@ -36,7 +36,7 @@ def build_library(force=False, verbose=True, extra_flags=()):
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-           *extra_flags, "-o", LIB, *SOURCES]
+           *extra_flags, "-o", LIB, *SOURCES, "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=HERE)

@@ -12,6 +12,7 @@
 #include "analysis_device.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -929,6 +930,180 @@ int bitnuc_hdist_pairs(bitnuc_ctx *c, const uint64_t *a, const uint64_t *b, size
 
 int bitnuc_hdist_query(bitnuc_ctx *c, uint64_t query, const uint64_t *targets, size_t count, size_t len, uint8_t *dist, bitnuc_err *err) {
     return hdist_words_host(c, true, targets, nullptr, query, count, len, dist, err);
+}
+
+// ---- multi-GPU: RCCL all-gather of the packed words -------------------------------------------
+// RCCL is bound at run time (dlopen) so that single-GPU users do not need librccl.so.
+extern "C++" {
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    void *CommInitRank = nullptr; // takes ncclUniqueId by value: called through a typed pointer below
+    bool ok = false;
+};
+struct UniqueIdBytes { char internal[BITNUC_UNIQUE_ID_BYTES]; }; // == ncclUniqueId
+constexpr int kNcclUint64 = 5;                                     // ncclUint64 (rccl.h)
+
+RcclApi &rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+            api.GetUniqueId = reinterpret_cast<int (*)(void *)>(dlsym(api.handle, "ncclGetUniqueId"));
+            api.CommInitAll = reinterpret_cast<int (*)(void **, int, const int *)>(dlsym(api.handle, "ncclCommInitAll"));
+            api.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(api.handle, "ncclCommDestroy"));
+            api.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(dlsym(api.handle, "ncclAllGather"));
+            api.GroupStart = reinterpret_cast<int (*)()>(dlsym(api.handle, "ncclGroupStart"));
+            api.GroupEnd = reinterpret_cast<int (*)()>(dlsym(api.handle, "ncclGroupEnd"));
+            api.CommInitRank = dlsym(api.handle, "ncclCommInitRank");
+            api.ok = api.GetUniqueId && api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.CommInitRank;
+        }
+    }
+    return api;
+}
+int fail_rccl(bitnuc_err *e, int rc) { // ncclResult_t in backend_code, offset so it cannot be mistaken for a hipError_t
+    if (e) { memset(e, 0, sizeof *e); e->status = BITNUC_BACKEND_ERROR; e->backend_code = 10000 + rc; }
+    return BITNUC_BACKEND_ERROR;
+}
+} // namespace
+} // extern "C++"
+
+struct bitnuc_comm {
+    void *nccl = nullptr; // ncclComm_t
+    int nranks = 0, rank = 0, device = 0;
+};
+
+int bitnuc_comm_get_unique_id(uint8_t id[BITNUC_UNIQUE_ID_BYTES], bitnuc_err *err) {
+    clear_err(err);
+    if (!id) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    UniqueIdBytes u;
+    if (int rc = r.GetUniqueId(&u)) return fail_rccl(err, rc);
+    memcpy(id, u.internal, BITNUC_UNIQUE_ID_BYTES);
+    return BITNUC_OK;
+}
+
+int bitnuc_comm_init_rank(bitnuc_ctx *c, int nranks, int rank, const uint8_t id[BITNUC_UNIQUE_ID_BYTES], bitnuc_comm **out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(err, BITNUC_UNSUPPORTED);
+    *out = nullptr;
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    DeviceGuard g(c->device);
+    UniqueIdBytes u;
+    memcpy(u.internal, id, BITNUC_UNIQUE_ID_BYTES);
+    void *comm = nullptr;
+    auto init = reinterpret_cast<int (*)(void **, int, UniqueIdBytes, int)>(r.CommInitRank);
+    if (int rc = init(&comm, nranks, u, rank)) return fail_rccl(err, rc);
+    bitnuc_comm *bc = new bitnuc_comm();
+    bc->nccl = comm; bc->nranks = nranks; bc->rank = rank; bc->device = c->device;
+    *out = bc;
+    return BITNUC_OK;
+}
+
+int bitnuc_comm_init_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, bitnuc_err *err) {
+    clear_err(err);
+    if (n_gpus < 1 || n_gpus > 64 || !ctxs || !comms) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    for (int i = 0; i < n_gpus; ++i) { ctxs[i] = nullptr; comms[i] = nullptr; }
+    for (int i = 0; i < n_gpus; ++i)
+        if (int st = bitnuc_ctx_create(i, &ctxs[i], err)) {
+            for (int j = 0; j < i; ++j) { bitnuc_ctx_destroy(ctxs[j]); ctxs[j] = nullptr; }
+            return st;
+        }
+    void *raw[64];
+    int devs[64];
+    for (int i = 0; i < n_gpus; ++i) devs[i] = i;
+    if (int rc = r.CommInitAll(raw, n_gpus, devs)) {
+        for (int j = 0; j < n_gpus; ++j) { bitnuc_ctx_destroy(ctxs[j]); ctxs[j] = nullptr; }
+        return fail_rccl(err, rc);
+    }
+    for (int i = 0; i < n_gpus; ++i) {
+        bitnuc_comm *bc = new bitnuc_comm();
+        bc->nccl = raw[i]; bc->nranks = n_gpus; bc->rank = i; bc->device = i;
+        comms[i] = bc;
+    }
+    return BITNUC_OK;
+}
+
+void bitnuc_comm_destroy(bitnuc_comm *comm) {
+    if (!comm) return;
+    RcclApi &r = rccl();
+    if (r.ok && comm->nccl) {
+        DeviceGuard g(comm->device);
+        (void)r.CommDestroy(comm->nccl);
+    }
+    delete comm;
+}
+
+int bitnuc_comm_nranks(const bitnuc_comm *comm) { return comm ? comm->nranks : 0; }
+int bitnuc_comm_rank(const bitnuc_comm *comm) { return comm ? comm->rank : -1; }
+
+int bitnuc_allgather_words_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint64_t *d_local, size_t count, uint64_t *d_all, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!comm || comm->device != c->device) return fail(err, BITNUC_UNSUPPORTED);
+    if (count == 0) return BITNUC_OK;
+    if (!d_local || !d_all) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    DeviceGuard g(c->device);
+    if (int rc = r.AllGather(d_local, d_all, count, kNcclUint64, comm->nccl, c->stream)) return fail_rccl(err, rc);
+    return BITNUC_OK;
+}
+
+int bitnuc_encode_sharded_allgather_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, uint64_t *d_all, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!comm || comm->device != c->device) return fail(err, BITNUC_UNSUPPORTED);
+    // every rank contributes the same number of whole words: shard_len must be a multiple of 32
+    // (ragged tails belong in the last rank of a bitnuc_amd.dist.shard_range-style split + padding)
+    if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
+    if (shard_len == 0) return BITNUC_OK;
+    const size_t count = shard_len / 32;
+    uint64_t *mine = d_all + (size_t)comm->rank * count;
+    if (int st = bitnuc_encode_dev(c, d_seq_shard, shard_len, mine, err)) return st;
+    return bitnuc_allgather_words_dev(c, comm, mine, count, d_all, err);
+}
+
+int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err) {
+    clear_err(err);
+    if (n_gpus < 1 || !ctxs || !comms || !d_seq_shards || !d_alls) return fail(err, BITNUC_UNSUPPORTED);
+    if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
+    if (shard_len == 0) return BITNUC_OK;
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    const size_t count = shard_len / 32;
+    for (int i = 0; i < n_gpus; ++i) // encode phase: independent, no communication
+        if (int st = bitnuc_encode_dev(ctxs[i], d_seq_shards[i], shard_len, d_alls[i] + (size_t)i * count, err)) return st;
+    if (int rc = r.GroupStart()) return fail_rccl(err, rc);
+    for (int i = 0; i < n_gpus; ++i) {
+        DeviceGuard g(ctxs[i]->device);
+        if (int rc = r.AllGather(d_alls[i] + (size_t)i * count, d_alls[i], count, kNcclUint64, comms[i]->nccl, ctxs[i]->stream)) {
+            (void)r.GroupEnd();
+            return fail_rccl(err, rc);
+        }
+    }
+    if (int rc = r.GroupEnd()) return fail_rccl(err, rc);
+    for (int i = 0; i < n_gpus; ++i) {
+        bitnuc_err e;
+        if (int st = bitnuc_ctx_sync(ctxs[i], &e)) { if (err) *err = e; return st; }
+    }
+    return BITNUC_OK;
 }
 
 // ---- single-word API: batches of one on the device ---------------------------------------------

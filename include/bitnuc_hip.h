@@ -155,6 +155,33 @@ int bitnuc_hdist_query_dev(bitnuc_ctx *ctx, uint64_t query, const uint64_t *d_ta
 int bitnuc_hdist_pairs(bitnuc_ctx *ctx, const uint64_t *a, const uint64_t *b, size_t count, size_t len, uint8_t *dist, bitnuc_err *err);
 int bitnuc_hdist_query(bitnuc_ctx *ctx, uint64_t query, const uint64_t *targets, size_t count, size_t len, uint8_t *dist, bitnuc_err *err);
 
+/* ---- multi-GPU: shard + concatenate (BASELINE config 4) ------------------------------------ */
+/* u64 words never share state (packing/avx.rs:138-145 has no carry), so a sequence split at
+ * multiples of 32 bases encodes shard by shard with no communication; the only exchange is the
+ * optional concatenation of the packed words, one RCCL all-gather over xGMI.  A communicator
+ * rank is bound to one context (one device + stream).  librccl.so is loaded on first use.
+ *   - one process per GPU: rank 0 calls bitnuc_comm_get_unique_id, hands the 128 bytes to the
+ *     other ranks (env, file, MPI, torch.distributed ...), every rank calls bitnuc_comm_init_rank;
+ *   - one process, all GPUs: bitnuc_comm_init_all creates n contexts + communicators at once. */
+typedef struct bitnuc_comm bitnuc_comm;
+#define BITNUC_UNIQUE_ID_BYTES 128
+int bitnuc_comm_get_unique_id(uint8_t id[BITNUC_UNIQUE_ID_BYTES], bitnuc_err *err);
+int bitnuc_comm_init_rank(bitnuc_ctx *ctx, int nranks, int rank, const uint8_t id[BITNUC_UNIQUE_ID_BYTES], bitnuc_comm **out, bitnuc_err *err);
+int bitnuc_comm_init_all(int n_gpus, bitnuc_ctx **ctxs /* out: n_gpus */, bitnuc_comm **comms /* out: n_gpus */, bitnuc_err *err);
+void bitnuc_comm_destroy(bitnuc_comm *comm);
+int bitnuc_comm_nranks(const bitnuc_comm *comm);
+int bitnuc_comm_rank(const bitnuc_comm *comm);
+/* All-gather `count` packed words per rank: d_all[r*count .. (r+1)*count) = rank r's d_local.
+ * d_local may alias d_all + rank*count (in place).  Asynchronous on the context's stream. */
+int bitnuc_allgather_words_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, const uint64_t *d_local, size_t count, uint64_t *d_all, bitnuc_err *err);
+/* Encode this rank's shard (shard_len bases, the same multiple of 32 on every rank) straight
+ * into its slot of d_all and all-gather in place: every rank ends with the packed words of the
+ * whole nranks*shard_len-base sequence, bit-identical to a single-GPU encode of it. */
+int bitnuc_encode_sharded_allgather_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, uint64_t *d_all, bitnuc_err *err);
+/* Single-process form over bitnuc_comm_init_all's contexts: one call drives all n GPUs
+ * (encode on every device, then one grouped all-gather), then synchronises all streams. */
+int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err);
+
 /* ---- synthetic input (the reference's tests use nucgen::Sequence::fill_buffer,
  * src/utils/mod.rs:116-121; its stream is unpinned, so the build ships its own) ---- */
 /* Fill d_out[0..len) with bases first..first+len of the seeded stream

@@ -27,6 +27,12 @@ pub struct bitnuc_ctx {
     _private: [u8; 0],
 }
 
+#[repr(C)]
+pub struct bitnuc_comm {
+    _private: [u8; 0],
+}
+pub const BITNUC_UNIQUE_ID_BYTES: usize = 128;
+
 extern "C" {
     pub fn bitnuc_version() -> *const c_char;
     pub fn bitnuc_ctx_create(device: c_int, out: *mut *mut bitnuc_ctx, err: *mut bitnuc_err) -> c_int;
@@ -62,6 +68,15 @@ extern "C" {
     pub fn bitnuc_hdist_query(ctx: *mut bitnuc_ctx, query: u64, targets: *const u64, count: usize, len: usize, dist: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_hdist_pairs_dev(ctx: *mut bitnuc_ctx, d_a: *const u64, d_b: *const u64, count: usize, len: usize, d_dist: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_hdist_query_dev(ctx: *mut bitnuc_ctx, query: u64, d_targets: *const u64, count: usize, len: usize, d_dist: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_comm_get_unique_id(id: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_comm_init_rank(ctx: *mut bitnuc_ctx, nranks: c_int, rank: c_int, id: *const u8, out: *mut *mut bitnuc_comm, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_comm_init_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_comm_destroy(comm: *mut bitnuc_comm);
+    pub fn bitnuc_comm_nranks(comm: *const bitnuc_comm) -> c_int;
+    pub fn bitnuc_comm_rank(comm: *const bitnuc_comm) -> c_int;
+    pub fn bitnuc_allgather_words_dev(ctx: *mut bitnuc_ctx, comm: *mut bitnuc_comm, d_local: *const u64, count: usize, d_all: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_encode_sharded_allgather_dev(ctx: *mut bitnuc_ctx, comm: *mut bitnuc_comm, d_seq_shard: *const u8, shard_len: usize, d_all: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_encode_sharded_allgather_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, d_seq_shards: *const *const u8, shard_len: usize, d_alls: *const *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_nucgen_dev(ctx: *mut bitnuc_ctx, d_out: *mut u8, len: usize, seed: u64, first: u64, flags: c_int, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_stream_probe_dev(ctx: *mut bitnuc_ctx, mode: c_int, d_src: *const c_void, d_dst: *mut c_void, bytes: usize, err: *mut bitnuc_err) -> c_int;
 }

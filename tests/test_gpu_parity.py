@@ -776,3 +776,46 @@ def test_hip_graph_capture_of_a_step(oracle):
             c.sync()
         assert (ei.value.byte, ei.value.index) == (ord("N"), 777)
         c.close()
+
+
+def test_rccl_comm_single_rank(oracle):
+    """C-ABI RCCL path on the one GPU we have: a 1-rank communicator (all-gather == copy) through
+    init_rank, and the single-process init_all / encode_sharded_allgather_all form with n = 1."""
+    import ctypes as C
+    import torch
+    import bitnuc_amd as bn
+    from bitnuc_amd import _lib as L
+    dev = torch.device("cuda:0")
+    c = bn.Context(0)
+    comm = bn.Comm(c, 1, 0, bn.Comm.unique_id())
+    assert (comm.nranks, comm.rank) == (1, 0)
+    n = 32 * 40001
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    c.nucgen_dev(seq, n, 5)
+    allw = torch.zeros(n // 32, dtype=torch.int64, device=dev)
+    c.sync()
+    comm.encode_sharded_allgather_dev(seq, n, allw)
+    c.sync()
+    assert np.array_equal(allw.cpu().numpy().view(np.uint64), oracle.encode(seq.cpu().numpy()))
+    out = torch.zeros(n // 32, dtype=torch.int64, device=dev)
+    comm.allgather_words_dev(allw, n // 32, out)
+    c.sync()
+    assert torch.equal(out, allw)
+    with pytest.raises(bn.NucleotideError) as ei:
+        comm.encode_sharded_allgather_dev(seq, n - 1, allw)  # shards must be whole words
+    assert ei.value.kind == "InvalidLength"
+    comm.close()
+    c.close()
+    # single-process form
+    lib = L.load()
+    ctxs, comms = (C.c_void_p * 1)(), (C.c_void_p * 1)()
+    err = L.BitnucErr()
+    assert lib.bitnuc_comm_init_all(1, ctxs, comms, C.byref(err)) == 0, err.backend_code
+    seqs = (C.c_void_p * 1)(seq.data_ptr())
+    alls = (C.c_void_p * 1)(out.data_ptr())
+    out.zero_()
+    torch.cuda.synchronize()
+    assert lib.bitnuc_encode_sharded_allgather_all(1, ctxs, comms, seqs, n, alls, C.byref(err)) == 0, err.backend_code
+    assert torch.equal(out, allw)
+    lib.bitnuc_comm_destroy(comms[0])
+    lib.bitnuc_ctx_destroy(ctxs[0])
