@@ -48,6 +48,7 @@ struct bitnuc_ctx {
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
+    int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
 };
 
@@ -270,14 +271,22 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
     if (stride == k && count >= 64 && c->batch_dense) {
         // dense layout: whole waves of 64 k-mers go through the bulk-encode-shaped kernel
         const unsigned long long items = count / 64;
-        const unsigned grid = grid_for(c, (items + kBlock / 64 - 1) / (kBlock / 64));
-        if (!aligned16(kmers)) kmer_dense_kernel<false, false, false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot);
-        else switch (c->dense_policy) { // bit0: nt loads, bit1: nt stores
-        case 0: kmer_dense_kernel<true, false, false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot); break;
-        case 1: kmer_dense_kernel<true, true, false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot); break;
-        case 2: kmer_dense_kernel<true, false, true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot); break;
-        default: kmer_dense_kernel<true, true, true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot); break;
-        }
+        const int un = c->dense_unroll;
+        const unsigned grid = grid_for(c, (items + (kBlock / 64) * un - 1) / ((kBlock / 64) * un));
+#define DENSE_LAUNCH(AL, NL, NS, U) kmer_dense_kernel<AL, NL, NS, U><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot)
+#define DENSE_POLICY(U)                                              \
+    switch (c->dense_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    case 0: DENSE_LAUNCH(true, false, false, U); break;              \
+    case 1: DENSE_LAUNCH(true, true, false, U); break;               \
+    case 2: DENSE_LAUNCH(true, false, true, U); break;               \
+    default: DENSE_LAUNCH(true, true, true, U); break;               \
+    }
+        if (!aligned16(kmers)) { DENSE_LAUNCH(false, false, false, 1); }
+        else if (un == 1) { DENSE_POLICY(1) }
+        else if (un == 2) { DENSE_POLICY(2) }
+        else { DENSE_POLICY(4) }
+#undef DENSE_POLICY
+#undef DENSE_LAUNCH
         hipError_t rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
         done = items * 64;
@@ -426,6 +435,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
     else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
     else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
+    else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
     else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
     else if (!strcmp(key, "num_variants")) { prev = kNumVariants; }
     else if (!strcmp(key, "num_cu")) { prev = c->num_cu; }

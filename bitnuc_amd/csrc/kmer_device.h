@@ -104,39 +104,49 @@ kmer_batch_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
 // strip, and lane j then funnel-shifts its 2k bits out of strip dwords (2kj)>>5 .. +2.
 // 4x less LDS traffic and ~half the VALU work of staging raw bytes (kmer_batch_kernel).
 // Handles whole waves only; the host sends the < 64 leftover k-mers to kmer_batch_kernel.
-template <bool ALIGNED, bool NTLD, bool NTST>
+template <bool ALIGNED, bool NTLD, bool NTST, int UNROLL>
 __global__ void __launch_bounds__(kBlock)
 kmer_dense_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long long nwave_items,
                   unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
-    __shared__ uint32_t strips[kBlock / 64][132];
+    __shared__ uint32_t strips[kBlock / 64][UNROLL][132];
     const unsigned lane = threadIdx.x & 63;
-    uint32_t *ws = strips[threadIdx.x >> 6];
     const unsigned long long wave = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned long long nwaves = ((unsigned long long)gridDim.x * kBlock) >> 6;
     const unsigned ngroups = 4 * k; // 16-byte groups per 64 k-mers
     const unsigned bit = 2 * k * lane, d = bit >> 5, sh = bit & 31;
     const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const u32x4 pad = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+    const bool a0 = lane < ngroups, a1 = lane + 64 < ngroups;
 
-    for (unsigned long long it = wave; it < nwave_items; it += nwaves) {
-        const uint8_t *base = kmers + it * 64ull * k;
-        const bool a0 = lane < ngroups, a1 = lane + 64 < ngroups;
-        const u32x4 v0 = a0 ? load_group<NTLD, ALIGNED>(base + 16 * lane) : pad;
-        const u32x4 v1 = a1 ? load_group<NTLD, ALIGNED>(base + 16 * (lane + 64)) : pad;
-        uint32_t bad = 0;
-        const uint32_t c0 = enc16(v0, bad), c1 = enc16(v1, bad);
-        ws[lane] = c0;
-        ws[lane + 64] = c1;
-        wave_lds_fence();
-        const uint32_t w0 = ws[d], w1 = ws[d + 1], w2 = ws[d + 2];
-        wave_lds_fence();
-        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-        const unsigned long long word = (((unsigned long long)hi << 32) | lo) & kmask;
-        if constexpr (NTST) __builtin_nontemporal_store(word, out + it * 64 + lane);
-        else out[it * 64 + lane] = word;
-        if (__builtin_expect(residue_is_bad(bad), 0)) {
-            if (a0) rescan_bytes(kmers, it * 64ull * k + 16 * lane, 16, slot);
-            if (a1) rescan_bytes(kmers, it * 64ull * k + 16 * (lane + 64), 16, slot);
+    // a wave owns UNROLL consecutive items (64 k-mers each) per trip; all loads are issued first
+    for (unsigned long long it0 = wave * UNROLL; it0 < nwave_items; it0 += nwaves * UNROLL) {
+        u32x4 v0[UNROLL], v1[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const unsigned long long it = it0 + u < nwave_items ? it0 + u : nwave_items - 1; // clamp: in bounds
+            const uint8_t *base = kmers + it * 64ull * k;
+            v0[u] = a0 ? load_group<NTLD, ALIGNED>(base + 16 * lane) : pad;
+            v1[u] = a1 ? load_group<NTLD, ALIGNED>(base + 16 * (lane + 64)) : pad;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (it0 + u >= nwave_items) break; // wave-uniform
+            const unsigned long long it = it0 + u;
+            uint32_t *ws = strips[threadIdx.x >> 6][u];
+            uint32_t bad = 0;
+            ws[lane] = enc16(v0[u], bad);
+            ws[lane + 64] = enc16(v1[u], bad);
+            wave_lds_fence();
+            const uint32_t w0 = ws[d], w1 = ws[d + 1], w2 = ws[d + 2];
+            wave_lds_fence();
+            const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+            const unsigned long long word = (((unsigned long long)hi << 32) | lo) & kmask;
+            if constexpr (NTST) __builtin_nontemporal_store(word, out + it * 64 + lane);
+            else out[it * 64 + lane] = word;
+            if (__builtin_expect(residue_is_bad(bad), 0)) {
+                if (a0) rescan_bytes(kmers, it * 64ull * k + 16 * lane, 16, slot);
+                if (a1) rescan_bytes(kmers, it * 64ull * k + 16 * (lane + 64), 16, slot);
+            }
         }
     }
 }

@@ -45,8 +45,10 @@ for rnd in range(3):
                 ms = burst(lambda i: ctx.kmer_hdist_scan_dev(ref[i % 2], n, k, 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1), dist[i % 2]))
                 rows.append(("scan", g, pol * 10 + un, ms))
             ctx.set_variant("dense_policy", pol)
-            ms = burst(lambda i: ctx.as_2bit_batch_dev(kseq, k, k, count, kout[i % 2]))
-            rows.append(("dense", g, pol, ms))
+            for un in (1, 2, 4):
+                ctx.set_variant("dense_unroll", un)
+                ms = burst(lambda i: ctx.as_2bit_batch_dev(kseq, k, k, count, kout[i % 2]))
+                rows.append(("dense", g, pol * 10 + un, ms))
 ctx.sync()
 agg = {}
 for kind, g, pol, ms in rows:
