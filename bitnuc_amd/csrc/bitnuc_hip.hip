@@ -706,16 +706,16 @@ int bitnuc_hdist(bitnuc_ctx *c, const uint64_t *a, size_t na, const uint64_t *b,
 }
 
 // ---- ragged batches ---------------------------------------------------------------------------
-// owner[b] of every 256-word workgroup, into context scratch (enqueued on the stream)
-static int batch_owners(bitnuc_ctx *c, const uint64_t *d_word_offsets, size_t count, size_t total_words,
-                        const unsigned long long **owner, bitnuc_err *err) {
-    const size_t nblocks = (total_words + kBatchBlock - 1) / kBatchBlock;
-    if (int st = ensure_scratch(c, 3, nblocks * sizeof(uint64_t), err)) return st;
-    unsigned long long *o = reinterpret_cast<unsigned long long *>(c->scratch[3]);
-    block_owner_kernel<<<(unsigned)((nblocks + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(
-        reinterpret_cast<const unsigned long long *>(d_word_offsets), count, nblocks, o);
+// rec[b] = {owner, first byte} of every 64-word wave tile, into context scratch (enqueued on the stream)
+static int batch_owners(bitnuc_ctx *c, const uint64_t *d_offsets, const uint64_t *d_word_offsets, size_t count, size_t total_words,
+                        const TileRec **recs, bitnuc_err *err) {
+    const size_t ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    if (int st = ensure_scratch(c, 3, ntiles * sizeof(TileRec), err)) return st;
+    TileRec *o = reinterpret_cast<TileRec *>(c->scratch[3]);
+    block_owner_kernel<<<(unsigned)((ntiles + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(
+        reinterpret_cast<const unsigned long long *>(d_offsets), reinterpret_cast<const unsigned long long *>(d_word_offsets), count, ntiles, o);
     HIPCHK(hipGetLastError());
-    *owner = o;
+    *recs = o;
     return BITNUC_OK;
 }
 
@@ -762,13 +762,14 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t 
     if (count == 0 || total_words == 0) return BITNUC_OK;
     if (!d_seq || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const unsigned long long *owner;
-    if (int st = batch_owners(c, d_word_offsets, count, total_words, &owner, err)) return st;
+    const TileRec *recs;
+    if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
     unsigned long long *slot;
     if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
-    const unsigned grid = grid_for(c, (total_words + kBatchBlock - 1) / kBatchBlock, kBatchBlock);
-    encode_batch_kernel<<<grid, kBatchBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
-                                                        reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, owner,
+    const size_t per_block = (size_t)kBatchTile * kBatchWaves * kBatchInFlight;
+    const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
+    encode_batch_kernel<<<grid, kBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
+                                                        reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, recs,
                                                         reinterpret_cast<unsigned long long *>(d_out), slot);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
@@ -780,12 +781,12 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64
     if (count == 0 || total_words == 0) return BITNUC_OK;
     if (!d_words || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const unsigned long long *owner;
-    if (int st = batch_owners(c, d_word_offsets, count, total_words, &owner, err)) return st;
-    const unsigned grid = grid_for(c, (total_words + kBatchBlock - 1) / kBatchBlock, kBatchBlock);
-    decode_batch_kernel<<<grid, kBatchBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words),
+    const TileRec *recs;
+    if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
+    const unsigned grid = grid_for(c, (total_words + kBatchDecBlock - 1) / kBatchDecBlock, kBatchDecBlock);
+    decode_batch_kernel<<<grid, kBatchDecBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words),
                                                         reinterpret_cast<const unsigned long long *>(d_word_offsets),
-                                                        reinterpret_cast<const unsigned long long *>(d_offsets), count, total_words, owner, d_out);
+                                                        reinterpret_cast<const unsigned long long *>(d_offsets), count, total_words, recs, d_out);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
