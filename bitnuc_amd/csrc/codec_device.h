@@ -34,8 +34,6 @@ namespace bitnuc_dev {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 u32x4_u __attribute__((aligned(1))); // any byte address (gfx950 unaligned-access mode)
-typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
-typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
 typedef uint32_t u32_u __attribute__((aligned(1)));
 
 constexpr unsigned long long kNoBad = ~0ull;

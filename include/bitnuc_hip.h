@@ -15,8 +15,9 @@
  * Conventions
  *   - plain pointers + sizes, no torch / C++ types in signatures;
  *   - return value == err->status (err may be NULL);
- *   - "host" entry points take host pointers, stage through pinned buffers and
- *     are synchronous; "_dev" entry points take device pointers, are enqueued
+ *   - "host" entry points take host pointers, stage through device scratch owned
+ *     by the context (hipMemcpyAsync in 128 Mbase chunks) and are synchronous;
+ *     "_dev" entry points take device pointers, are enqueued
  *     on the context's stream and return immediately -- data-dependent errors
  *     (InvalidBase) are latched on the device and reported by bitnuc_ctx_sync();
  *   - a bitnuc_ctx owns one device + stream + scratch and must not be used from
@@ -40,7 +41,7 @@ typedef enum bitnuc_status {
     BITNUC_SEQUENCE_TOO_LONG = 2,   /* SequenceTooLong(usize)  -> err.value */
     BITNUC_INVALID_LENGTH = 3,      /* InvalidLength(usize)    -> err.value */
     BITNUC_INDEX_OUT_OF_BOUNDS = 4, /* not produced by this path */
-    BITNUC_INVALID_RANGE = 5,       /* not produced by this path */
+    BITNUC_INVALID_RANGE = 5,       /* decreasing offsets in the ragged-batch entry points -> err.value = index */
     BITNUC_UNSUPPORTED = 6,         /* Unsupported (bad argument combination) */
     BITNUC_BACKEND_ERROR = 100      /* hipError_t in err.backend_code */
 } bitnuc_status;
