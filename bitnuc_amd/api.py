@@ -312,6 +312,15 @@ class Context:
             _raise(err)
         return out[: nw.value], wo
 
+    def encode_many(self, seqs):
+        """`[encode_alloc(s) for s in seqs]` in one launch: seqs is an iterable of bytes-like
+        sequences.  -> list of uint64 arrays (views into one buffer), one per sequence."""
+        seqs = [bytes(s) for s in seqs]
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        words, wo = self.encode_batch(b"".join(seqs), off)
+        return [words[int(wo[i]):int(wo[i + 1])] for i in range(len(seqs))]
+
     def decode_batch(self, words, word_offsets, offsets):
         """Inverse of encode_batch: -> ndarray[uint8] of offsets[-1] bytes, sequence i at
         [offsets[i], offsets[i+1]) (bytes before offsets[0] are zero)."""

@@ -32,6 +32,7 @@ base_counts_kernel(const unsigned long long *__restrict__ words, unsigned long l
     if ((reinterpret_cast<uintptr_t>(words) & 15) == 0) {
         const unsigned long long pairs = full >> 1;
         const u32x4 *w4 = reinterpret_cast<const u32x4 *>(words);
+#pragma unroll 4
         for (unsigned long long p = gt; p < pairs; p += nthreads) {
             const u32x4 v = __builtin_nontemporal_load(w4 + p);
             count_word(((unsigned long long)v.y << 32) | v.x, c, g, t);

@@ -99,11 +99,11 @@ int ensure_scratch(bitnuc_ctx *c, int which, size_t bytes, bitnuc_err *err) {
 // Drain: wait for the stream, find the first latched data error among the pending
 // launches (launch order), reset the slots.
 int drain(bitnuc_ctx *c, bitnuc_err *err) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->n_pending == 0) { clear_err(err); return BITNUC_OK; }
     const int n = c->n_pending;
-    HIPCHK(hipMemcpyAsync(c->h_slots, c->d_slots, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+    // the slot read-back is stream-ordered behind the launches it reports on: one wait covers both
+    if (n > 0) HIPCHK(hipMemcpyAsync(c->h_slots, c->d_slots, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (n == 0) { clear_err(err); return BITNUC_OK; }
     int hit = -1;
     for (int i = 0; i < n; ++i)
         if (c->h_slots[i] != kNoBad) { hit = i; break; }
@@ -128,6 +128,7 @@ int drain(bitnuc_ctx *c, bitnuc_err *err) {
 // return is their own; an InvalidBase latched by earlier asynchronous launches is kept for
 // the next bitnuc_ctx_sync().
 int flush_pending(bitnuc_ctx *c, bitnuc_err *err) {
+    if (c->n_pending == 0) return BITNUC_OK; // nothing asynchronous outstanding: stream order is enough
     bitnuc_err e;
     const int st = drain(c, &e);
     if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }

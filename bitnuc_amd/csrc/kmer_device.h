@@ -278,6 +278,7 @@ hdist_kernel(const unsigned long long *__restrict__ a, const unsigned long long 
     if (al) {
         const unsigned long long pairs = full >> 1;
         const u32x4 *a4 = reinterpret_cast<const u32x4 *>(a), *b4 = reinterpret_cast<const u32x4 *>(b);
+#pragma unroll 4
         for (unsigned long long p = gt; p < pairs; p += nthreads) {
             const u32x4 x = __builtin_nontemporal_load(a4 + p) ^ __builtin_nontemporal_load(b4 + p);
             acc += __builtin_popcount(mismatch_bits(x.x, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.y, 0x55555555u)) +

@@ -819,3 +819,33 @@ def test_rccl_comm_single_rank(oracle):
     assert torch.equal(out, allw)
     lib.bitnuc_comm_destroy(comms[0])
     lib.bitnuc_ctx_destroy(ctxs[0])
+
+
+def test_encode_many_and_fuzz(ctx, oracle):
+    """Seeded fuzz over lengths, alphabets, strides and batch shapes (every result vs the oracle)."""
+    rng = np.random.default_rng(20251004)
+    seqs = [bytes(rand_seq(int(n))) for n in rng.integers(1, 300, size=200)]
+    got = ctx.encode_many(seqs)
+    for s, w in zip(seqs, got):
+        assert np.array_equal(w, oracle.encode(s))
+    for _ in range(150):
+        n = int(rng.choice([rng.integers(1, 70), rng.integers(70, 5000), rng.integers(5000, 400000)]))
+        s = ALPHA8[rng.integers(0, 8, size=n)]
+        w = ctx.encode_array(s)
+        assert np.array_equal(w, oracle.encode(s)), n
+        m = int(rng.integers(1, n + 1))
+        assert np.array_equal(ctx.decode_array(w, m), oracle.decode(w, m)), (n, m)
+        k = int(rng.integers(1, 33))
+        if n >= k:
+            stride = int(rng.integers(1, 70))
+            count = (n - k) // stride + 1
+            assert np.array_equal(ctx.as_2bit_batch(s, k, stride, count), oracle.as_2bit_batch(s, k, stride, count)), (n, k, stride)
+            q = int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))
+            assert np.array_equal(ctx.kmer_hdist_scan(s, k, q), oracle.kmer_hdist_scan(s, k, q)), (n, k)
+        # ragged split of the same bytes into random pieces, incl. empty ones
+        cuts = np.sort(rng.integers(0, n + 1, size=int(rng.integers(0, 40))))
+        off = np.concatenate([[0], cuts, [n]]).astype(np.uint64)
+        bw, bwo = ctx.encode_batch(s, off)
+        ew, ewo = _oracle_batch(oracle, s, off)
+        assert np.array_equal(bw, ew) and np.array_equal(bwo, ewo), n
+        assert bytes(ctx.decode_batch(bw, bwo, off)) == bytes(s).upper()
