@@ -71,6 +71,11 @@ def cpu_baseline(n_sample, reps, all_cores):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): libraries that print banners from C (RCCL does
+    # at communicator init) are sent to stderr by pointing fd 1 there and keeping the real stdout aside
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -85,6 +90,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (k-mer batch) and config-5 (scan) side measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse the N>1 control flow")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise torch.distributed and run the collectives even at world size 1")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box)")
     ap.add_argument("--probe", action="store_true", help="also time pure read/copy/fill kernels (the box's own HBM ceiling)")
     args = ap.parse_args()
@@ -103,7 +109,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -142,7 +149,7 @@ def main():
             ev[2].record(stream)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +170,7 @@ def main():
     assert torch.equal(seqs[r_last], backs[r_last]), "decode(encode(x)) != x"
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if on_gpu_collectives else "cpu")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     sec_per_step = float(elapsed.item()) / args.steps
     enc_ms = [e[0].elapsed_time(e[1]) for e in events]
@@ -171,7 +178,7 @@ def main():
     enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
 
     extra = {}
-    if world > 1 and on_gpu_collectives:  # config 4's concatenation, reported beside the step, never inside it
+    if use_dist and on_gpu_collectives:  # config 4's concatenation, reported beside the step, never inside it
         try:
             from bitnuc_amd.dist import allgather_packed
             allgather_packed(words[0])
@@ -324,9 +331,10 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)[:300]}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
