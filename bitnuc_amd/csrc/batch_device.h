@@ -278,28 +278,26 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
             const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so);
             if (!active) continue;
             const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]);
-            const unsigned nfull = loc.nb >> 2, rem = loc.nb & 3;
-            // the word's bytes start at any byte offset: read the <= 9 ALIGNED LDS dwords that cover
-            // them and funnel-shift (misaligned ds_read_b32 works on gfx950 but runs ~2x slower)
-            const unsigned sh = off & 3, nd = (sh + loc.nb + 3) >> 2;
+            // The word's bytes start at any byte offset: read the 9 ALIGNED LDS dwords that cover 32
+            // bytes from there and funnel-shift (misaligned ds_read_b32 works on gfx950 but runs ~2x
+            // slower).  These kernels are VALU-issue bound (PMC), so there is no per-dword length
+            // logic: all 32 bytes are packed -- past the word's nb bases they are the next sequence's
+            // bytes or stage slack -- and the packed word is masked to 2*nb bits instead.  A residue
+            // from those extra bytes only sends the lane to rescan_bytes, which looks at its own nb.
+            const unsigned sh = off & 3;
             const uint32_t *src = reinterpret_cast<const uint32_t *>(my.stage + (off & ~3u));
-            uint32_t a[10];
+            uint32_t a[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) a[i] = (unsigned)i < nd ? src[i] : 0u;
-            a[9] = 0;
+            for (int i = 0; i < 9; ++i) a[i] = src[i];
             uint32_t bad = 0, wlo = 0, whi = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                uint32_t x = __builtin_amdgcn_alignbyte(a[i + 1], a[i], sh);
-                if ((unsigned)i == nfull) { // partial dword: bytes past the sequence end become 'A' (code 0, valid)
-                    const uint32_t keep = rem ? ((1u << (8 * rem)) - 1u) : 0u;
-                    x = (x & keep) | (0x41414141u & ~keep);
-                } else if ((unsigned)i > nfull) {
-                    x = 0x41414141u;
-                }
-                const uint32_t r = enc4(x, bad);
+                const uint32_t r = enc4(__builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), bad);
                 if (i < 4) wlo |= r << (8 * i); else whi |= r << (8 * (i - 4));
             }
+            const unsigned long long keep = loc.nb >= 32 ? ~0ull : ((1ull << (2 * loc.nb)) - 1);
+            wlo &= (uint32_t)keep;
+            whi &= (uint32_t)(keep >> 32);
             __builtin_nontemporal_store(((unsigned long long)whi << 32) | wlo, out + w);
             if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, loc.base, loc.nb, slot);
         }
