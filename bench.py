@@ -277,21 +277,26 @@ def main():
             backs.append(dist_out)  # reused by the probe below
         except Exception as e:  # noqa: BLE001 -- side measurements must never cost the headline line
             extra["extras_error"] = repr(e)[:300]
-    if args.probe:
-        probe = {}
-        for name, mode, nbytes in [("read", 0 | 8, n), ("copy", 1 | 8, n), ("fill", 2 | 8, n), ("read_plain", 0, n), ("copy_plain", 1, n)]:
-            ms = []
-            for i in range(10):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-                ctx.stream_probe_dev(mode, seqs[i % len(seqs)], backs[(i + 1) % len(backs)], min(nbytes, backs[(i + 1) % len(backs)].numel()))
-                b.record(stream)
-                torch.cuda.synchronize()
-                ms.append(a.elapsed_time(b))
-            moved = nbytes * (2 if (mode & 7) == 1 else 1)
-            probe[name] = round(moved / (statistics.median(ms) * 1e-3) / 1e9, 1)
-        extra["stream_probe_gb_s"] = probe
-
+    if args.probe or (world == 1 and not args.no_extras):
+        # the box's own streaming ceiling, same harness: best of a few cache-policy variants per shape
+        try:
+            def probe_rate(mode, moved):
+                ms = []
+                for i in range(8):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    ctx.stream_probe_dev(mode, seqs[i % len(seqs)], backs[(i + 1) % len(backs)], min(n, backs[(i + 1) % len(backs)].numel()))
+                    b.record(stream)
+                    torch.cuda.synchronize()
+                    ms.append(a.elapsed_time(b))
+                return round(moved / (statistics.median(ms[2:]) * 1e-3) / 1e9, 1)
+            nb = min(n, min(t.numel() for t in backs))
+            probe = {"read": max(probe_rate(m, nb) for m in (0 | 8, 0 | 8 | 32, 0)),
+                     "copy": max(probe_rate(m, 2 * nb) for m in (1 | 8 | 16, 1 | 8, 1 | 16, 1)),
+                     "fill": max(probe_rate(m, nb) for m in (2 | 16, 2))}
+            extra["stream_probe_gb_s"] = probe
+        except Exception as e:  # noqa: BLE001
+            extra["stream_probe_gb_s"] = {"error": repr(e)[:300]}
     if rank == 0:
         total_bases = world * 2 * n  # encoded + decoded, all ranks, per step
         enc_gbs = n * BYTES_PER_BASE / (enc_avg * 1e-3) / 1e9
@@ -326,6 +331,13 @@ def main():
                                 "gbases_s": round(n / (dec_avg * 1e-3) / 1e9, 1)},
         }
         line.update(extra)
+        pr = extra.get("stream_probe_gb_s", {})
+        if "read" in pr:  # report % of nominal AND % of the box's measured streaming peak
+            best = max(pr["read"], pr["copy"], pr["fill"])
+            line["roofline"]["measured_stream_peak"] = best
+            line["roofline"]["frac_of_measured"] = round(enc_gbs / best, 4)
+            line["roofline_decode"]["measured_stream_peak"] = best
+            line["roofline_decode"]["frac_of_measured"] = round(dec_gbs / best, 4)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)

@@ -531,31 +531,37 @@ int bitnuc_nucgen_dev(bitnuc_ctx *c, uint8_t *d_out, size_t len, uint64_t seed, 
 }
 
 int bitnuc_stream_probe_dev(bitnuc_ctx *c, int mode, const void *d_src, void *d_dst, size_t bytes, bitnuc_err *err) {
+    // mode: bits 0-2 = 0 read / 1 copy / 2 fill; bit 3 = nt loads; bit 4 = nt stores; bit 5 = 2 (not 4) groups per lane
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
     DeviceGuard g(c->device);
     const unsigned long long n16 = bytes / 16;
-    const unsigned grid = grid_for(c, n16 / (kBlock * 4) + 1);
-    const bool nt = (mode & 8) != 0;
+    const bool ntl = (mode & 8) != 0, nts = (mode & 16) != 0, u2 = (mode & 32) != 0;
+    const unsigned grid = grid_for(c, n16 / (kBlock * (u2 ? 2 : 4)) + 1);
+    const u32x4 *src = static_cast<const u32x4 *>(d_src);
+    u32x4 *dst = static_cast<u32x4 *>(d_dst);
+#define PROBE(K, ...) K<<<grid, kBlock, 0, c->stream>>>(__VA_ARGS__)
     switch (mode & 7) {
     case 0:
         if (!d_src || !aligned16(d_src)) return fail(err, BITNUC_UNSUPPORTED);
-        if (nt) probe_read_kernel<4, true><<<grid, kBlock, 0, c->stream>>>(static_cast<const u32x4 *>(d_src), n16, c->d_sink);
-        else probe_read_kernel<4, false><<<grid, kBlock, 0, c->stream>>>(static_cast<const u32x4 *>(d_src), n16, c->d_sink);
+        if (u2) { if (ntl) PROBE((probe_read_kernel<2, true>), src, n16, c->d_sink); else PROBE((probe_read_kernel<2, false>), src, n16, c->d_sink); }
+        else { if (ntl) PROBE((probe_read_kernel<4, true>), src, n16, c->d_sink); else PROBE((probe_read_kernel<4, false>), src, n16, c->d_sink); }
         break;
     case 1:
         if (!d_src || !d_dst || !aligned16(d_src) || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
-        if (nt) probe_copy_kernel<4, true><<<grid, kBlock, 0, c->stream>>>(static_cast<const u32x4 *>(d_src), static_cast<u32x4 *>(d_dst), n16);
-        else probe_copy_kernel<4, false><<<grid, kBlock, 0, c->stream>>>(static_cast<const u32x4 *>(d_src), static_cast<u32x4 *>(d_dst), n16);
+        if (ntl && nts) PROBE((probe_copy_kernel<4, true, true>), src, dst, n16);
+        else if (ntl) PROBE((probe_copy_kernel<4, true, false>), src, dst, n16);
+        else if (nts) PROBE((probe_copy_kernel<4, false, true>), src, dst, n16);
+        else PROBE((probe_copy_kernel<4, false, false>), src, dst, n16);
         break;
     case 2:
         if (!d_dst || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
-        if (nt) probe_fill_kernel<4, true><<<grid, kBlock, 0, c->stream>>>(static_cast<u32x4 *>(d_dst), n16);
-        else probe_fill_kernel<4, false><<<grid, kBlock, 0, c->stream>>>(static_cast<u32x4 *>(d_dst), n16);
+        if (nts) PROBE((probe_fill_kernel<4, true>), dst, n16); else PROBE((probe_fill_kernel<4, false>), dst, n16);
         break;
     default:
         return fail(err, BITNUC_UNSUPPORTED);
     }
+#undef PROBE
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }

@@ -357,7 +357,7 @@ probe_read_kernel(const u32x4 *__restrict__ src, unsigned long long n16, uint32_
     if (r == 0x9E3779B9u) sink[0] = r; // never true for real data; keeps the loads alive
 }
 
-template <int UNROLL, bool NT>
+template <int UNROLL, bool NT, bool NTST = NT>
 __global__ void __launch_bounds__(kBlock)
 probe_copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, unsigned long long n16) {
     constexpr unsigned long long TILE = (unsigned long long)kBlock * UNROLL;
@@ -372,7 +372,7 @@ probe_copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, unsign
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             u32x4 *q = dst + tile * TILE + u * kBlock + threadIdx.x;
-            if constexpr (NT) __builtin_nontemporal_store(v[u], q); else *q = v[u];
+            if constexpr (NTST) __builtin_nontemporal_store(v[u], q); else *q = v[u];
         }
     }
 }

@@ -195,8 +195,9 @@ int bitnuc_nucgen_dev(bitnuc_ctx *ctx, uint8_t *d_out, size_t len, uint64_t seed
  * previous value or -1 for an unknown key. */
 int bitnuc_ctx_set_variant(bitnuc_ctx *ctx, const char *key, int value);
 /* Pure streaming kernels used to measure the box's HBM ceiling next to the codec:
- * mode 0 = read-only sum of `bytes` from d_src; mode 1 = copy d_src -> d_dst;
- * mode 2 = write-only fill of d_dst. */
+ * mode bits 0-2: 0 = read-only sum of `bytes` from d_src; 1 = copy d_src -> d_dst;
+ * 2 = write-only fill of d_dst.  bit 3: nt loads, bit 4: nt stores, bit 5: 2 (not 4)
+ * 16-byte groups in flight per lane. */
 int bitnuc_stream_probe_dev(bitnuc_ctx *ctx, int mode, const void *d_src, void *d_dst, size_t bytes, bitnuc_err *err);
 
 #ifdef __cplusplus
