@@ -48,12 +48,34 @@ struct TileRec { unsigned long long owner, base0; };
 
 __global__ void __launch_bounds__(kBlock)
 block_owner_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets,
-                   unsigned long long count, unsigned long long ntiles, TileRec *__restrict__ recs) {
+                   unsigned long long count, unsigned long long total_words, unsigned long long ntiles,
+                   TileRec *__restrict__ recs) {
     const unsigned long long b = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    if (b < ntiles) {
-        const unsigned long long wb = b * kBatchTile, s = owner_of_word(word_offsets, count, wb);
-        recs[b] = TileRec{s, offsets[s] + ((wb - word_offsets[s]) << 5)};
+    if (b >= ntiles) return;
+    const unsigned long long wb = b * kBatchTile;
+    // owner = upper_bound(word_offsets[0..count], wb) - 1.  Interpolate first (exact for
+    // equal-length reads), gallop outwards to bracket, then bisect the bracket: a handful of
+    // dependent loads instead of log2(count).
+    unsigned long long lo, hi; // invariant: word_offsets[lo] <= wb < word_offsets[hi]
+    {
+        const unsigned long long est = (unsigned long long)(((unsigned __int128)wb * count) / total_words);
+        unsigned long long p = est < count ? est : count - 1, step = 1;
+        if (word_offsets[p] <= wb) {
+            lo = p;
+            hi = p + 1;
+            while (hi < count && word_offsets[hi] <= wb) { lo = hi; hi = hi + step < count ? hi + step : count; step <<= 1; }
+            // word_offsets[count] = total_words > wb closes the bracket
+        } else {
+            hi = p;
+            lo = p > 0 ? p - 1 : 0;
+            while (lo > 0 && word_offsets[lo] > wb) { hi = lo; lo = lo > step ? lo - step : 0; step <<= 1; }
+        }
     }
+    while (hi - lo > 1) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if (word_offsets[mid] <= wb) lo = mid; else hi = mid;
+    }
+    recs[b] = TileRec{lo, offsets[lo] + ((wb - word_offsets[lo]) << 5)};
 }
 
 // Resolve this lane's word from the wave's LDS window (already holding `filled` = 64 entries

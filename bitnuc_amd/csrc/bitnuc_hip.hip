@@ -720,7 +720,7 @@ static int batch_owners(bitnuc_ctx *c, const uint64_t *d_offsets, const uint64_t
     if (int st = ensure_scratch(c, 3, ntiles * sizeof(TileRec), err)) return st;
     TileRec *o = reinterpret_cast<TileRec *>(c->scratch[3]);
     block_owner_kernel<<<(unsigned)((ntiles + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(
-        reinterpret_cast<const unsigned long long *>(d_offsets), reinterpret_cast<const unsigned long long *>(d_word_offsets), count, ntiles, o);
+        reinterpret_cast<const unsigned long long *>(d_offsets), reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, ntiles, o);
     HIPCHK(hipGetLastError());
     *recs = o;
     return BITNUC_OK;
