@@ -404,18 +404,25 @@ decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned
             // write the lane's nb bytes at byte offset `off`: <= 3 head bytes up to the next
             // 4-byte boundary, then ALIGNED dwords re-cut from d[] with v_alignbyte, then <= 3
             // tail bytes (misaligned ds_write_b32 works on gfx950 but runs ~2x slower)
-            const unsigned head = (4u - (off & 3u)) & 3u;          // bytes before the first aligned dword
+            // Branch-free placement (these kernels are VALU/SALU-issue bound): <= 3 predicated byte
+            // stores for the head, 8 predicated aligned dword stores, <= 3 predicated byte stores
+            // for the tail, whose bytes are re-decoded straight from the packed word.
+            const unsigned head = (4u - (off & 3u)) & 3u; // bytes before the first aligned dword
             const unsigned hb = head < loc.nb ? head : loc.nb;
-            for (unsigned j = 0; j < hb; ++j) stage[off + j] = (uint8_t)(d[0] >> (8 * j));
             const unsigned body = loc.nb - hb, ndw = body >> 2, tb = body & 3;
+            if (hb > 0) stage[off] = (uint8_t)d[0];
+            if (hb > 1) stage[off + 1] = (uint8_t)(d[0] >> 8);
+            if (hb > 2) stage[off + 2] = (uint8_t)(d[0] >> 16);
             uint32_t *dst = reinterpret_cast<uint32_t *>(stage + off + hb);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const uint32_t v = __builtin_amdgcn_alignbyte(d[m + 1], d[m], head); // lane bytes [head+4m, head+4m+4)
-                if ((unsigned)m < ndw) dst[m] = v;
-                else if ((unsigned)m == ndw)
-                    for (unsigned j = 0; j < tb; ++j) stage[off + hb + 4 * m + j] = (uint8_t)(v >> (8 * j));
-            }
+            for (int m = 0; m < 8; ++m)
+                if ((unsigned)m < ndw) dst[m] = __builtin_amdgcn_alignbyte(d[m + 1], d[m], head); // lane bytes [head+4m, head+4m+4)
+            const unsigned q = hb + 4 * ndw;                               // first tail base
+            const uint32_t tv = dec4((uint32_t)(word >> (2 * q)) & 0xFFu); // bases q..q+3 as ASCII
+            uint8_t *tp = stage + off + q;
+            if (tb > 0) tp[0] = (uint8_t)tv;
+            if (tb > 1) tp[1] = (uint8_t)(tv >> 8);
+            if (tb > 2) tp[2] = (uint8_t)(tv >> 16);
         }
         __syncthreads();
         // coalesced write-out; the first/last 16-byte chunk may be shared with a neighbouring
