@@ -32,7 +32,6 @@ def cpu_baseline(n_sample, reps, all_cores):
     """Reference-algorithm restatement (oracle/bitnuc_avx2.c, the reference's AVX2 path as
     written) timed on this host.  kind = "port": the Rust reference cannot be built here."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_py
     seq = oracle_py.nucgen(n_sample, SEED)
     enc, dec = [], []

@@ -203,6 +203,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
     X(34, 4, 256, false, true, false, true)           \
     X(35, 4, 128, true, true, false, false)
 constexpr int kNumVariants = 36;
+constexpr int kBallotVariant = 100; // encode only: lane-per-base + ballot (selectable with set_variant("encode", 100))
 // defaults from the sustained (back-to-back) pair sweep in profiles/ (10^9 bases, one tile
 // per workgroup; the pair matters because decode's 1 GB of stores sits dirty in the
 // 256 MiB Infinity Cache when the next encode starts):
@@ -230,6 +231,11 @@ hipError_t launch_encode_t(bitnuc_ctx *c, const uint8_t *seq, uint32_t *out32, u
 hipError_t launch_encode(bitnuc_ctx *c, const uint8_t *seq, uint64_t *out, unsigned long long len, unsigned long long *slot) {
     uint32_t *o = reinterpret_cast<uint32_t *>(out);
     const bool in_al = aligned16(seq), out_al = aligned16(out);
+    if (c->enc_variant == kBallotVariant) { // lane-per-base + ballot formulation (evidence variant)
+        const unsigned grid = grid_for(c, ((len + 63) / 64 + (kBlock / 64) * 4 - 1) / ((kBlock / 64) * 4));
+        encode_ballot_kernel<4><<<grid, kBlock, 0, c->stream>>>(seq, reinterpret_cast<unsigned long long *>(out), len, slot);
+        return hipGetLastError();
+    }
     int v = c->enc_variant;
     // the LDS-transpose variant needs 16-byte aligned buffers on both sides
     if (kVariants[v].xpose && !(in_al && out_al)) v = kDefaultEnc;
@@ -430,7 +436,7 @@ int bitnuc_ctx_sync(bitnuc_ctx *c, bitnuc_err *err) {
 int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     if (!c || !key) return -1;
     int prev = -1;
-    if (!strcmp(key, "encode")) { prev = c->enc_variant; if (value >= 0 && value < kNumVariants) c->enc_variant = value; }
+    if (!strcmp(key, "encode")) { prev = c->enc_variant; if ((value >= 0 && value < kNumVariants) || value == kBallotVariant) c->enc_variant = value; }
     else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0 && value < kNumVariants) c->dec_variant = value; }
     else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }

@@ -849,3 +849,21 @@ def test_encode_many_and_fuzz(ctx, oracle):
         ew, ewo = _oracle_batch(oracle, s, off)
         assert np.array_equal(bw, ew) and np.array_equal(bwo, ewo), n
         assert bytes(ctx.decode_batch(bw, bwo, off)) == bytes(s).upper()
+
+
+def test_ballot_formulation_variant(ctx, oracle):
+    """north_star's lane-per-base + wavefront-ballot encode (variant 100): same bits, same errors."""
+    import bitnuc_amd as bn
+    prev = ctx.set_variant("encode", 100)
+    try:
+        for n in [1, 31, 32, 33, 63, 64, 65, 127, 128, 1000, 4097, 1000003]:
+            s = rand_seq(n)
+            assert np.array_equal(ctx.encode_array(s), oracle.encode(s)), n
+        s = rand_seq(100000).copy()
+        s[54321] = ord("N")
+        s[70000] = ord("X")
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.encode_array(s)
+        assert (ei.value.byte, ei.value.index) == (ord("N"), 54321)
+    finally:
+        ctx.set_variant("encode", prev)
