@@ -44,7 +44,7 @@ struct WordLoc {
 // per wave tile, so the ~log2(count) dependent loads of the search are paid once, in
 // parallel, instead of by every wave -- and the main kernels can start fetching a tile's
 // bytes straight after reading its 16-byte record.
-struct TileRec { unsigned long long owner, base0; };
+struct TileRec { unsigned long long owner, base0, avail; }; // avail = bases left in the owner sequence from base0
 
 __global__ void __launch_bounds__(kBlock)
 block_owner_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets,
@@ -75,7 +75,8 @@ block_owner_kernel(const unsigned long long *__restrict__ offsets, const unsigne
         const unsigned long long mid = (lo + hi) >> 1;
         if (word_offsets[mid] <= wb) lo = mid; else hi = mid;
     }
-    recs[b] = TileRec{lo, offsets[lo] + ((wb - word_offsets[lo]) << 5)};
+    const unsigned long long base0 = offsets[lo] + ((wb - word_offsets[lo]) << 5);
+    recs[b] = TileRec{lo, base0, offsets[lo + 1] - base0};
 }
 
 // Resolve this lane's word from the wave's LDS window (already holding `filled` = 64 entries
@@ -288,6 +289,23 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
             BatchLds &my = lds[wave][u];
             const unsigned long long wb = (t0 + u) * kBatchTile, w = wb + lane;
             const bool active = w < total_words;
+            if (rec[u].avail >= kBatchTile * 32) {
+                // fast tile (wave-uniform): all 64 words are full and inside one sequence, so the
+                // tile is a plain 2 KiB bulk encode: the bytes already sit in st[u][0..1] as 128
+                // coalesced 16-base groups (group g = chunk g when base0 is 16-byte aligned)
+                if (((reinterpret_cast<uintptr_t>(seq) + rec[u].base0) & 15) == 0) {
+                    uint32_t bad = 0;
+                    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + wb);
+                    const uint32_t c0 = enc16(st[u][0], bad), c1 = enc16(st[u][1], bad);
+                    __builtin_nontemporal_store(c0, o32 + lane);
+                    __builtin_nontemporal_store(c1, o32 + 64 + lane);
+                    if (__builtin_expect(residue_is_bad(bad), 0)) {
+                        rescan_bytes(seq, rec[u].base0 + 16 * lane, 16, slot);
+                        rescan_bytes(seq, rec[u].base0 + 16 * (lane + 64), 16, slot);
+                    }
+                    continue;
+                }
+            }
             wave_lds_fence(); // previous trip's LDS readers are done
             my.win_wo[lane] = wo_r[u];
             my.win_so[lane] = so_r[u];
@@ -389,9 +407,25 @@ decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned
          wb += (unsigned long long)gridDim.x * kBatchDecBlock) {
         const unsigned long long w = wb + t;
         const bool active = w < total_words;
-        const unsigned long long word = active ? __builtin_nontemporal_load(words + w) : 0ull;
+        const unsigned long long word = active ? __builtin_nontemporal_load(words + w) : 0ull; // independent of the lookup: issued first
+        const TileRec rec = recs[wb / kBatchTile]; // block-uniform
+        if (rec.avail >= kBatchDecBlock * 32 && ((reinterpret_cast<uintptr_t>(out) + rec.base0) & 15) == 0) {
+            // fast tile (block-uniform): 128 full words inside one sequence = a plain 4 KiB bulk
+            // decode.  The words cross LDS once so that thread t owns 16-base groups t and t+128:
+            // every dwordx4 store of a wave is then one contiguous 1 KiB span.
+            unsigned long long *xw = reinterpret_cast<unsigned long long *>(stage);
+            __syncthreads(); // previous trip's LDS readers are done
+            xw[t] = word;
+            __syncthreads();
+            const uint32_t *x32 = reinterpret_cast<const uint32_t *>(stage);
+            const uint32_t h0 = x32[t], h1 = x32[kBatchDecBlock + t];
+            uint8_t *dst = out + rec.base0;
+            store_group<true, true>(dst + 16 * t, dec16(h0));
+            store_group<true, true>(dst + 16 * (t + kBatchDecBlock), dec16(h1));
+            continue;
+        }
         __syncthreads();
-        const WordLoc loc = locate_word_block(offsets, word_offsets, count, recs[wb / kBatchTile].owner, wb, w, active, win_wo, win_so);
+        const WordLoc loc = locate_word_block(offsets, word_offsets, count, rec.owner, wb, w, active, win_wo, win_so);
         if (t == 0) span[0] = loc.base;
         if (active && (w + 1 == total_words || t == kBatchDecBlock - 1)) span[1] = loc.base + loc.nb;
         __syncthreads();
