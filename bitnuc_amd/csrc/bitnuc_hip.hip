@@ -44,7 +44,7 @@ struct bitnuc_ctx {
     uint8_t *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[6] = {0, 0, 0, 0, 0, 0};
     uint32_t *d_sink = nullptr;
-    int enc_variant = 3, dec_variant = 1; // kDefaultEnc / kDefaultDec
+    int enc_variant = 14, dec_variant = 42; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
@@ -201,15 +201,26 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
     X(32, 8, 256, true, true, false, false)           \
     X(33, 4, 512, true, true, false, false)           \
     X(34, 4, 256, false, true, false, true)           \
-    X(35, 4, 128, true, true, false, false)
-constexpr int kNumVariants = 36;
+    X(35, 4, 128, true, true, false, false)           \
+    X(36, 2, 64, true, false, false, false)           \
+    X(37, 4, 128, true, false, false, false)          \
+    X(38, 1, 128, true, false, false, false)          \
+    X(39, 2, 128, true, true, false, true)            \
+    X(40, 4, 128, true, true, false, true)            \
+    X(41, 2, 512, true, true, false, true)            \
+    X(42, 1, 256, true, true, false, true)            \
+    X(43, 2, 128, true, false, false, true)           \
+    X(44, 1, 128, true, true, false, true)            \
+    X(45, 1, 512, true, true, false, true)            \
+    X(46, 1, 1024, true, true, false, true)
+constexpr int kNumVariants = 47;
 constexpr int kBallotVariant = 100; // encode only: lane-per-base + ballot (selectable with set_variant("encode", 100))
-// defaults from the sustained (back-to-back) pair sweep in profiles/ (10^9 bases, one tile
-// per workgroup; the pair matters because decode's 1 GB of stores sits dirty in the
-// 256 MiB Infinity Cache when the next encode starts):
-//   encode: nt loads + plain stores, 2 groups in flight per lane -> 6.80 TB/s algorithmic
-//   decode: nt loads + nt stores, 4 groups per lane              -> 6.79 TB/s algorithmic
-constexpr int kDefaultEnc = 3, kDefaultDec = 1;
+// defaults from the sustained (back-to-back) pair sweeps in profiles/ (10^9 bases, one tile per
+// workgroup; the pair matters because decode's 1 GB of stores sits dirty in the 256 MiB
+// Infinity Cache when the next encode starts; 21 interleaved rounds in one process):
+//   encode 14: nt loads + plain stores, 2 groups in flight per lane, 128-thread workgroups -> 6.86 TB/s
+//   decode 42: nt loads + nt stores, 1 group per lane, XCD-contiguous tile order           -> 6.99 TB/s
+constexpr int kDefaultEnc = 14, kDefaultDec = 42;
 
 struct VariantInfo { int unroll, block; bool ntld, ntst, xpose, xcd; };
 constexpr VariantInfo kVariants[kNumVariants] = {

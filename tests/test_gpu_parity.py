@@ -111,9 +111,9 @@ def test_kmer_count_doc_example(ctx, golden):
 SIZES = [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, 4095, 4096, 4097, 16384 * 4 + 5, 1000003, (1 << 22) + 17]
 
 
-@pytest.mark.parametrize("variant", range(36))
+@pytest.mark.parametrize("variant", range(47))
 def test_encode_decode_variants_vs_oracle(ctx, oracle, variant):
-    assert ctx.get("num_variants") == 36
+    assert ctx.get("num_variants") == 47
     enc0 = ctx.set_variant("encode", variant)
     dec0 = ctx.set_variant("decode", variant)
     try:
