@@ -314,6 +314,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the same measurement, three readings (value is the first): bases through the codec per
+            # second (encoded + decoded), and the per-kernel rates from the HIP events of rank 0
+            "codec_gbases_s": round(total_bases / sec_per_step / 1e9, 2),
+            "roundtrip_gbases_s": round(world * n / sec_per_step / 1e9, 2),
+            "encode_gbases_s": round(world * n / (enc_avg * 1e-3) / 1e9, 1),
+            "decode_gbases_s": round(world * n / (dec_avg * 1e-3) / 1e9, 1),
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident, bit-exact vs CPU oracle",
                        "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
