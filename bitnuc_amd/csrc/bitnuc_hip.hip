@@ -48,6 +48,7 @@ struct bitnuc_ctx {
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
+    int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
 };
@@ -289,9 +290,9 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
     if (stride == k && count >= 64 && c->batch_dense) {
         // dense layout: whole waves of 64 k-mers go through the bulk-encode-shaped kernel
         const unsigned long long items = count / 64;
-        const int un = c->dense_unroll;
-        const unsigned grid = grid_for(c, (items + (kBlock / 64) * un - 1) / ((kBlock / 64) * un));
-#define DENSE_LAUNCH(AL, NL, NS, U) kmer_dense_kernel<AL, NL, NS, U><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot)
+        const int un = c->dense_unroll, kb = c->kmer_block;
+        const unsigned grid = grid_for(c, (items + (kb / 64) * un - 1) / ((kb / 64) * un), kb);
+#define DENSE_LAUNCH(AL, NL, NS, U) kmer_dense_kernel<AL, NL, NS, U><<<grid, kb, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot)
 #define DENSE_POLICY(U)                                              \
     switch (c->dense_policy) { /* bit0: nt loads, bit1: nt stores */ \
     case 0: DENSE_LAUNCH(true, false, false, U); break;              \
@@ -329,10 +330,10 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
         ql |= (uint32_t)((query >> (2 * i)) & 1) << i;
         qh |= (uint32_t)((query >> (2 * i + 1)) & 1) << i;
     }
-    const int unroll = c->scan_unroll;
-    const unsigned grid = grid_for(c, rounds / ((kBlock / 64) * unroll) + 1);
+    const int unroll = c->scan_unroll, kb = c->kmer_block;
+    const unsigned grid = grid_for(c, rounds / ((kb / 64) * unroll) + 1, kb);
 #define SCAN_LAUNCH(AL, NL, NS, U) \
-    kmer_scan_kernel<AL, NL, NS, U><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot)
+    kmer_scan_kernel<AL, NL, NS, U><<<grid, kb, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot)
 #define SCAN_POLICY(U)                                             \
     switch (c->scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
     case 0: SCAN_LAUNCH(true, false, false, U); break;             \
@@ -453,6 +454,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
     else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
     else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
+    else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
     else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
     else if (!strcmp(key, "num_variants")) { prev = kNumVariants; }

@@ -110,8 +110,8 @@ kmer_dense_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
                   unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     __shared__ uint32_t strips[kBlock / 64][UNROLL][132];
     const unsigned lane = threadIdx.x & 63;
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const unsigned long long nwaves = ((unsigned long long)gridDim.x * kBlock) >> 6;
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; // blockDim <= kBlock
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
     const unsigned ngroups = 4 * k; // 16-byte groups per 64 k-mers
     const unsigned bit = 2 * k * lane, d = bit >> 5, sh = bit & 31;
     const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -190,8 +190,8 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
     const unsigned long long nwin = n - k + 1; // host guarantees 1 <= k <= 32, n >= k
     const unsigned long long rounds = n >= 1024 ? (n - 1024) / kScanWaveWindows + 1 : 0;
     const unsigned lane = threadIdx.x & 63;
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const unsigned long long nwaves = ((unsigned long long)gridDim.x * kBlock) >> 6;
+    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; // blockDim <= kBlock
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
     // ql / qh: the query's bit-planes (bit i = low / high code bit of base i), split on the host
     const uint32_t km = k == 32 ? ~0u : ((1u << k) - 1u);
 
@@ -244,8 +244,8 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
 
     // tail: one window per thread, byte loads
     const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    const unsigned long long gt = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    const unsigned long long nthreads = (unsigned long long)gridDim.x * kBlock;
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long i = rounds * kScanWaveWindows + gt; i < nwin; i += nthreads) {
         unsigned long long w = 0;
         bool flagged = false;

@@ -35,17 +35,18 @@ def burst(fn, reps=8):
 
 
 rows = []
-for rnd in range(3):
-    for g in (0, 8):
-        ctx.set_variant("grid_mult", g)
-        for pol in range(4):
+for rnd in range(5):
+    for g in (64, 128, 256):  # threads per workgroup (grid: one item per wave)
+        ctx.set_variant("grid_mult", 0)
+        ctx.set_variant("kmer_block", g)
+        for pol in (3,):
             ctx.set_variant("scan_policy", pol)
-            for un in (1, 2, 4):
+            for un in (2, 4):
                 ctx.set_variant("scan_unroll", un)
                 ms = burst(lambda i: ctx.kmer_hdist_scan_dev(ref[i % 2], n, k, 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1), dist[i % 2]))
                 rows.append(("scan", g, pol * 10 + un, ms))
             ctx.set_variant("dense_policy", pol)
-            for un in (1, 2, 4):
+            for un in (1, 2):
                 ctx.set_variant("dense_unroll", un)
                 ms = burst(lambda i: ctx.as_2bit_batch_dev(kseq, k, k, count, kout[i % 2]))
                 rows.append(("dense", g, pol * 10 + un, ms))
@@ -54,7 +55,7 @@ agg = {}
 for kind, g, pol, ms in rows:
     agg.setdefault((kind, g, pol), []).append(ms)
 for kind, nbytes in (("scan", 2 * (n - k + 1)), ("dense", count * (k + 8))):
-    print(f"== {kind}: ms  GB/s  grid_mult policy(bit0 nt-load, bit1 nt-store; scan: policy*10+unroll)")
+    print(f"== {kind}: ms  GB/s  threads/workgroup policy*10+unroll")
     for (kd, g, pol), v in sorted(((kk, vv) for kk, vv in agg.items() if kk[0] == kind), key=lambda kv: statistics.median(kv[1])):
         ms = statistics.median(v)
         print(f"{ms:.4f} {nbytes/ms/1e6:7.0f}  g{g:<2d} p{pol}")
