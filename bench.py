@@ -271,6 +271,14 @@ def main():
                                     "encode_gbases_s": round(rb / (ms_e * 1e-3) / 1e9, 1), "decode_gbases_s": round(rb / (ms_d * 1e-3) / 1e9, 1),
                                     "encode_gb_s": round(alg / (ms_e * 1e-3) / 1e9, 1), "decode_gb_s": round(alg / (ms_d * 1e-3) / 1e9, 1),
                                     "algorithmic_bytes_per_launch": alg}
+            ms_fe = timed(lambda: ctx.encode_fixed_dev(seqs[0], L, L, rcount, rwords))
+            ms_fd = timed(lambda: ctx.decode_fixed_dev(rwords, L, L, rcount, backs[0]))
+            extra["reads_fixed"] = {"workload": f"{rcount} fixed-length 150-base reads, encode_fixed / decode_fixed (no offsets tables)",
+                                    "encode_ms": round(ms_fe, 4), "decode_ms": round(ms_fd, 4),
+                                    "encode_gbases_s": round(rb / (ms_fe * 1e-3) / 1e9, 1), "decode_gbases_s": round(rb / (ms_fd * 1e-3) / 1e9, 1),
+                                    "encode_gb_s": round(alg / (ms_fe * 1e-3) / 1e9, 1), "decode_gb_s": round(alg / (ms_fd * 1e-3) / 1e9, 1),
+                                    "encode_frac": round(alg / (ms_fe * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "decode_frac": round(alg / (ms_fd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "algorithmic_bytes_per_launch": alg}
             del rwords, roff, rwo
             ctx.sync()
             backs.append(dist_out)  # reused by the probe below

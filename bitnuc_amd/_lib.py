@@ -52,6 +52,10 @@ SIGNATURES = {
     "bitnuc_decode_batch_dev": (C.c_int, [_P, _P, _P, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_encode_batch": (C.c_int, [_P, _P, _P, _SZ, _P, _SZ, _P, C.POINTER(_SZ), _ERR]),
     "bitnuc_decode_batch": (C.c_int, [_P, _P, _P, _P, _SZ, _P, _ERR]),
+    "bitnuc_encode_fixed_dev": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_decode_fixed_dev": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_encode_fixed": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_decode_fixed": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
     "bitnuc_base_counts": (C.c_int, [_P, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_base_counts_dev": (C.c_int, [_P, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_hdist_pairs_dev": (C.c_int, [_P, _P, _P, _SZ, _SZ, _P, _ERR]),

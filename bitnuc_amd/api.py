@@ -312,6 +312,41 @@ class Context:
             _raise(err)
         return out[: nw.value], wo
 
+    def encode_fixed(self, seq, read_len, stride=None, count=None):
+        """Encode `count` reads of `read_len` bases, read r at seq[r*stride:]. -> ndarray[uint64] of
+        shape (count, ceil(read_len/32)): row r == encode(read r)."""
+        s = _as_u8(seq)
+        stride = read_len if stride is None else stride
+        if count is None:
+            count = 0 if s.size < read_len else (s.size - read_len) // stride + 1
+        wpr = (read_len + 31) // 32
+        out = np.empty((count, wpr), dtype=np.uint64)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_encode_fixed(self._h, _ptr(s), int(read_len), int(stride), int(count), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out
+
+    def decode_fixed(self, words, read_len, stride=None, out=None):
+        """Inverse of encode_fixed: -> ndarray[uint8]; read r at [r*stride, r*stride+read_len).
+        With stride > read_len pass `out` to keep its separator bytes."""
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        wpr = (read_len + 31) // 32
+        count = w.size // wpr if wpr else 0
+        stride = read_len if stride is None else stride
+        nbytes = (count - 1) * stride + read_len if count else 0
+        if out is None:
+            out = np.zeros(nbytes, dtype=np.uint8)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_decode_fixed(self._h, _ptr(w), int(read_len), int(stride), int(count), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+        return out
+
+    def encode_fixed_dev(self, d_seq, read_len, stride, count, d_out):
+        self._call_dev(self._lib.bitnuc_encode_fixed_dev, _dev_ptr(d_seq), int(read_len), int(stride), int(count), _dev_ptr(d_out))
+
+    def decode_fixed_dev(self, d_words, read_len, stride, count, d_out):
+        self._call_dev(self._lib.bitnuc_decode_fixed_dev, _dev_ptr(d_words), int(read_len), int(stride), int(count), _dev_ptr(d_out))
+
     def encode_many(self, seqs):
         """`[encode_alloc(s) for s in seqs]` in one launch: seqs is an iterable of bytes-like
         sequences.  -> list of uint64 arrays (views into one buffer), one per sequence."""

@@ -21,7 +21,7 @@ namespace bitnuc_dev {
 constexpr int kBatchTile = 64;                      // words per WAVE: every wave works alone on its own tile, so the
                                                     // kernels have no workgroup barrier at all
 constexpr int kBatchWin = 128;                      // offsets window per wave (>= kBatchTile + 1, + slack for empty sequences)
-constexpr int kBatchStage = kBatchTile * 32 + 64;   // 2 KiB span + alignment slack, per wave
+constexpr int kBatchStage = kBatchTile * 32 + 128;  // 2 KiB span + alignment / read-ahead slack, per wave
 constexpr int kBatchWaves = kBlock / 64;            // waves (= tiles in flight) per workgroup
 
 // index of the sequence that owns word w: upper_bound(word_offsets[0..count], w) - 1
@@ -33,6 +33,36 @@ __device__ __forceinline__ unsigned long long owner_of_word(const unsigned long 
         if (wo[mid] <= w) lo = mid + 1; else hi = mid;
     }
     return lo - 1;
+}
+
+// Write-out of one 16-byte stage chunk to global address g, restricted to [lo, hi): whole
+// chunks are one dwordx4 store; a chunk cut by the span's edge (its other bytes belong to the
+// neighbouring tile) is written as <= 3 bytes, <= 3 aligned dwords, <= 3 bytes -- predicated
+// stores, no loop (the edge lanes would otherwise hold their whole wave for a 16-trip loop).
+__device__ __forceinline__ void store_stage_chunk(const uint8_t *chunk, uintptr_t g, uintptr_t lo, uintptr_t hi) {
+    if (g >= lo && g + 16 <= hi) {
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(chunk), reinterpret_cast<u32x4 *>(g));
+        return;
+    }
+    const uintptr_t s = g > lo ? g : lo, e = g + 16 < hi ? g + 16 : hi; // [s, e) non-empty, < 16 bytes
+    const unsigned o = (unsigned)(s - g), n = (unsigned)(e - s);
+    const unsigned head = (4u - (o & 3u)) & 3u, hb = head < n ? head : n;
+    uint8_t *dst = reinterpret_cast<uint8_t *>(s);
+    const uint8_t *src = chunk + o;
+    if (hb > 0) dst[0] = src[0];
+    if (hb > 1) dst[1] = src[1];
+    if (hb > 2) dst[2] = src[2];
+    const unsigned body = n - hb, ndw = body >> 2, tb = body & 3;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src + hb); // 4-byte aligned in LDS and in global
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + hb);
+    if (ndw > 0) d32[0] = s32[0];
+    if (ndw > 1) d32[1] = s32[1];
+    if (ndw > 2) d32[2] = s32[2];
+    const uint8_t *ts = src + hb + 4 * ndw;
+    uint8_t *td = dst + hb + 4 * ndw;
+    if (tb > 0) td[0] = ts[0];
+    if (tb > 1) td[1] = ts[1];
+    if (tb > 2) td[2] = ts[2];
 }
 
 struct WordLoc {
@@ -344,6 +374,154 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
     }
 }
 
+// ---------------------------------------------------------------------------------
+// fixed-length reads: `count` reads of `read_len` bases, read r at byte r*stride
+// ---------------------------------------------------------------------------------
+// The common sequencing layout (every read the same length, back to back or with a separator).
+// Word w belongs to read w / wpr (wpr = ceil(read_len/32)): the lookup is one integer division,
+// no offsets tables, no pre-kernel.  Same wave-private tile as encode_batch_kernel: 64 words
+// per wave, the tile's byte span staged through LDS with coalesced 16-byte loads when it fits
+// (stride - read_len small), per-lane aligned-dword loads from global memory otherwise.
+// GAPS (stride > read_len): the bytes after a read's last base are separators, so the validity
+// residue of each dword is masked to the bytes that belong to the read.
+template <bool GAPS>
+__global__ void __launch_bounds__(kBlock)
+encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned long long stride, unsigned wpr,
+                    unsigned long long total_words, unsigned long long seq_end /* bytes in the buffer */,
+                    unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
+    __shared__ BatchLds lds[kBatchWaves];
+    BatchLds &my = lds[threadIdx.x >> 6];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + (threadIdx.x >> 6); tile < ntiles;
+         tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        const unsigned long long wb = tile * kBatchTile, w = wb + lane;
+        const bool active = w < total_words;
+        const unsigned long long wc = active ? w : total_words - 1; // clamp: inactive lanes mirror the last word
+        const unsigned long long r = wc / wpr;
+        const unsigned j = (unsigned)(wc - r * wpr);
+        const unsigned long long base = r * stride + 32ull * j;
+        const unsigned left = read_len - 32 * j, nb = left < 32 ? left : 32u;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        // stage 32 bytes past the last word too (clipped to the buffer): the unconditional 32-byte
+        // pack of a partial last word then sees the next read's real bytes, not stale LDS
+        unsigned long long span_hi = __shfl(base + nb, last) + 32;
+        if (span_hi > seq_end) span_hi = seq_end;
+        const unsigned long long span_lo = __shfl(base, 0);
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(seq) + span_lo, hi = reinterpret_cast<uintptr_t>(seq) + span_hi;
+        const uintptr_t lo16 = lo & ~(uintptr_t)15;
+        const bool staged = hi - lo16 <= (uintptr_t)(kBatchStage - 16); // wave-uniform
+        uint32_t a[9];
+        unsigned sh;
+        if (staged) {
+            const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
+            wave_lds_fence(); // previous trip's LDS readers are done
+            for (unsigned c = lane; c < nchunk; c += 64)
+                *reinterpret_cast<u32x4 *>(my.stage + 16 * c) = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)c));
+            wave_lds_fence();
+            const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + base - lo16);
+            sh = off & 3;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(my.stage + (off & ~3u));
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[i] = src[i];
+        } else { // wide separators: the aligned dwords that hold this word's bytes, straight from global memory
+            const uintptr_t p = reinterpret_cast<uintptr_t>(seq) + base;
+            sh = (unsigned)(p & 3);
+            const unsigned nd = (sh + nb + 3) >> 2;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(p & ~(uintptr_t)3);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[i] = (unsigned)i < nd ? src[i] : 0x41414141u;
+        }
+        if (!active) continue;
+        uint32_t bad = 0, wlo = 0, whi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t b = 0;
+            const uint32_t c = enc4(__builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), b);
+            if constexpr (GAPS) { // only this read's bytes may raise the residue
+                const int remain = (int)nb - 4 * i;
+                const uint32_t m = remain >= 4 ? 0xFFFFFFFFu : (remain <= 0 ? 0u : ((1u << (8 * remain)) - 1u));
+                bad |= b & m;
+            } else {
+                bad |= b;
+            }
+            if (i < 4) wlo |= c << (8 * i); else whi |= c << (8 * (i - 4));
+        }
+        const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
+        wlo &= (uint32_t)keep;
+        whi &= (uint32_t)(keep >> 32);
+        __builtin_nontemporal_store(((unsigned long long)whi << 32) | wlo, out + w);
+        if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, base, nb, slot);
+    }
+}
+
+// decode of fixed-length reads; read r's bases go to out[r*stride .. r*stride + read_len).
+// CONTIG (stride == read_len): the tile's output bytes are one contiguous span, assembled in LDS
+// and written with coalesced 16-byte stores (edges byte-wise).  Otherwise the bytes between reads
+// belong to the caller: every lane stores its own 1..32 bytes straight to global memory.
+template <bool CONTIG>
+__global__ void __launch_bounds__(kBlock)
+decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned long long stride, unsigned wpr,
+                    unsigned long long total_words, uint8_t *__restrict__ out) {
+    __shared__ BatchLds lds[kBatchWaves];
+    BatchLds &my = lds[threadIdx.x >> 6];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + (threadIdx.x >> 6); tile < ntiles;
+         tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        const unsigned long long wb = tile * kBatchTile, w = wb + lane;
+        const bool active = w < total_words;
+        const unsigned long long wc = active ? w : total_words - 1;
+        const unsigned long long word = __builtin_nontemporal_load(words + wc);
+        const unsigned long long r = wc / wpr;
+        const unsigned j = (unsigned)(wc - r * wpr);
+        const unsigned long long base = r * stride + 32ull * j;
+        const unsigned left = read_len - 32 * j, nb = left < 32 ? left : 32u;
+        const u32x4 da = dec16((uint32_t)word), db = dec16((uint32_t)(word >> 32));
+        const uint32_t d[9] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w, 0u};
+        if constexpr (CONTIG) {
+            const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+            const unsigned long long span_lo = __shfl(base, 0), span_hi = __shfl(base + nb, last);
+            const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + span_lo, hi = reinterpret_cast<uintptr_t>(out) + span_hi;
+            const uintptr_t lo16 = lo & ~(uintptr_t)15;
+            wave_lds_fence();
+            if (active) {
+                const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16);
+                const unsigned head = (4u - (off & 3u)) & 3u;
+                const unsigned hb = head < nb ? head : nb;
+                const unsigned body = nb - hb, ndw = body >> 2, tb = body & 3;
+                if (hb > 0) my.stage[off] = (uint8_t)d[0];
+                if (hb > 1) my.stage[off + 1] = (uint8_t)(d[0] >> 8);
+                if (hb > 2) my.stage[off + 2] = (uint8_t)(d[0] >> 16);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(my.stage + off + hb);
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    if ((unsigned)m < ndw) dst[m] = __builtin_amdgcn_alignbyte(d[m + 1], d[m], head);
+                const unsigned q = hb + 4 * ndw;
+                const uint32_t tv = dec4((uint32_t)(word >> (2 * q)) & 0xFFu);
+                uint8_t *tp = my.stage + off + q;
+                if (tb > 0) tp[0] = (uint8_t)tv;
+                if (tb > 1) tp[1] = (uint8_t)(tv >> 8);
+                if (tb > 2) tp[2] = (uint8_t)(tv >> 16);
+            }
+            wave_lds_fence();
+            const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
+            for (unsigned c = lane; c < nchunk; c += 64)
+                store_stage_chunk(my.stage + 16 * c, lo16 + 16 * (uintptr_t)c, lo, hi);
+        } else if (active) {
+            uint8_t *dst = out + base;
+            const unsigned ndw = nb >> 2, tb = nb & 3;
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                if ((unsigned)m < ndw) *reinterpret_cast<u32_u *>(dst + 4 * m) = d[m];
+            const uint32_t tv = dec4((uint32_t)(word >> (8 * ndw)) & 0xFFu); // bases 4*ndw ..
+            if (tb > 0) dst[4 * ndw] = (uint8_t)tv;
+            if (tb > 1) dst[4 * ndw + 1] = (uint8_t)(tv >> 8);
+            if (tb > 2) dst[4 * ndw + 2] = (uint8_t)(tv >> 16);
+        }
+    }
+}
+
 // The decode side keeps a workgroup-level tile (128 words, 128 threads, workgroup barriers):
 // measured faster than the wave-private form for decode (0.35 vs 0.47 ms on 150-base reads),
 // while encode is faster wave-private with the tile records (0.33 vs 0.33-0.35 ms).
@@ -462,15 +640,8 @@ decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned
         // coalesced write-out; the first/last 16-byte chunk may be shared with a neighbouring
         // workgroup's span, so only this span's bytes are written there
         const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
-        for (unsigned c = t; c < nchunk; c += kBatchDecBlock) {
-            const uintptr_t g = lo16 + 16 * (uintptr_t)c;
-            if (g >= lo && g + 16 <= hi) {
-                __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(stage + 16 * c), reinterpret_cast<u32x4 *>(g));
-            } else {
-                for (unsigned j = 0; j < 16; ++j)
-                    if (g + j >= lo && g + j < hi) *reinterpret_cast<uint8_t *>(g + j) = stage[16 * c + j];
-            }
-        }
+        for (unsigned c = t; c < nchunk; c += kBatchDecBlock)
+            store_stage_chunk(stage + 16 * c, lo16 + 16 * (uintptr_t)c, lo, hi);
     }
 }
 

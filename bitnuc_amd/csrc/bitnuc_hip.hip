@@ -876,6 +876,98 @@ int bitnuc_decode_batch(bitnuc_ctx *c, const uint64_t *words, const uint64_t *wo
     return BITNUC_OK;
 }
 
+// ---- fixed-length reads ------------------------------------------------------------------------
+int bitnuc_encode_fixed_dev(bitnuc_ctx *c, const uint8_t *d_seq, size_t read_len, size_t stride, size_t count, uint64_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0 || read_len == 0) return BITNUC_OK; // zero-length reads produce no words
+    if (stride < read_len || read_len > 0xFFFFFFFFull - 64) return fail(err, BITNUC_UNSUPPORTED);
+    if (!d_seq || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const unsigned wpr = (unsigned)((read_len + 31) / 32);
+    const unsigned long long total = (unsigned long long)count * wpr;
+    unsigned long long *slot;
+    if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
+    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
+    const unsigned grid = grid_for(c, (total + per_block - 1) / per_block);
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
+    const unsigned long long seq_end = (unsigned long long)(count - 1) * stride + read_len;
+    if (stride == read_len) encode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, total, seq_end, o, slot);
+    else encode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, total, seq_end, o, slot);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_len, size_t stride, size_t count, uint8_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0 || read_len == 0) return BITNUC_OK;
+    if (stride < read_len || read_len > 0xFFFFFFFFull - 64) return fail(err, BITNUC_UNSUPPORTED);
+    if (!d_words || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const unsigned wpr = (unsigned)((read_len + 31) / 32);
+    const unsigned long long total = (unsigned long long)count * wpr;
+    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
+    const unsigned grid = grid_for(c, (total + per_block - 1) / per_block);
+    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
+    if (stride == read_len) decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, total, d_out);
+    else decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, total, d_out);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_encode_fixed(bitnuc_ctx *c, const uint8_t *seq, size_t read_len, size_t stride, size_t count, uint64_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0 || read_len == 0) return BITNUC_OK;
+    if (stride < read_len || !seq || !out) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (int st = flush_pending(c, err)) return st;
+    const size_t wpr = (read_len + 31) / 32;
+    size_t per = kHostChunk / stride; // reads per staged chunk
+    if (per == 0) per = 1;
+    if (per > count) per = count;
+    if (int st = ensure_scratch(c, 0, (per - 1) * stride + read_len + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, per * wpr * 8 + 16, err)) return st;
+    for (size_t r0 = 0; r0 < count; r0 += per) {
+        const size_t m = count - r0 < per ? count - r0 : per;
+        const size_t bytes = (m - 1) * stride + read_len;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], seq + r0 * stride, bytes, hipMemcpyHostToDevice, c->stream));
+        bitnuc_err e;
+        if (int st = bitnuc_encode_fixed_dev(c, c->scratch[0], read_len, stride, m, reinterpret_cast<uint64_t *>(c->scratch[1]), &e)) { if (err) *err = e; return st; }
+        c->pending[c->n_pending - 1].base = (unsigned long long)r0 * stride; // report the index in the caller's buffer
+        HIPCHK(hipMemcpyAsync(out + r0 * wpr, c->scratch[1], m * wpr * 8, hipMemcpyDeviceToHost, c->stream));
+        int st = drain(c, &e);
+        if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    }
+    return BITNUC_OK;
+}
+
+int bitnuc_decode_fixed(bitnuc_ctx *c, const uint64_t *words, size_t read_len, size_t stride, size_t count, uint8_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0 || read_len == 0) return BITNUC_OK;
+    if (stride < read_len || !words || !out) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const size_t wpr = (read_len + 31) / 32;
+    size_t per = kHostChunk / stride;
+    if (per == 0) per = 1;
+    if (per > count) per = count;
+    if (int st = ensure_scratch(c, 0, (per - 1) * stride + read_len + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, per * wpr * 8 + 16, err)) return st;
+    for (size_t r0 = 0; r0 < count; r0 += per) {
+        const size_t m = count - r0 < per ? count - r0 : per;
+        const size_t bytes = (m - 1) * stride + read_len;
+        HIPCHK(hipMemcpyAsync(c->scratch[1], words + r0 * wpr, m * wpr * 8, hipMemcpyHostToDevice, c->stream));
+        if (stride != read_len) // separator bytes are the caller's: bring them in so they go back unchanged
+            HIPCHK(hipMemcpyAsync(c->scratch[0], out + r0 * stride, bytes, hipMemcpyHostToDevice, c->stream));
+        if (int st = bitnuc_decode_fixed_dev(c, reinterpret_cast<const uint64_t *>(c->scratch[1]), read_len, stride, m, c->scratch[0], err)) return st;
+        HIPCHK(hipMemcpyAsync(out + r0 * stride, c->scratch[0], bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return BITNUC_OK;
+}
+
 // ---- analysis on packed words --------------------------------------------------------------
 int bitnuc_base_counts_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t n_words, size_t n_bases, uint64_t *d_counts, bitnuc_err *err) {
     clear_err(err);

@@ -234,6 +234,14 @@ class Context {
         out.resize(nw);
         return out;
     }
+    // Fixed-length reads: `count` reads of read_len bases, read r at seq[r*stride ..]; returns
+    // count*ceil(read_len/32) words, row r == encode_alloc(read r).
+    Result<std::vector<uint64_t>> encode_fixed(Bytes seq, size_t read_len, size_t stride, size_t count) const {
+        std::vector<uint64_t> out(count * ((read_len + 31) / 32));
+        bitnuc_err e;
+        if (bitnuc_encode_fixed(ctx_, seq.ptr, read_len, stride, count, out.data(), &e) != BITNUC_OK) return NucleotideError::from_c(e);
+        return out;
+    }
     // Inverse: sequence i's bases are written at out[offsets[i] .. offsets[i+1]).
     Result<std::vector<uint8_t>> decode_batch(Words words, const std::vector<uint64_t> &word_offsets,
                                               const std::vector<uint64_t> &offsets) const {

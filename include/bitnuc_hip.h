@@ -141,6 +141,18 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *ctx, const uint64_t *d_words, const uint
 int bitnuc_encode_batch(bitnuc_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, size_t count, uint64_t *out, size_t out_cap_words, uint64_t *word_offsets, size_t *n_words, bitnuc_err *err);
 int bitnuc_decode_batch(bitnuc_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets, const uint64_t *offsets, size_t count, uint8_t *out, bitnuc_err *err);
 
+/* Fixed-length reads (the common sequencing layout): `count` reads of `read_len` bases, read r
+ * at byte r*stride (stride >= read_len; stride == read_len: back to back; stride == read_len+1:
+ * newline-separated, ...).  Read r's ceil(read_len/32) words are out[r*wpr .. (r+1)*wpr), its
+ * last word zero-padded high -- the same words as `encode(read_r)` per read.  Separator bytes
+ * are never examined.  No offsets tables and no lookup: the fastest batch form. */
+int bitnuc_encode_fixed_dev(bitnuc_ctx *ctx, const uint8_t *d_seq, size_t read_len, size_t stride, size_t count, uint64_t *d_out, bitnuc_err *err);
+/* Inverse: read r's bases are written at d_out[r*stride .. r*stride + read_len); bytes between
+ * reads are left untouched. */
+int bitnuc_decode_fixed_dev(bitnuc_ctx *ctx, const uint64_t *d_words, size_t read_len, size_t stride, size_t count, uint8_t *d_out, bitnuc_err *err);
+int bitnuc_encode_fixed(bitnuc_ctx *ctx, const uint8_t *seq, size_t read_len, size_t stride, size_t count, uint64_t *out, bitnuc_err *err);
+int bitnuc_decode_fixed(bitnuc_ctx *ctx, const uint64_t *words, size_t read_len, size_t stride, size_t count, uint8_t *out, bitnuc_err *err);
+
 /* ---- analysis on packed words (the callers just above the codec) ------ */
 /* BaseCount::base_counts / GCContent::gc_content of a packed sequence
  * (src/utils/analysis.rs:7-39: the reference decodes to ASCII, then counts bytes): counts[] =

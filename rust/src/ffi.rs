@@ -62,6 +62,10 @@ extern "C" {
     pub fn bitnuc_decode_batch_dev(ctx: *mut bitnuc_ctx, d_words: *const u64, d_word_offsets: *const u64, d_offsets: *const u64, count: usize, total_words: usize, d_out: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_encode_batch(ctx: *mut bitnuc_ctx, seq: *const u8, offsets: *const u64, count: usize, out: *mut u64, out_cap_words: usize, word_offsets: *mut u64, n_words: *mut usize, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_decode_batch(ctx: *mut bitnuc_ctx, words: *const u64, word_offsets: *const u64, offsets: *const u64, count: usize, out: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_encode_fixed(ctx: *mut bitnuc_ctx, seq: *const u8, read_len: usize, stride: usize, count: usize, out: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_decode_fixed(ctx: *mut bitnuc_ctx, words: *const u64, read_len: usize, stride: usize, count: usize, out: *mut u8, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_encode_fixed_dev(ctx: *mut bitnuc_ctx, d_seq: *const u8, read_len: usize, stride: usize, count: usize, d_out: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_decode_fixed_dev(ctx: *mut bitnuc_ctx, d_words: *const u64, read_len: usize, stride: usize, count: usize, d_out: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_base_counts(ctx: *mut bitnuc_ctx, words: *const u64, n_words: usize, n_bases: usize, counts: *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_base_counts_dev(ctx: *mut bitnuc_ctx, d_words: *const u64, n_words: usize, n_bases: usize, d_counts: *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_hdist_pairs(ctx: *mut bitnuc_ctx, a: *const u64, b: *const u64, count: usize, len: usize, dist: *mut u8, err: *mut bitnuc_err) -> c_int;

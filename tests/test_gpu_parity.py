@@ -867,3 +867,62 @@ def test_ballot_formulation_variant(ctx, oracle):
         assert (ei.value.byte, ei.value.index) == (ord("N"), 54321)
     finally:
         ctx.set_variant("encode", prev)
+
+
+# ---- fixed-length reads --------------------------------------------------------------------------
+@pytest.mark.parametrize("read_len,stride", [(150, 150), (150, 151), (100, 100), (31, 31), (32, 32), (33, 40), (1, 1), (1, 3),
+                                             (250, 250), (250, 251), (151, 300), (64, 200), (1000, 1000), (5000, 5003)])
+def test_fixed_reads_vs_oracle_loop(ctx, oracle, read_len, stride):
+    import bitnuc_amd as bn
+    for count in [1, 2, 13, 64, 1000]:
+        nbytes = (count - 1) * stride + read_len
+        buf = np.full(nbytes, ord("\n"), dtype=np.uint8)  # separators are never examined
+        for r in range(count):
+            buf[r * stride: r * stride + read_len] = rand_seq(read_len)
+        exp = np.stack([oracle.encode(buf[r * stride: r * stride + read_len]) for r in range(count)])
+        got = ctx.encode_fixed(buf, read_len, stride, count)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (read_len, stride, count)
+        back = np.full(nbytes, ord("#"), dtype=np.uint8)
+        ctx.decode_fixed(got, read_len, stride, out=back)
+        for r in (0, count // 2, count - 1):
+            assert bytes(back[r * stride: r * stride + read_len]) == bytes(buf[r * stride: r * stride + read_len]).upper()
+        if stride > read_len and count > 1:
+            assert bytes(back[read_len:stride]) == b"#" * (stride - read_len)  # gap bytes untouched
+    # an invalid base inside a read is reported with its offset in the caller's buffer
+    count = 500
+    buf = np.full((count - 1) * stride + read_len, ord("\n"), dtype=np.uint8)
+    for r in range(count):
+        buf[r * stride: r * stride + read_len] = rand_seq(read_len)
+    pos = 321 * stride + read_len - 1
+    buf[pos] = ord("N")
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.encode_fixed(buf, read_len, stride, count)
+    assert (ei.value.byte, ei.value.index) == (ord("N"), pos)
+
+
+def test_fixed_reads_full_scale(ctx, oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    L, count = 150, 6_666_666
+    n = L * count
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, n, 0xB17C0DE)
+    words = torch.empty(count * 5, dtype=torch.int64, device=dev)
+    back = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx.sync()
+    ctx.encode_fixed_dev(seq, L, L, count, words)
+    ctx.decode_fixed_dev(words, L, L, count, back)
+    ctx.sync()
+    assert torch.equal(seq, back)
+    # the ragged-batch path must give the same words
+    off = torch.arange(0, count + 1, dtype=torch.int64, device=dev) * L
+    wo = torch.empty(count + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    total = ctx.batch_word_offsets_dev(off, count, wo)
+    w2 = torch.empty(total, dtype=torch.int64, device=dev)
+    ctx.encode_batch_dev(seq, off, wo, count, total, w2)
+    ctx.sync()
+    assert torch.equal(words, w2)
+    h = seq[:L * 1000].cpu().numpy()
+    exp = np.concatenate([oracle.encode(h[i * L:(i + 1) * L]) for i in range(1000)])
+    assert np.array_equal(words[:5000].cpu().numpy().view(np.uint64), exp)

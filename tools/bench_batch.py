@@ -43,8 +43,10 @@ for L in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "32,
     words = torch.empty(total, dtype=torch.int64, device=dev)
     e = timed(lambda: ctx.encode_batch_dev(seq, off, wo, count, total, words))
     d = timed(lambda: ctx.decode_batch_dev(words, wo, off, count, total, back))
+    ef = timed(lambda: ctx.encode_fixed_dev(seq, L, L, count, words)) if total == count * ((L + 31) // 32) else 0
+    df = timed(lambda: ctx.decode_fixed_dev(words, L, L, count, back))
     ctx.sync()
     nb = L * count
     ok = bool(torch.equal(seq[:nb], back[:nb]))
     alg = nb + 8 * total
-    print(f"L={L:8d} count={count:9d} encode {e:.4f} ms {alg/e/1e6:6.0f} GB/s | decode {d:.4f} ms {alg/d/1e6:6.0f} GB/s | word_offsets {t_off:.3f} ms (host-synchronous) | roundtrip {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"L={L:8d} count={count:9d} encode {e:.4f} ms {alg/e/1e6:6.0f} GB/s | decode {d:.4f} ms {alg/d/1e6:6.0f} GB/s | fixed: encode {ef:.4f} ms {alg/ef/1e6:6.0f} GB/s decode {df:.4f} ms {alg/df/1e6:6.0f} GB/s | word_offsets {t_off:.3f} ms (host-synchronous) | roundtrip {'ok' if ok else 'MISMATCH'}", flush=True)
