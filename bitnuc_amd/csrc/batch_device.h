@@ -65,6 +65,27 @@ __device__ __forceinline__ void store_stage_chunk(const uint8_t *chunk, uintptr_
     if (tb > 2) td[2] = ts[2];
 }
 
+// value of a 64-bit per-lane quantity in one (wave-uniform) lane, as a scalar: v_readlane_b32 x2
+// instead of the ds_bpermute pair a generic __shfl costs
+__device__ __forceinline__ unsigned long long read_lane_u64(unsigned long long x, unsigned src_lane) {
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)x, (int)src_lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// read index and word-in-read of word wb + lane without a per-lane 64-bit division: one
+// wave-uniform division for the tile's first word, then a 32-bit step for the lane offset
+// (t = j0 + lane < wpr + 64): multiply-high by the host's magic = ceil(2^32 / wpr) when
+// wpr <= 64, a single compare when wpr > 64.
+struct ReadPos { unsigned long long r; unsigned j; };
+__device__ __forceinline__ ReadPos fixed_read_pos(unsigned long long wb, unsigned lane, unsigned wpr, unsigned magic) {
+    const unsigned long long r0 = wb / wpr; // wave-uniform
+    const unsigned j0 = (unsigned)(wb - r0 * wpr);
+    const unsigned t = j0 + lane;
+    const unsigned q = wpr > 64 ? (t >= wpr ? 1u : 0u) : (wpr == 1 ? t : __umulhi(t, magic)); // wpr == 1: magic would be 2^32
+    return ReadPos{r0 + q, t - q * wpr};
+}
+
 struct WordLoc {
     unsigned long long base; // byte offset of the word's first base in the sequence buffer
     unsigned nb;             // bases in this word (1..32)
@@ -386,7 +407,7 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
 // residue of each dword is masked to the bytes that belong to the read.
 template <bool GAPS>
 __global__ void __launch_bounds__(kBlock)
-encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned long long stride, unsigned wpr,
+encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned long long stride, unsigned wpr, unsigned magic,
                     unsigned long long total_words, unsigned long long seq_end /* bytes in the buffer */,
                     unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     __shared__ BatchLds lds[kBatchWaves];
@@ -397,17 +418,16 @@ encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned
          tile += (unsigned long long)gridDim.x * kBatchWaves) {
         const unsigned long long wb = tile * kBatchTile, w = wb + lane;
         const bool active = w < total_words;
-        const unsigned long long wc = active ? w : total_words - 1; // clamp: inactive lanes mirror the last word
-        const unsigned long long r = wc / wpr;
-        const unsigned j = (unsigned)(wc - r * wpr);
-        const unsigned long long base = r * stride + 32ull * j;
-        const unsigned left = read_len - 32 * j, nb = left < 32 ? left : 32u;
         const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic); // inactive lanes mirror the last word
+        const unsigned j = pos.j;
+        const unsigned long long base = pos.r * stride + 32ull * j;
+        const unsigned left = read_len - 32 * j, nb = left < 32 ? left : 32u;
         // stage 32 bytes past the last word too (clipped to the buffer): the unconditional 32-byte
         // pack of a partial last word then sees the next read's real bytes, not stale LDS
-        unsigned long long span_hi = __shfl(base + nb, last) + 32;
+        unsigned long long span_hi = read_lane_u64(base + nb, last) + 32;
         if (span_hi > seq_end) span_hi = seq_end;
-        const unsigned long long span_lo = __shfl(base, 0);
+        const unsigned long long span_lo = read_lane_u64(base, 0);
         const uintptr_t lo = reinterpret_cast<uintptr_t>(seq) + span_lo, hi = reinterpret_cast<uintptr_t>(seq) + span_hi;
         const uintptr_t lo16 = lo & ~(uintptr_t)15;
         const bool staged = hi - lo16 <= (uintptr_t)(kBatchStage - 16); // wave-uniform
@@ -462,7 +482,7 @@ encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned
 template <bool CONTIG>
 __global__ void __launch_bounds__(kBlock)
 decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned long long stride, unsigned wpr,
-                    unsigned long long total_words, uint8_t *__restrict__ out) {
+                    unsigned magic, unsigned long long total_words, uint8_t *__restrict__ out) {
     __shared__ BatchLds lds[kBatchWaves];
     BatchLds &my = lds[threadIdx.x >> 6];
     const unsigned lane = threadIdx.x & 63;
@@ -471,17 +491,16 @@ decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_
          tile += (unsigned long long)gridDim.x * kBatchWaves) {
         const unsigned long long wb = tile * kBatchTile, w = wb + lane;
         const bool active = w < total_words;
-        const unsigned long long wc = active ? w : total_words - 1;
-        const unsigned long long word = __builtin_nontemporal_load(words + wc);
-        const unsigned long long r = wc / wpr;
-        const unsigned j = (unsigned)(wc - r * wpr);
-        const unsigned long long base = r * stride + 32ull * j;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last));
+        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic);
+        const unsigned j = pos.j;
+        const unsigned long long base = pos.r * stride + 32ull * j;
         const unsigned left = read_len - 32 * j, nb = left < 32 ? left : 32u;
         const u32x4 da = dec16((uint32_t)word), db = dec16((uint32_t)(word >> 32));
         const uint32_t d[9] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w, 0u};
         if constexpr (CONTIG) {
-            const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
-            const unsigned long long span_lo = __shfl(base, 0), span_hi = __shfl(base + nb, last);
+            const unsigned long long span_lo = read_lane_u64(base, 0), span_hi = read_lane_u64(base + nb, last);
             const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + span_lo, hi = reinterpret_cast<uintptr_t>(out) + span_hi;
             const uintptr_t lo16 = lo & ~(uintptr_t)15;
             wave_lds_fence();
