@@ -287,6 +287,74 @@ word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned lon
 // ---------------------------------------------------------------------------------
 // batched encode
 // ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// tile core for CONTIGUOUS layouts (ragged batches, back-to-back fixed-length reads)
+// ---------------------------------------------------------------------------------
+// When the sequences sit back to back, every byte between the first and the last word of a
+// tile is a base of some word of the tile, so the tile is a bulk encode whose 2-bit stream is
+// cut at word starts (the kmer_dense_kernel idea with a per-lane cut position): the wave
+// encodes the tile's 16-byte chunks (coalesced dwordx4 loads, enc16) into an LDS strip of u32
+// code words, and each lane funnel-shifts its 64 bits out of strip dwords (byte_off >> 4) .. +2
+// and masks them to 2*nb bits.  Per word that is 3 LDS dword reads and 2 v_alignbit instead of
+// 9 LDS reads, 8 v_alignbyte and 8 per-dword packs, and a quarter of the LDS bytes.
+// `base`/`nb` = this lane's word (byte offset of its first base, bases in it); lanes past the
+// tile's last word mirror it.  span = [span_lo, span_hi) bytes of the tile (wave-uniform).
+// strip[c] = codes of chunk c (already in registers: chunk lane+64r in v[r]); validates every
+// chunk byte that lies inside the buffer.  Wave-private; call between two wave_lds_fence()s.
+__device__ __forceinline__ void stream_fill(const u32x4 (&v)[3], unsigned nchunk, uintptr_t lo16, const uint8_t *__restrict__ seq,
+                                            unsigned long long seq_end, uint32_t *strip, unsigned long long *__restrict__ slot) {
+    const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const unsigned c = lane + 64 * r;
+        if (c < nchunk) {
+            uint32_t bad = 0;
+            strip[c] = enc16(v[r], bad);
+            if (__builtin_expect(residue_is_bad(bad), 0)) {
+                // a 16-byte aligned chunk may stick out of the buffer at either end: look only at bytes inside it
+                const uintptr_t g = lo16 + 16 * (uintptr_t)c, s0 = reinterpret_cast<uintptr_t>(seq), e0 = s0 + seq_end;
+                const uintptr_t a = g > s0 ? g : s0, b = g + 16 < e0 ? g + 16 : e0;
+                if (b > a) rescan_bytes(seq, (unsigned long long)(a - s0), (unsigned)(b - a), slot);
+            }
+        }
+    }
+    if (lane < 4) strip[nchunk + lane] = 0; // the funnel may read up to 2 dwords past the last chunk
+}
+
+// the word whose first base sits byte_off bytes into the strip's span, nb bases long
+__device__ __forceinline__ unsigned long long stream_cut(const uint32_t *strip, unsigned byte_off, unsigned nb) {
+    const unsigned d = byte_off >> 4, sh = (byte_off & 15) * 2;
+    const uint32_t w0 = strip[d], w1 = strip[d + 1], w2 = strip[d + 2];
+    const uint32_t wlo = __builtin_amdgcn_alignbit(w1, w0, sh), whi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
+    return (((unsigned long long)whi << 32) | wlo) & keep;
+}
+
+// load + fill + cut for a tile whose span [span_lo, span_hi) is known up front
+__device__ __forceinline__ unsigned long long
+encode_word_from_stream(const uint8_t *__restrict__ seq, unsigned long long seq_end, unsigned long long span_lo,
+                        unsigned long long span_hi, unsigned long long base, unsigned nb, uint32_t *strip /* >= 136 dwords */,
+                        unsigned long long *__restrict__ slot) {
+    const unsigned lane = threadIdx.x & 63;
+    // read 32 bytes past the last word (clipped to the buffer) so that the 64-bit funnel of a
+    // partial last word sees real codes
+    unsigned long long hi_off = span_hi + 32;
+    if (hi_off > seq_end) hi_off = seq_end;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(seq) + span_lo, hi = reinterpret_cast<uintptr_t>(seq) + hi_off;
+    const uintptr_t lo16 = lo & ~(uintptr_t)15;
+    const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4); // <= 132
+    u32x4 v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const unsigned c = lane + 64 * r;
+        v[r] = c < nchunk ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)c)) : u32x4{0, 0, 0, 0};
+    }
+    wave_lds_fence(); // previous trip's strip readers are done
+    stream_fill(v, nchunk, lo16, seq, seq_end, strip, slot);
+    wave_lds_fence();
+    return stream_cut(strip, (unsigned)(reinterpret_cast<uintptr_t>(seq) + base - lo16), nb);
+}
+
 struct BatchLds { // one per wave and tile in flight
     unsigned long long win_wo[kBatchWin + 1], win_so[kBatchWin + 1];
     __attribute__((aligned(16))) uint8_t stage[kBatchStage];
@@ -298,6 +366,7 @@ constexpr int kBatchInFlight = 1; // tiles whose loads a wave issues before it c
 // tile's instead of adding up: (A) tile records, (B) window entries + the tile's bytes
 // (always the 2 KiB after its first base, clipped at the buffer end: known from the record
 // alone), (C) LDS lookup, funnel, encode, store.
+template <bool STREAM>
 __global__ void __launch_bounds__(kBlock)
 encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets,
                     unsigned long long count, unsigned long long total_words, const TileRec *__restrict__ recs,
@@ -323,7 +392,7 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
             const unsigned long long s = rec[u].owner + lane < count ? rec[u].owner + lane : count;
             wo_r[u] = word_offsets[s];
             so_r[u] = offsets[s];
-            const unsigned long long hi_off = rec[u].base0 + kBatchTile * 32 < seq_end ? rec[u].base0 + kBatchTile * 32 : seq_end;
+            const unsigned long long hi_off = rec[u].base0 + kBatchTile * 32 + 32 < seq_end ? rec[u].base0 + kBatchTile * 32 + 32 : seq_end;
             const uintptr_t lo = reinterpret_cast<uintptr_t>(seq) + rec[u].base0, hi = reinterpret_cast<uintptr_t>(seq) + hi_off;
             lo16[u] = lo & ~(uintptr_t)15;
             nchunk[u] = hi > lo16[u] ? (unsigned)((hi - lo16[u] + 15) >> 4) : 0; // <= 129
@@ -357,40 +426,56 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
                     continue;
                 }
             }
-            wave_lds_fence(); // previous trip's LDS readers are done
-            my.win_wo[lane] = wo_r[u];
-            my.win_so[lane] = so_r[u];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const unsigned c = lane + 64 * j;
-                if (c < nchunk[u]) *reinterpret_cast<u32x4 *>(my.stage + 16 * c) = st[u][j];
+            if constexpr (STREAM) {
+                // The sequences are back to back, so the tile is a bulk encode whose 2-bit stream is cut at
+                // the word starts: chunks -> u32 code words in the wave's strip, then one 64-bit funnel per
+                // word (stream_fill / stream_cut).
+                uint32_t *strip = reinterpret_cast<uint32_t *>(my.stage);
+                wave_lds_fence(); // previous trip's LDS readers are done
+                my.win_wo[lane] = wo_r[u];
+                my.win_so[lane] = so_r[u];
+                stream_fill(st[u], nchunk[u], lo16[u], seq, seq_end, strip, slot);
+                wave_lds_fence();
+                const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so);
+                if (!active) continue;
+                const unsigned long long word = stream_cut(strip, (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]), loc.nb);
+                __builtin_nontemporal_store(word, out + w);
+            } else {
+                wave_lds_fence(); // previous trip's LDS readers are done
+                my.win_wo[lane] = wo_r[u];
+                my.win_so[lane] = so_r[u];
+    #pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const unsigned c = lane + 64 * j;
+                    if (c < nchunk[u]) *reinterpret_cast<u32x4 *>(my.stage + 16 * c) = st[u][j];
+                }
+                wave_lds_fence();
+                const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so);
+                if (!active) continue;
+                const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]);
+                // The word's bytes start at any byte offset: read the 9 ALIGNED LDS dwords that cover 32
+                // bytes from there and funnel-shift (misaligned ds_read_b32 works on gfx950 but runs ~2x
+                // slower).  These kernels are VALU-issue bound (PMC), so there is no per-dword length
+                // logic: all 32 bytes are packed -- past the word's nb bases they are the next sequence's
+                // bytes or stage slack -- and the packed word is masked to 2*nb bits instead.  A residue
+                // from those extra bytes only sends the lane to rescan_bytes, which looks at its own nb.
+                const unsigned sh = off & 3;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(my.stage + (off & ~3u));
+                uint32_t a[9];
+    #pragma unroll
+                for (int i = 0; i < 9; ++i) a[i] = src[i];
+                uint32_t bad = 0, wlo = 0, whi = 0;
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t r = enc4(__builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), bad);
+                    if (i < 4) wlo |= r << (8 * i); else whi |= r << (8 * (i - 4));
+                }
+                const unsigned long long keep = loc.nb >= 32 ? ~0ull : ((1ull << (2 * loc.nb)) - 1);
+                wlo &= (uint32_t)keep;
+                whi &= (uint32_t)(keep >> 32);
+                __builtin_nontemporal_store(((unsigned long long)whi << 32) | wlo, out + w);
+                if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, loc.base, loc.nb, slot);
             }
-            wave_lds_fence();
-            const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so);
-            if (!active) continue;
-            const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]);
-            // The word's bytes start at any byte offset: read the 9 ALIGNED LDS dwords that cover 32
-            // bytes from there and funnel-shift (misaligned ds_read_b32 works on gfx950 but runs ~2x
-            // slower).  These kernels are VALU-issue bound (PMC), so there is no per-dword length
-            // logic: all 32 bytes are packed -- past the word's nb bases they are the next sequence's
-            // bytes or stage slack -- and the packed word is masked to 2*nb bits instead.  A residue
-            // from those extra bytes only sends the lane to rescan_bytes, which looks at its own nb.
-            const unsigned sh = off & 3;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(my.stage + (off & ~3u));
-            uint32_t a[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) a[i] = src[i];
-            uint32_t bad = 0, wlo = 0, whi = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t r = enc4(__builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), bad);
-                if (i < 4) wlo |= r << (8 * i); else whi |= r << (8 * (i - 4));
-            }
-            const unsigned long long keep = loc.nb >= 32 ? ~0ull : ((1ull << (2 * loc.nb)) - 1);
-            wlo &= (uint32_t)keep;
-            whi &= (uint32_t)(keep >> 32);
-            __builtin_nontemporal_store(((unsigned long long)whi << 32) | wlo, out + w);
-            if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, loc.base, loc.nb, slot);
         }
     }
 }
@@ -408,7 +493,7 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
 template <bool GAPS>
 __global__ void __launch_bounds__(kBlock)
 encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned long long stride, unsigned wpr, unsigned magic,
-                    unsigned long long total_words, unsigned long long seq_end /* bytes in the buffer */,
+                    unsigned long long total_words, unsigned long long seq_end /* bytes in the buffer */, int use_stream,
                     unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     __shared__ BatchLds lds[kBatchWaves];
     BatchLds &my = lds[threadIdx.x >> 6];
@@ -430,6 +515,12 @@ encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned
         const unsigned long long span_lo = read_lane_u64(base, 0);
         const uintptr_t lo = reinterpret_cast<uintptr_t>(seq) + span_lo, hi = reinterpret_cast<uintptr_t>(seq) + span_hi;
         const uintptr_t lo16 = lo & ~(uintptr_t)15;
+        if (!GAPS && use_stream) { // back-to-back reads: cut the tile's 2-bit stream at the word starts
+            const unsigned long long word = encode_word_from_stream(seq, seq_end, span_lo, read_lane_u64(base + nb, last), base, nb,
+                                                                    reinterpret_cast<uint32_t *>(my.stage), slot);
+            if (active) __builtin_nontemporal_store(word, out + w);
+            continue;
+        }
         const bool staged = hi - lo16 <= (uintptr_t)(kBatchStage - 16); // wave-uniform
         uint32_t a[9];
         unsigned sh;

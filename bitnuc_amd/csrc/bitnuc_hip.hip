@@ -48,6 +48,8 @@ struct bitnuc_ctx {
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
+    int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
+    int batch_stream = 0;                  // encode_batch: 1 = cut the tile's 2-bit stream, 0 = funnel raw bytes per word
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
@@ -454,6 +456,8 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
     else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
     else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
+    else if (!strcmp(key, "fixed_stream")) { prev = c->fixed_stream; if (value == 0 || value == 1) c->fixed_stream = value; }
+    else if (!strcmp(key, "batch_stream")) { prev = c->batch_stream; if (value == 0 || value == 1) c->batch_stream = value; }
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
     else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
@@ -794,9 +798,14 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t 
     if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
     const size_t per_block = (size_t)kBatchTile * kBatchWaves * kBatchInFlight;
     const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
-    encode_batch_kernel<<<grid, kBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
-                                                        reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, recs,
-                                                        reinterpret_cast<unsigned long long *>(d_out), slot);
+    if (c->batch_stream)
+        encode_batch_kernel<true><<<grid, kBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
+                                                              reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, recs,
+                                                              reinterpret_cast<unsigned long long *>(d_out), slot);
+    else
+        encode_batch_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
+                                                               reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, recs,
+                                                               reinterpret_cast<unsigned long long *>(d_out), slot);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
@@ -893,8 +902,8 @@ int bitnuc_encode_fixed_dev(bitnuc_ctx *c, const uint8_t *d_seq, size_t read_len
     unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
     const unsigned long long seq_end = (unsigned long long)(count - 1) * stride + read_len;
     const unsigned magic = (unsigned)((0x100000000ull + wpr - 1) / wpr); // ceil(2^32 / wpr): exact floor(t / wpr) for t < 2^16
-    if (stride == read_len) encode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, total, seq_end, o, slot);
-    else encode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, total, seq_end, o, slot);
+    if (stride == read_len) encode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, total, seq_end, c->fixed_stream, o, slot);
+    else encode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, total, seq_end, 0, o, slot);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
