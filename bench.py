@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--bases", type=int, default=10**9, help="bases per GPU per step (BASELINE configs[1]: 1e9)")
-    ap.add_argument("--rotate", type=int, default=3, help="buffer sets rotated so the 256 MiB Infinity Cache cannot serve a step")
+    ap.add_argument("--rotate", type=int, default=3, help="buffer sets rotated so the 256 MiB Infinity Cache cannot serve a step (>= 2)")
     ap.add_argument("--enc-variant", type=int, default=-1)
     ap.add_argument("--dec-variant", type=int, default=-1)
     ap.add_argument("--grid-mult", type=int, default=-1)
@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse the N>1 control flow")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise torch.distributed and run the collectives even at world size 1")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box)")
+    ap.add_argument("--warm-decode", action="store_true", help="decode the words the same step just encoded (a literal round trip: 20 %% of decode's input then comes from the Infinity Cache)")
     ap.add_argument("--probe", action="store_true", help="also time pure read/copy/fill kernels (the box's own HBM ceiling)")
     args = ap.parse_args()
 
@@ -128,7 +129,7 @@ def main():
     if args.grid_mult >= 0:
         ctx.set_variant("grid_mult", args.grid_mult)
 
-    R = max(1, args.rotate)
+    R = max(2, args.rotate)
     seqs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
     words = [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)]
     backs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
@@ -136,14 +137,23 @@ def main():
         ctx.nucgen_dev(seqs[r], n, SEED + r, first=rank * n)
     ctx.sync()
 
+    # Step i encodes buffer set r = i % R and decodes set (r + 1) % R, whose words were written
+    # R - 1 steps earlier: >= 2 x 2.25 GB of traffic ago, so no part of the decode's input can still
+    # sit in the 256 MiB Infinity Cache (decoding the words the same step just wrote would read
+    # 20 % of its bytes from cache and flatter the HBM fraction).
+    for r in range(R):
+        ctx.encode_dev(seqs[r], n, words[r])
+    ctx.sync()
+
     def step(i, ev=None):
         r = i % R
+        d = r if args.warm_decode else (r + 1) % R
         if ev:
             ev[0].record(stream)
         ctx.encode_dev(seqs[r], n, words[r])
         if ev:
             ev[1].record(stream)
-        ctx.decode_dev(words[r], nw, n, backs[r])
+        ctx.decode_dev(words[d], nw, n, backs[d])
         if ev:
             ev[2].record(stream)
 
@@ -165,7 +175,7 @@ def main():
     ctx.sync()  # raises if any launch latched an InvalidBase
 
     # parity guard inside the bench: the last step's round trip must be the identity
-    r_last = (args.steps - 1) % R
+    r_last = (args.steps - 1) % R if args.warm_decode else ((args.steps - 1) % R + 1) % R
     assert torch.equal(seqs[r_last], backs[r_last]), "decode(encode(x)) != x"
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if on_gpu_collectives else "cpu")
@@ -332,6 +342,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident, bit-exact vs CPU oracle",
                        "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
                        "seed": hex(SEED), "rotating_buffer_sets": R,
+                       "decode_input": "words encoded in the same step (Infinity-Cache warm)" if args.warm_decode else f"words encoded {R - 1} steps earlier (HBM resident, cache cold)",
                        "encode_variant": ctx.get("encode"), "decode_variant": ctx.get("decode"), "grid_mult": ctx.get("grid_mult"),
                        "parallelism": f"shard{world}" if world > 1 else "single"},
             "roofline": {"kernel": "encode_kernel", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,

@@ -44,7 +44,7 @@ struct bitnuc_ctx {
     uint8_t *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[6] = {0, 0, 0, 0, 0, 0};
     uint32_t *d_sink = nullptr;
-    int enc_variant = 14, dec_variant = 42; // kDefaultEnc / kDefaultDec
+    int enc_variant = 14, dec_variant = 22; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
@@ -219,11 +219,15 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 constexpr int kNumVariants = 47;
 constexpr int kBallotVariant = 100; // encode only: lane-per-base + ballot (selectable with set_variant("encode", 100))
 // defaults from the sustained (back-to-back) pair sweeps in profiles/ (10^9 bases, one tile per
-// workgroup; the pair matters because decode's 1 GB of stores sits dirty in the 256 MiB
-// Infinity Cache when the next encode starts; 21 interleaved rounds in one process):
+// workgroup, 15 interleaved rounds in one process, decode reading words written two steps
+// earlier so that none of its input is Infinity-Cache resident -- what bench.py times):
 //   encode 14: nt loads + plain stores, 2 groups in flight per lane, 128-thread workgroups -> 6.86 TB/s
-//   decode 42: nt loads + nt stores, 1 group per lane, XCD-contiguous tile order           -> 6.99 TB/s
-constexpr int kDefaultEnc = 14, kDefaultDec = 42;
+//   decode 22: plain loads + nt stores, 2 groups per lane                                   -> 5.93 TB/s
+// The pair is tuned, not each kernel: encode's 250 MB of plain-stored words sit dirty in the
+// 256 MiB Infinity Cache; decode's plain (allocating) loads push them out while decode runs,
+// nt loads would leave that write-back to the next encode.  All good pairs land on the same
+// plateau of ~0.40 ms per step = 6.3 TB/s of mixed read/write HBM traffic.
+constexpr int kDefaultEnc = 14, kDefaultDec = 22;
 
 struct VariantInfo { int unroll, block; bool ntld, ntst, xpose, xcd; };
 constexpr VariantInfo kVariants[kNumVariants] = {

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--enc", type=str, default="1,2,3,5,11,12,19")
     ap.add_argument("--dec", type=str, default="0,1,4,9,13,18,22,24,25,26,28")
     ap.add_argument("--grids", type=str, default="0")
+    ap.add_argument("--cold", type=int, default=1, help="1: decode a set encoded R-1 steps earlier (what bench.py does); 0: decode the words just written (Infinity-Cache warm)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream()
@@ -52,7 +53,8 @@ def main():
                         e[0].record(stream)
                         ctx.encode_dev(seqs[r], n, words[r])
                         e[1].record(stream)
-                        ctx.decode_dev(words[r], nw, n, backs[r])
+                        d = (r + 1) % R if args.cold else r  # --cold: decode words written R-1 steps ago (HBM, not Infinity Cache)
+                        ctx.decode_dev(words[d], nw, n, backs[d])
                         e[2].record(stream)
                         evs.append(e)
                     torch.cuda.synchronize()
