@@ -3,8 +3,10 @@
 "Gbases/s encode+decode on 10^9-base synthetic; % of HBM3E roofline".
 
 A step = one pass of the hot path over one batch: bulk-encode 10^9 device-resident
-ASCII bases to 2-bit words, then bulk-decode them back (two kernel launches through the
-C ABI's device-pointer entry points).  Weak scaling: every rank (one process per GPU)
+ASCII bases to 2-bit words and bulk-decode 10^9 bases of packed words (two kernel launches
+through the C ABI's device-pointer entry points).  Three buffer sets rotate and the decode
+reads the set encoded two steps earlier, so every input of every kernel comes from HBM, not
+from the 256 MiB Infinity Cache (--warm-decode gives the literal same-step round trip).  Weak scaling: every rank (one process per GPU)
 owns its own 10^9-base shard; there is no data-path collective (the optional
 concatenating all-gather of config 4 is timed separately, outside the step).
 
