@@ -274,6 +274,17 @@ def main():
                                     "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 9 * nw}}
             del qd
+            # split_packed at an odd base in the middle (16 B per word: read once, write once)
+            sidx = n // 2 + 5
+            snl, snr = ctx.split_packed_sizes(nw, n, sidx, canonical=True)
+            sl, sr = torch.empty(snl, dtype=torch.int64, device=dev), torch.empty(snr, dtype=torch.int64, device=dev)
+            ms = timed(lambda: ctx.split_packed_dev(alt(), nw, n, sidx, sl, sr, canonical=True))
+            gbs = 8 * (nw + snl + snr) / (ms * 1e-3) / 1e9
+            extra["split_packed"] = {"workload": "split 10^9 packed bases at base n/2+5 (functions/split.rs:15-99, funnel-shift form)", "ms": round(ms, 4),
+                                     "gbases_s": round(n / (ms * 1e-3) / 1e9, 1),
+                                     "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 8 * (nw + snl + snr)}}
+            del sl, sr
             # ragged batch of independent sequences: 150-base reads (each read pads its own last word)
             L, rcount = 150, n // 150
             roff = torch.arange(0, rcount + 1, dtype=torch.int64, device=dev) * L

@@ -9,10 +9,10 @@ Layout
 """
 from .api import (BackendError, Comm, Context, NucleotideError, as_2bit, as_2bit_batch, decode,
                   default_context, encode, encode_alloc, from_2bit, from_2bit_alloc, hdist,
-                  hdist_scalar, kmer_hdist_scan)
+                  hdist_scalar, kmer_hdist_scan, split_packed)
 
 from .sequence import PackedSequence
 
 __all__ = ["PackedSequence", "Comm", "BackendError", "Context", "NucleotideError", "as_2bit", "as_2bit_batch", "decode",
            "default_context", "encode", "encode_alloc", "from_2bit", "from_2bit_alloc", "hdist",
-           "hdist_scalar", "kmer_hdist_scan"]
+           "hdist_scalar", "kmer_hdist_scan", "split_packed"]

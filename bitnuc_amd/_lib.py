@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "libbitnuc_hip.so")
 # bitnuc_status (include/bitnuc_hip.h) == NucleotideError (src/error.rs:3-18)
 OK, INVALID_BASE, SEQUENCE_TOO_LONG, INVALID_LENGTH = 0, 1, 2, 3
 INDEX_OUT_OF_BOUNDS, INVALID_RANGE, UNSUPPORTED, BACKEND_ERROR = 4, 5, 6, 100
+SPLIT_AS_WRITTEN, SPLIT_CANONICAL = 0, 1
 
 
 class BitnucErr(C.Structure):
@@ -62,6 +63,9 @@ SIGNATURES = {
     "bitnuc_hdist_query_dev": (C.c_int, [_P, _U64, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_hdist_pairs": (C.c_int, [_P, _P, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_hdist_query": (C.c_int, [_P, _U64, _P, _SZ, _SZ, _P, _ERR]),
+    "bitnuc_split_packed_sizes": (C.c_int, [_SZ, _SZ, _SZ, C.c_int, C.POINTER(_SZ), C.POINTER(_SZ), _ERR]),
+    "bitnuc_split_packed": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, C.c_int, _P, C.POINTER(_SZ), _P, C.POINTER(_SZ), _ERR]),
+    "bitnuc_split_packed_dev": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, C.c_int, _P, _P, _ERR]),
     "bitnuc_comm_get_unique_id": (C.c_int, [_P, _ERR]),
     "bitnuc_comm_init_rank": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(_P), _ERR]),
     "bitnuc_comm_init_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), _ERR]),

@@ -68,6 +68,8 @@ def _raise(err):
         raise NucleotideError("SequenceTooLong", len=int(err.value))
     if st == L.INVALID_LENGTH:
         raise NucleotideError("InvalidLength", len=int(err.value))
+    if st == L.INDEX_OUT_OF_BOUNDS:
+        raise NucleotideError("IndexOutOfBounds", index=int(err.index), length=int(err.value))
     if st == L.UNSUPPORTED:
         raise NucleotideError("Unsupported")
     if st == L.BACKEND_ERROR:
@@ -280,6 +282,37 @@ class Context:
         if self._lib.bitnuc_hdist_query(self._h, C.c_uint64(query), _ptr(t), t.size, int(length), _ptr(out), C.byref(err)) != L.OK:
             _raise(err)
         return out
+
+    def split_packed(self, ebuf, slen, idx, lbuf, rbuf, canonical=False):
+        """split_packed(ebuf, slen, idx, &mut lbuf, &mut rbuf) (functions/split.rs:15-99): clears both
+        lists, then fills them.  canonical=False reproduces the reference word for word (see
+        include/bitnuc_hip.h); canonical=True gives encode(seq[:idx]) / encode(seq[idx:])."""
+        e = _as_u64(ebuf)
+        flags = L.SPLIT_CANONICAL if canonical else L.SPLIT_AS_WRITTEN
+        nl, nr = C.c_size_t(0), C.c_size_t(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_split_packed_sizes(e.size, int(slen), int(idx), flags, C.byref(nl), C.byref(nr), C.byref(err)) != L.OK:
+            _raise(err)  # the reference validates before it clears (split.rs:23-32)
+        lo, ro = np.empty(nl.value, dtype=np.uint64), np.empty(nr.value, dtype=np.uint64)
+        if self._lib.bitnuc_split_packed(self._h, _ptr(e), e.size, int(slen), int(idx), flags, _ptr(lo), C.byref(nl),
+                                         _ptr(ro), C.byref(nr), C.byref(err)) != L.OK:
+            _raise(err)
+        del lbuf[:]
+        del rbuf[:]
+        lbuf.extend(int(x) for x in lo[: nl.value])
+        rbuf.extend(int(x) for x in ro[: nr.value])
+
+    def split_packed_sizes(self, n_words, slen, idx, canonical=False):
+        nl, nr = C.c_size_t(0), C.c_size_t(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_split_packed_sizes(int(n_words), int(slen), int(idx), L.SPLIT_CANONICAL if canonical else L.SPLIT_AS_WRITTEN,
+                                               C.byref(nl), C.byref(nr), C.byref(err)) != L.OK:
+            _raise(err)
+        return nl.value, nr.value
+
+    def split_packed_dev(self, d_ebuf, n_words, slen, idx, d_lbuf, d_rbuf, canonical=False):
+        self._call_dev(self._lib.bitnuc_split_packed_dev, _dev_ptr(d_ebuf), int(n_words), int(slen), int(idx),
+                       L.SPLIT_CANONICAL if canonical else L.SPLIT_AS_WRITTEN, _dev_ptr(d_lbuf), _dev_ptr(d_rbuf))
 
     def base_counts_dev(self, d_words, n_words, n_bases, d_counts):
         self._call_dev(self._lib.bitnuc_base_counts_dev, _dev_ptr(d_words), int(n_words), int(n_bases), _dev_ptr(d_counts))
@@ -511,3 +544,7 @@ def as_2bit_batch(kmers, k, stride=None, count=None):
 
 def kmer_hdist_scan(ref, k, query):
     return default_context().kmer_hdist_scan(ref, k, query)
+
+
+def split_packed(ebuf, slen, idx, lbuf, rbuf, canonical=False):
+    return default_context().split_packed(ebuf, slen, idx, lbuf, rbuf, canonical=canonical)

@@ -110,4 +110,88 @@ hdist_words_kernel(const unsigned long long *__restrict__ a, const unsigned long
     }
 }
 
+// split_packed (src/utils/functions/split.rs:15-99): cut a packed sequence at base c*32 + s/2.
+//   left[j]  = e[j] for j < n_left-1, left[n_left-1] = e[n_left-1] & lmask_last
+//   CANON:     right[j] = e[c+j] >> s | e[c+j+1] << (64-s)   (the funnel shift; last word & rmask_last)
+//   as written: right[j] = e[c+j] >> s | e[c+j-1] << (64-s)  for j > 0 (split.rs:84-94 carries the
+//              *previous* word's low bits), right[0] = e[c] >> s
+// One lane -> two output words (one 16-byte store); the three source words a right-hand pair
+// needs are one dwordx4 + one dwordx2 load, whichever of the two is 16-byte aligned (wave-uniform
+// choice).  The last two words of each side (masks, buffer end) take the one-word path.
+template <bool CANON>
+__device__ __forceinline__ unsigned long long split_right_word(const unsigned long long *__restrict__ e, unsigned long long src_words,
+                                                               unsigned long long c, unsigned s, unsigned long long j) {
+    const unsigned long long k = c + j;
+    unsigned long long v = e[k] >> s;
+    if (s) {
+        if constexpr (CANON) {
+            if (k + 1 < src_words) v |= e[k + 1] << (64 - s);
+        } else {
+            if (j) v |= e[k - 1] << (64 - s);
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long u64_of(uint32_t lo, uint32_t hi) { return ((unsigned long long)hi << 32) | lo; }
+
+template <bool CANON>
+__global__ void __launch_bounds__(kBlock)
+split_packed_kernel(const unsigned long long *__restrict__ e, unsigned long long src_words, unsigned long long c, unsigned s,
+                    unsigned long long n_left, unsigned long long n_right, unsigned long long lmask_last,
+                    unsigned long long rmask_last, unsigned long long *__restrict__ l, unsigned long long *__restrict__ r) {
+    const bool fast = ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(l) | reinterpret_cast<uintptr_t>(r)) & 15) == 0;
+    const unsigned long long lpairs = fast && n_left > 2 ? (n_left - 1) >> 1 : 0;  // pairs that end before the last left word
+    const unsigned long long rpairs = fast && n_right > 2 ? (n_right - 1) >> 1 : 0;
+    const unsigned long long ltail = n_left - 2 * lpairs, rtail = n_right - 2 * rpairs;
+    const unsigned long long items = lpairs + rpairs + ltail + rtail;
+    // first source word of a right pair is c + 2p (CANON) or c + 2p - 1 (as written): is that one 16-byte aligned?
+    const bool first_aligned = (((CANON ? c : c + 1) & 1) == 0);
+    const unsigned sh = s ? 64 - s : 0;
+    const unsigned long long keep = s ? ~0ull : 0; // s == 0: nothing is carried in
+    for (unsigned long long t = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; t < items;
+         t += (unsigned long long)gridDim.x * kBlock) {
+        if (t < lpairs) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(e) + t);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(l) + t);
+        } else if (t < lpairs + rpairs) {
+            const unsigned long long p = t - lpairs;
+            // w0..w2 = the three consecutive source words starting at `base`
+            const unsigned long long base = CANON ? c + 2 * p : c + 2 * p - 1; // as written, p == 0: e[c-1] is not used
+            unsigned long long w0, w1, w2;
+            if (first_aligned) { // as written this means c is odd, so e[c - 1] exists (and is ignored for p == 0)
+                const u32x4 a = *reinterpret_cast<const u32x4 *>(e + base);
+                w0 = u64_of(a.x, a.y);
+                w1 = u64_of(a.z, a.w);
+                w2 = e[base + 2];
+            } else {
+                w0 = (CANON || p) ? e[base] : 0;
+                const u32x4 a = *reinterpret_cast<const u32x4 *>(e + (base + 1));
+                w1 = u64_of(a.x, a.y);
+                w2 = u64_of(a.z, a.w);
+            }
+            unsigned long long o0, o1;
+            if constexpr (CANON) {
+                o0 = (w0 >> s) | ((w1 << sh) & keep);
+                o1 = (w1 >> s) | ((w2 << sh) & keep);
+            } else {
+                o0 = (w1 >> s) | (p ? (w0 << sh) & keep : 0);
+                o1 = (w2 >> s) | ((w1 << sh) & keep);
+            }
+            __builtin_nontemporal_store(u32x4{(uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)o1, (uint32_t)(o1 >> 32)},
+                                        reinterpret_cast<u32x4 *>(r) + p);
+        } else if (t < lpairs + rpairs + ltail) {
+            const unsigned long long j = 2 * lpairs + (t - lpairs - rpairs);
+            unsigned long long v = e[j];
+            if (j == n_left - 1) v &= lmask_last;
+            l[j] = v;
+        } else {
+            const unsigned long long j = 2 * rpairs + (t - lpairs - rpairs - ltail);
+            unsigned long long v = split_right_word<CANON>(e, src_words, c, s, j);
+            if (CANON && j == n_right - 1) v &= rmask_last;
+            r[j] = v;
+        }
+    }
+}
+
 } // namespace bitnuc_dev

@@ -14,6 +14,8 @@
 //   decode(&[u64], usize, &mut Vec<u8>) -> Result<()>  Result<void> decode(words, n, std::vector<uint8_t>&)
 //   hdist_scalar(u64, u64, usize) -> Result<u32>       Result<uint32_t> hdist_scalar(u, v, len)
 //   hdist(&[u64], &[u64], usize) -> Result<u32>        Result<uint32_t> hdist(a, b, n)
+//   split_packed(&[u64], usize, usize, &mut Vec<u64>, &mut Vec<u64>) -> Result<()>
+//                                                      Result<void> split_packed(words, slen, idx, lbuf&, rbuf&)
 //
 // Every function computes on the GPU through libbitnuc_hip.so; there is no CPU path.
 #pragma once
@@ -74,7 +76,7 @@ struct NucleotideError {
         case BITNUC_INVALID_BASE: r.kind = InvalidBase; r.base = e.byte; r.index = e.index; break;
         case BITNUC_SEQUENCE_TOO_LONG: r.kind = SequenceTooLong; r.len = (size_t)e.value; break;
         case BITNUC_INVALID_LENGTH: r.kind = InvalidLength; r.len = (size_t)e.value; break;
-        case BITNUC_INDEX_OUT_OF_BOUNDS: r.kind = IndexOutOfBounds; break;
+        case BITNUC_INDEX_OUT_OF_BOUNDS: r.kind = IndexOutOfBounds; r.oob_index = (size_t)e.index; r.length = (size_t)e.value; break;
         case BITNUC_INVALID_RANGE: r.kind = InvalidRange; break;
         case BITNUC_BACKEND_ERROR: r.kind = Backend; r.backend_code = e.backend_code; break;
         default: r.kind = Unsupported; break;
@@ -205,6 +207,21 @@ class Context {
         if (bitnuc_hdist(ctx_, a.ptr, a.len, b.ptr, b.len, n_bases, &out, &e) != BITNUC_OK) return NucleotideError::from_c(e);
         return out;
     }
+    // split_packed(ebuf, slen, idx, &mut lbuf, &mut rbuf)  functions/split.rs:15-99: validates, clears both
+    // vectors, fills them.  canonical = false: the reference's words as written; true: encode(seq[..idx]) /
+    // encode(seq[idx..]) (see include/bitnuc_hip.h).
+    Result<void> split_packed(Words ebuf, size_t slen, size_t idx, std::vector<uint64_t> &lbuf, std::vector<uint64_t> &rbuf,
+                              bool canonical = false) const {
+        const int flags = canonical ? BITNUC_SPLIT_CANONICAL : BITNUC_SPLIT_AS_WRITTEN;
+        size_t nl = 0, nr = 0;
+        bitnuc_err e;
+        if (bitnuc_split_packed_sizes(ebuf.len, slen, idx, flags, &nl, &nr, &e) != BITNUC_OK) return NucleotideError::from_c(e);
+        lbuf.assign(nl, 0);
+        rbuf.assign(nr, 0);
+        if (bitnuc_split_packed(ctx_, ebuf.ptr, ebuf.len, slen, idx, flags, lbuf.data(), &nl, rbuf.data(), &nr, &e) != BITNUC_OK)
+            return NucleotideError::from_c(e);
+        return Result<void>();
+    }
     // batched forms of the README.md:52-56 / src/lib.rs:170-173 host loops
     Result<std::vector<uint64_t>> as_2bit_batch(Bytes kmers, size_t k, size_t stride, size_t count) const {
         std::vector<uint64_t> out(count);
@@ -333,5 +350,9 @@ inline Result<std::vector<uint64_t>> encode_alloc(Bytes sequence) { return defau
 inline Result<void> decode(Words ebuf, size_t n_bases, std::vector<uint8_t> &dbuf) { return default_context().decode(ebuf, n_bases, dbuf); }
 inline Result<uint32_t> hdist_scalar(uint64_t u, uint64_t v, size_t len) { return default_context().hdist_scalar(u, v, len); }
 inline Result<uint32_t> hdist(Words a, Words b, size_t n_bases) { return default_context().hdist(a, b, n_bases); }
+inline Result<void> split_packed(Words ebuf, size_t slen, size_t idx, std::vector<uint64_t> &lbuf, std::vector<uint64_t> &rbuf,
+                                 bool canonical = false) {
+    return default_context().split_packed(ebuf, slen, idx, lbuf, rbuf, canonical);
+}
 
 } // namespace bitnuc

@@ -40,7 +40,7 @@ typedef enum bitnuc_status {
     BITNUC_INVALID_BASE = 1,        /* InvalidBase(u8)         -> err.byte, err.index */
     BITNUC_SEQUENCE_TOO_LONG = 2,   /* SequenceTooLong(usize)  -> err.value */
     BITNUC_INVALID_LENGTH = 3,      /* InvalidLength(usize)    -> err.value */
-    BITNUC_INDEX_OUT_OF_BOUNDS = 4, /* not produced by this path */
+    BITNUC_INDEX_OUT_OF_BOUNDS = 4, /* IndexOutOfBounds{index,length} -> err.index, err.value (split_packed) */
     BITNUC_INVALID_RANGE = 5,       /* decreasing offsets in the ragged-batch entry points -> err.value = index */
     BITNUC_UNSUPPORTED = 6,         /* Unsupported (bad argument combination) */
     BITNUC_BACKEND_ERROR = 100      /* hipError_t in err.backend_code */
@@ -167,6 +167,31 @@ int bitnuc_hdist_pairs_dev(bitnuc_ctx *ctx, const uint64_t *d_a, const uint64_t 
 int bitnuc_hdist_query_dev(bitnuc_ctx *ctx, uint64_t query, const uint64_t *d_targets, size_t count, size_t len, uint8_t *d_dist, bitnuc_err *err);
 int bitnuc_hdist_pairs(bitnuc_ctx *ctx, const uint64_t *a, const uint64_t *b, size_t count, size_t len, uint8_t *dist, bitnuc_err *err);
 int bitnuc_hdist_query(bitnuc_ctx *ctx, uint64_t query, const uint64_t *targets, size_t count, size_t len, uint8_t *dist, bitnuc_err *err);
+
+/* ---- split_packed ----------------------------------------------------- */
+/* split_packed(ebuf, slen, idx, &mut lbuf, &mut rbuf)   src/utils/functions/split.rs:15-99
+ * Cut a packed sequence of slen bases at base idx (idx goes to the right part).
+ * idx > slen -> INDEX_OUT_OF_BOUNDS{err.index = idx, err.value = slen} (split.rs:23-28).
+ * flags:
+ *   BITNUC_SPLIT_AS_WRITTEN  the reference's output, word for word: idx == 0 -> right = ebuf;
+ *       idx == slen -> left = ebuf; otherwise left = ebuf[..idx/32] + the masked split word
+ *       (idx/32 + 1 words, a zero word when idx % 32 == 0) and right = n_words - idx/32 words,
+ *       right[j] = ebuf[idx/32 + j] >> s | ebuf[idx/32 + j - 1] << (64 - s), s = 2*(idx % 32)
+ *       (split.rs:84-94 ORs in the low bits of the PREVIOUS word, so a right part longer than
+ *       one word is not the shifted sequence unless s == 0; the reference's tests only cover
+ *       one-word right parts and s == 0).
+ *   BITNUC_SPLIT_CANONICAL   the funnel shift the function documents: left == encode(seq[..idx])
+ *       (ceil(idx/32) words) and right == encode(seq[idx..]) (ceil((slen-idx)/32) words), bits
+ *       above the last base cleared.  Agrees with AS_WRITTEN (up to trailing words / the zero
+ *       word) wherever the reference's own tests look.
+ * n_words < ceil(slen/32) -> INVALID_LENGTH(slen) (the reference panics or returns a
+ * data-dependent length there).  lbuf / rbuf must not overlap ebuf.  _sizes returns the word
+ * counts a call will write; the host form returns them too. */
+#define BITNUC_SPLIT_AS_WRITTEN 0
+#define BITNUC_SPLIT_CANONICAL 1
+int bitnuc_split_packed_sizes(size_t n_words, size_t slen, size_t idx, int flags, size_t *n_left, size_t *n_right, bitnuc_err *err);
+int bitnuc_split_packed(bitnuc_ctx *ctx, const uint64_t *ebuf, size_t n_words, size_t slen, size_t idx, int flags, uint64_t *lbuf, size_t *n_left, uint64_t *rbuf, size_t *n_right, bitnuc_err *err);
+int bitnuc_split_packed_dev(bitnuc_ctx *ctx, const uint64_t *d_ebuf, size_t n_words, size_t slen, size_t idx, int flags, uint64_t *d_lbuf, uint64_t *d_rbuf, bitnuc_err *err);
 
 /* ---- multi-GPU: shard + concatenate (BASELINE config 4) ------------------------------------ */
 /* u64 words never share state (packing/avx.rs:138-145 has no carry), so a sequence split at

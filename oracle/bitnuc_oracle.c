@@ -232,6 +232,52 @@ int orc_hdist_pairs(const uint64_t *a, const uint64_t *b, size_t count, size_t l
     return ORC_OK;
 }
 
+int orc_split_packed(const uint64_t *ebuf, size_t n_words, size_t slen, size_t idx, uint64_t *lbuf, size_t *n_left,
+                     uint64_t *rbuf, size_t *n_right, orc_err *err) {
+    set_err(err, ORC_OK, 0, 0, 0);
+    size_t nl = 0, nr = 0; /* lbuf.clear(); rbuf.clear(), split.rs:31-32 (after the bounds check) */
+    if (idx > slen) {      /* split.rs:23-28 */
+        set_err(err, ORC_INDEX_OUT_OF_BOUNDS, 0, slen, idx);
+        return ORC_INDEX_OUT_OF_BOUNDS;
+    }
+    *n_left = *n_right = 0;
+    if (idx == 0) { /* split.rs:35-39 */
+        memcpy(rbuf, ebuf, n_words * 8);
+        *n_right = n_words;
+        return ORC_OK;
+    }
+    if (idx == slen) { /* split.rs:40-44 */
+        memcpy(lbuf, ebuf, n_words * 8);
+        *n_left = n_words;
+        return ORC_OK;
+    }
+    if (n_words == 0) return ORC_OK; /* split.rs:47-49 */
+    size_t right_chunks = (slen - idx + 31) / 32; /* split.rs:53-57 */
+    size_t chunk_idx = idx / 32;                  /* split.rs:64 */
+    unsigned bit_idx = (unsigned)(idx % 32) * 2;  /* split.rs:65 */
+    if (chunk_idx > 0 && chunk_idx <= n_words) {  /* split.rs:68-70 */
+        memcpy(lbuf, ebuf, chunk_idx * 8);
+        nl = chunk_idx;
+    }
+    if (chunk_idx >= n_words) { /* ebuf[chunk_idx], split.rs:78: index out of bounds -> panic */
+        set_err(err, ORC_PANIC, 0, 0, 0);
+        return ORC_PANIC;
+    }
+    uint64_t split_mask = bit_idx == 0 ? 0 : (1ull << bit_idx) - 1; /* split.rs:73-77 */
+    lbuf[nl++] = ebuf[chunk_idx] & split_mask;                     /* split.rs:78 */
+    unsigned right_shift = bit_idx;                                /* split.rs:81 */
+    uint64_t carry = 0;                                            /* split.rs:82 */
+    for (size_t i = chunk_idx; i < n_words; i++) {                 /* split.rs:84 */
+        uint64_t curr = ebuf[i];
+        rbuf[nr++] = carry | (curr >> right_shift);                /* split.rs:86-87 */
+        carry = right_shift == 0 ? 0 : curr << (64 - right_shift); /* split.rs:90-94 */
+    }
+    if (carry != 0 && nr < right_chunks) rbuf[nr++] = carry; /* split.rs:97-99 */
+    *n_left = nl;
+    *n_right = nr;
+    return ORC_OK;
+}
+
 static uint64_t mix64(uint64_t z) { /* splitmix64 finaliser */
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;

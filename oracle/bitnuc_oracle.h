@@ -90,6 +90,15 @@ double orc_gc_content(const uint64_t *words, size_t n_words, size_t n_bases);
 /* loop of hdist_scalar over word pairs / one query (hamming/scalar.rs:11-48) */
 int orc_hdist_pairs(const uint64_t *a, const uint64_t *b, size_t count, size_t len, uint8_t *dist, orc_err *err);
 
+/* src/utils/functions/split.rs:15-99, as written (including the previous-word carry of :84-94
+ * and the conditional final push of :97-99).  lbuf and rbuf must each hold n_words + 1 words.
+ * idx > slen -> ORC_INDEX_OUT_OF_BOUNDS {index = idx, value = slen}; a buffer that does not reach
+ * the split word -> ORC_PANIC (ebuf[chunk_idx], :78).  Parity: the reference's tests (split.rs:108-224)
+ * cover one-word right parts and idx % 32 == 0; multi-word right parts with a shift are pinned
+ * by this restatement only. */
+int orc_split_packed(const uint64_t *ebuf, size_t n_words, size_t slen, size_t idx, uint64_t *lbuf, size_t *n_left,
+                     uint64_t *rbuf, size_t *n_right, orc_err *err);
+
 /* Synthetic "nucgen-like" generator shared with the device generator:
  * base i = "ACGT"[(mix(seed, i/32) >> 2*(i%32)) & 3], mix = splitmix64
  * finaliser of seed + (i/32+1)*0x9E3779B97F4A7C15. `first` = absolute index of

@@ -9,6 +9,8 @@ pub const BITNUC_INVALID_LENGTH: c_int = 3;
 pub const BITNUC_INDEX_OUT_OF_BOUNDS: c_int = 4;
 pub const BITNUC_INVALID_RANGE: c_int = 5;
 pub const BITNUC_UNSUPPORTED: c_int = 6;
+pub const BITNUC_SPLIT_AS_WRITTEN: c_int = 0;
+pub const BITNUC_SPLIT_CANONICAL: c_int = 1;
 pub const BITNUC_BACKEND_ERROR: c_int = 100;
 
 #[repr(C)]
@@ -49,6 +51,9 @@ extern "C" {
     pub fn bitnuc_encode(ctx: *mut bitnuc_ctx, seq: *const u8, len: usize, out: *mut u64, n_words: *mut usize, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_decode(ctx: *mut bitnuc_ctx, ebuf: *const u64, n_words: usize, n_bases: usize, out: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_hdist(ctx: *mut bitnuc_ctx, a: *const u64, na: usize, b: *const u64, nb: usize, n_bases: usize, out: *mut u32, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_split_packed_sizes(n_words: usize, slen: usize, idx: usize, flags: c_int, n_left: *mut usize, n_right: *mut usize, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_split_packed(ctx: *mut bitnuc_ctx, ebuf: *const u64, n_words: usize, slen: usize, idx: usize, flags: c_int, lbuf: *mut u64, n_left: *mut usize, rbuf: *mut u64, n_right: *mut usize, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_split_packed_dev(ctx: *mut bitnuc_ctx, d_ebuf: *const u64, n_words: usize, slen: usize, idx: usize, flags: c_int, d_lbuf: *mut u64, d_rbuf: *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_as_2bit_batch(ctx: *mut bitnuc_ctx, kmers: *const u8, k: usize, stride: usize, count: usize, out: *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_kmer_hdist_scan(ctx: *mut bitnuc_ctx, reference: *const u8, n: usize, k: usize, query: u64, dist: *mut u8, err: *mut bitnuc_err) -> c_int;
 

@@ -45,6 +45,7 @@ fn to_err(e: &ffi::bitnuc_err) -> NucleotideError {
         ffi::BITNUC_INVALID_BASE => NucleotideError::InvalidBase(e.byte),
         ffi::BITNUC_SEQUENCE_TOO_LONG => NucleotideError::SequenceTooLong(e.value as usize),
         ffi::BITNUC_INVALID_LENGTH => NucleotideError::InvalidLength(e.value as usize),
+        ffi::BITNUC_INDEX_OUT_OF_BOUNDS => NucleotideError::IndexOutOfBounds { index: e.index as usize, length: e.value as usize },
         // a HIP failure has no reference counterpart; there is no CPU fallback to fall to
         ffi::BITNUC_BACKEND_ERROR => panic!("bitnuc-hip: HIP backend error {}", e.backend_code),
         _ => NucleotideError::Unsupported,
@@ -167,6 +168,33 @@ pub fn hdist(ebuf1: &[u64], ebuf2: &[u64], n_bases: usize) -> Result<u32, Nucleo
         ffi::bitnuc_hdist(c, ebuf1.as_ptr(), ebuf1.len(), ebuf2.as_ptr(), ebuf2.len(), n_bases, &mut out, &mut e)
     });
     if st == ffi::BITNUC_OK { Ok(out) } else { Err(to_err(&e)) }
+}
+
+/// `bitnuc::split_packed` (src/utils/functions/split.rs:15-99), word for word
+/// (`BITNUC_SPLIT_AS_WRITTEN`): validates, clears `lbuf`/`rbuf`, fills them.
+pub fn split_packed(ebuf: &[u64], slen: usize, idx: usize, lbuf: &mut Vec<u64>, rbuf: &mut Vec<u64>) -> Result<(), NucleotideError> {
+    split_packed_with(ebuf, slen, idx, lbuf, rbuf, ffi::BITNUC_SPLIT_AS_WRITTEN)
+}
+
+/// The funnel-shift split: `lbuf == encode(seq[..idx])`, `rbuf == encode(seq[idx..])`.
+pub fn split_packed_canonical(ebuf: &[u64], slen: usize, idx: usize, lbuf: &mut Vec<u64>, rbuf: &mut Vec<u64>) -> Result<(), NucleotideError> {
+    split_packed_with(ebuf, slen, idx, lbuf, rbuf, ffi::BITNUC_SPLIT_CANONICAL)
+}
+
+fn split_packed_with(ebuf: &[u64], slen: usize, idx: usize, lbuf: &mut Vec<u64>, rbuf: &mut Vec<u64>, flags: std::os::raw::c_int) -> Result<(), NucleotideError> {
+    let (mut nl, mut nr) = (0usize, 0usize);
+    let mut e = ffi::bitnuc_err::default();
+    if unsafe { ffi::bitnuc_split_packed_sizes(ebuf.len(), slen, idx, flags, &mut nl, &mut nr, &mut e) } != ffi::BITNUC_OK {
+        return Err(to_err(&e)); // before the buffers are cleared, like split.rs:23-32
+    }
+    lbuf.clear();
+    rbuf.clear();
+    lbuf.resize(nl, 0);
+    rbuf.resize(nr, 0);
+    let st = with_ctx(|c| unsafe {
+        ffi::bitnuc_split_packed(c, ebuf.as_ptr(), ebuf.len(), slen, idx, flags, lbuf.as_mut_ptr(), &mut nl, rbuf.as_mut_ptr(), &mut nr, &mut e)
+    });
+    if st == ffi::BITNUC_OK { Ok(()) } else { Err(to_err(&e)) }
 }
 
 /// Batched form of the `for kmer in kmers { as_2bit(kmer)? }` idiom (README.md:52-56 of

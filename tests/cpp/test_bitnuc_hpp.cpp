@@ -125,6 +125,32 @@ static void test_hdist() {
     }
 }
 
+// src/utils/functions/split.rs:108-224, the reference's own cases, for both modes
+static void test_split_packed() {
+    auto dec = [](const std::vector<uint64_t> &w, size_t n) { std::vector<uint8_t> d; decode(w, n, d).unwrap(); return std::string(d.begin(), d.end()); };
+    for (bool canonical : {false, true}) {
+        std::vector<uint64_t> l{9}, r{9};
+        auto e = encode_alloc("ACTGACTG").unwrap();
+        split_packed(e, 8, 4, l, r, canonical).unwrap();
+        CHECK(l.size() == 1 && r.size() == 1 && dec(l, 4) == "ACTG" && dec(r, 4) == "ACTG");
+        e = encode_alloc("ACTG").unwrap();
+        split_packed(e, 4, 0, l, r, canonical).unwrap();
+        CHECK(l.empty() && r.size() == 1 && dec(r, 4) == "ACTG");
+        split_packed(e, 4, 4, l, r, canonical).unwrap();
+        CHECK(l.size() == 1 && r.empty() && dec(l, 4) == "ACTG");
+        auto bad = split_packed(e, 4, 5, l, r, canonical);
+        CHECK(bad.is_err() && bad.unwrap_err().kind == NucleotideError::IndexOutOfBounds && bad.unwrap_err().oob_index == 5 &&
+              bad.unwrap_err().length == 4 && l.size() == 1); // buffers untouched on error
+        e = encode_alloc("ACTGACTGAC").unwrap();
+        split_packed(e, 10, 7, l, r, canonical).unwrap();
+        CHECK(l.size() == 1 && r.size() == 1 && dec(l, 7) == "ACTGACT" && dec(r, 3) == "GAC");
+        const std::string s40 = "ACTGACTGACTGACTGACTGACTGACTGACTGACTGACTG";
+        e = encode_alloc(s40).unwrap();
+        split_packed(e, 40, 32, l, r, canonical).unwrap();
+        CHECK(l.size() == (canonical ? 1u : 2u) && r.size() == 1 && dec(l, 32) == s40.substr(0, 32) && dec(r, 8) == s40.substr(32));
+    }
+}
+
 static void test_batch_equals_loop() {
     std::mt19937_64 rng(7);
     std::vector<uint8_t> seq;
@@ -185,6 +211,7 @@ int main() {
     RUN(test_large_sequence_round_trip);
     RUN(test_encode_error_keeps_prefix_words);
     RUN(test_hdist);
+    RUN(test_split_packed);
     RUN(test_batch_equals_loop);
     RUN(test_packed_sequence);
     std::printf("ALL OK\n");

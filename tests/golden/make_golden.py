@@ -117,6 +117,23 @@ V["packed_sequence"] = {
     "empty": {"seq": "", "len": 0, "to_vec": "", "src": "src/sequence.rs:42-46,80,250"},
 }
 
+# --- split_packed -----------------------------------------------------------
+# each case: encode(seq), split at idx -> word counts the test asserts, and the decoded halves
+V["split_packed"] = [
+    {"seq": "ACTGACTG", "idx": 4, "n_left": 1, "n_right": 1, "left": "ACTG", "right": "ACTG",
+     "src": "src/utils/functions/split.rs:108-133"},
+    {"seq": "ACTG", "idx": 0, "n_left": 0, "n_right": 1, "left": "", "right": "ACTG",
+     "src": "src/utils/functions/split.rs:136-152"},
+    {"seq": "ACTG", "idx": 4, "n_left": 1, "n_right": 0, "left": "ACTG", "right": "",
+     "src": "src/utils/functions/split.rs:154-161"},
+    {"seq": "ACTGACTGAC", "idx": 7, "n_left": 1, "n_right": 1, "left": "ACTGACT", "right": "GAC",
+     "src": "src/utils/functions/split.rs:164-187"},
+    {"seq": "ACTG" * 10, "idx": 32, "n_left": 2, "n_right": 1, "left": "ACTG" * 8, "right": "ACTGACTG",
+     "src": "src/utils/functions/split.rs:190-213"},
+]
+V["split_packed_err"] = {"seq": "ACTG", "idx": 5, "status": "IndexOutOfBounds", "index": 5, "length": 4,
+                         "src": "src/utils/functions/split.rs:216-224,23-28"}
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json")
     with open(out, "w") as f:

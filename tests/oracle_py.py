@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libbitnuc_oracle.so")
 
-STATUS = {0: "Ok", 1: "InvalidBase", 2: "SequenceTooLong", 3: "InvalidLength", 99: "Panic"}
+STATUS = {0: "Ok", 1: "InvalidBase", 2: "SequenceTooLong", 3: "InvalidLength", 4: "IndexOutOfBounds", 99: "Panic"}
 
 
 class OrcErr(C.Structure):
@@ -57,6 +57,7 @@ def lib():
         L.orc_gc_content.argtypes = [P, SZ, SZ]
         L.orc_gc_content.restype = C.c_double
         L.orc_hdist_pairs.argtypes = [P, P, SZ, SZ, P, E]
+        L.orc_split_packed.argtypes = [P, SZ, SZ, SZ, P, C.POINTER(SZ), P, C.POINTER(SZ), E]
         L.orc_nucgen.argtypes = [P, SZ, U64, U64, C.c_int]
         L.orc_nucgen.restype = None
         L.orc_avx2_encode.argtypes = [P, SZ, C.POINTER(P), C.POINTER(SZ), E]
@@ -182,6 +183,16 @@ def hdist_pairs(a, b, length):
     if lib().orc_hdist_pairs(_p(a), _p(b), a.size, length, _p(out), C.byref(err)):
         raise OracleError(err)
     return out
+
+
+def split_packed(ebuf, slen, idx):
+    """-> (lbuf, rbuf) as the reference leaves them (functions/split.rs:15-99, as written)."""
+    e = np.ascontiguousarray(ebuf, dtype=np.uint64)
+    lo, ro = np.zeros(e.size + 1, dtype=np.uint64), np.zeros(e.size + 1, dtype=np.uint64)
+    nl, nr, err = C.c_size_t(0), C.c_size_t(0), OrcErr()
+    if lib().orc_split_packed(_p(e), e.size, slen, idx, _p(lo), C.byref(nl), _p(ro), C.byref(nr), C.byref(err)):
+        raise OracleError(err)
+    return lo[: nl.value].copy(), ro[: nr.value].copy()
 
 
 def nucgen(length, seed, first=0, flags=0):

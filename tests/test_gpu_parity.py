@@ -676,6 +676,113 @@ def test_hdist_pairs_and_query(ctx, oracle):
     assert ei.value.kind == "InvalidLength" and ei.value.len == 33
 
 
+def test_split_packed_golden(ctx, oracle, golden):
+    import bitnuc_amd as bn
+    for canonical in (False, True):
+        for v in golden["split_packed"]:
+            s = v["seq"].encode()
+            ebuf, lbuf, rbuf = [], [123], [456]  # cleared by the call, split.rs:31-32
+            ctx.encode(s, ebuf)
+            ctx.split_packed(ebuf, len(s), v["idx"], lbuf, rbuf, canonical=canonical)
+            if not canonical:
+                assert (len(lbuf), len(rbuf)) == (v["n_left"], v["n_right"]), v["src"]
+            left, right = bytearray(), bytearray()
+            ctx.decode(lbuf, len(v["left"]), left)
+            ctx.decode(rbuf, len(v["right"]), right)
+            assert (bytes(left), bytes(right)) == (v["left"].encode(), v["right"].encode()), v["src"]
+        e = golden["split_packed_err"]
+        lbuf, rbuf = [1], [2]
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.split_packed(oracle.encode(e["seq"].encode()), len(e["seq"]), e["idx"], lbuf, rbuf, canonical=canonical)
+        assert ei.value == bn.NucleotideError("IndexOutOfBounds", index=e["index"], length=e["length"])
+        assert (lbuf, rbuf) == ([1], [2])  # validated before the buffers are cleared, split.rs:23-32
+
+
+def test_split_packed_vs_oracle(ctx, oracle):
+    import bitnuc_amd as bn
+    for n in [1, 31, 32, 33, 64, 65, 200, 1000, 4099, 100003]:
+        s = rand_seq(n, ALPHA)
+        w = oracle.encode(s)
+        idxs = sorted({0, 1, n // 3, n // 2, (n // 2) & ~31, n - 1, n} | {int(x) for x in RNG.integers(0, n + 1, size=6)})
+        for idx in idxs:
+            lbuf, rbuf = [], []
+            ctx.split_packed(w, n, idx, lbuf, rbuf)  # the reference word for word
+            lo, ro = oracle.split_packed(w, n, idx)
+            assert np.array_equal(np.array(lbuf, dtype=np.uint64), lo), (n, idx)
+            assert np.array_equal(np.array(rbuf, dtype=np.uint64), ro), (n, idx)
+            assert ctx.split_packed_sizes(w.size, n, idx) == (lo.size, ro.size)
+            ctx.split_packed(w, n, idx, lbuf, rbuf, canonical=True)  # == encode of the two halves
+            assert np.array_equal(np.array(lbuf, dtype=np.uint64), oracle.encode(s[:idx]) if idx else np.zeros(0, np.uint64)), (n, idx)
+            assert np.array_equal(np.array(rbuf, dtype=np.uint64), oracle.encode(s[idx:]) if idx < n else np.zeros(0, np.uint64)), (n, idx)
+    # device buffers at 8-byte (not 16-byte) alignment take the one-word-per-lane path
+    import torch
+    dev = torch.device("cuda:0")
+    n = 70001
+    s = rand_seq(n, ALPHA)
+    w = oracle.encode(s)
+    buf = torch.zeros(w.size + 1, dtype=torch.int64, device=dev)
+    buf[1:] = torch.from_numpy(w.view(np.int64)).to(dev)
+    for idx in (37, 32 * 1001 + 9, 32 * 1002 + 9, 64 * 500):
+        for canonical in (False, True):
+            nl, nr = ctx.split_packed_sizes(w.size, n, idx, canonical=canonical)
+            for off in (0, 1):  # all operands misaligned, then only the source
+                lt, rt = torch.zeros(nl + 1, dtype=torch.int64, device=dev), torch.zeros(nr + 1, dtype=torch.int64, device=dev)
+                ctx.split_packed_dev(buf[1:], w.size, n, idx, lt[1 - off:], rt[1 - off:], canonical=canonical)
+                ctx.sync()
+                got_l = lt[1 - off: 1 - off + nl].cpu().numpy().view(np.uint64)
+                got_r = rt[1 - off: 1 - off + nr].cpu().numpy().view(np.uint64)
+                exp_l, exp_r = (oracle.encode(s[:idx]), oracle.encode(s[idx:])) if canonical else oracle.split_packed(w, n, idx)
+                assert np.array_equal(got_l, exp_l) and np.array_equal(got_r, exp_r), (idx, canonical, off)
+    # junk above the last base is cleared in canonical mode and carried along as written
+    w = np.array([2**64 - 1, 2**64 - 1], dtype=np.uint64)
+    lbuf, rbuf = [], []
+    ctx.split_packed(w, 40, 7, lbuf, rbuf, canonical=True)
+    assert lbuf == [(1 << 14) - 1] and rbuf == [2**64 - 1, 3]
+    ctx.split_packed(w, 40, 7, lbuf, rbuf)
+    lo, ro = oracle.split_packed(w, 40, 7)
+    assert lbuf == [int(x) for x in lo] and rbuf == [int(x) for x in ro]
+    # short buffers: defined as InvalidLength(slen) (the reference panics / data-dependent length)
+    for canonical in (False, True):
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.split_packed(w, 200, 100, lbuf, rbuf, canonical=canonical)
+        assert ei.value == bn.NucleotideError("InvalidLength", len=200)
+    ctx.split_packed([], 10, 5, lbuf, rbuf)  # empty ebuf, split.rs:47-49
+    assert (lbuf, rbuf) == ([], [])
+
+
+def test_split_packed_full_scale(ctx, oracle):
+    """10^9+17 bases on the device: canonical split at an odd base == encode of the two halves."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 10**9 + 17
+    idx = 333_333_341
+    nw = (n + 31) // 32
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, n, 0xB17C0DE)
+    words = torch.empty(nw, dtype=torch.int64, device=dev)
+    ctx.encode_dev(seq, n, words)
+    nl, nr = ctx.split_packed_sizes(nw, n, idx, canonical=True)
+    assert (nl, nr) == ((idx + 31) // 32, (n - idx + 31) // 32)
+    left, right = torch.empty(nl, dtype=torch.int64, device=dev), torch.empty(nr, dtype=torch.int64, device=dev)
+    ctx.split_packed_dev(words, nw, n, idx, left, right, canonical=True)
+    el, er = torch.empty(nl, dtype=torch.int64, device=dev), torch.empty(nr, dtype=torch.int64, device=dev)
+    ctx.encode_dev(seq, idx, el)
+    ctx.encode_dev(seq[idx:], n - idx, er)  # unaligned device pointer
+    ctx.sync()
+    assert torch.equal(left, el) and torch.equal(right, er)
+    # as written: sizes and a sampled window against the oracle's restatement
+    nl, nr = ctx.split_packed_sizes(nw, n, idx)
+    assert (nl, nr) == (idx // 32 + 1, nw - idx // 32)
+    left, right = torch.empty(nl, dtype=torch.int64, device=dev), torch.empty(nr, dtype=torch.int64, device=dev)
+    ctx.split_packed_dev(words, nw, n, idx, left, right)
+    ctx.sync()
+    c, s = idx // 32, (idx % 32) * 2
+    wh = words[c - 1: c + 1001].cpu().numpy().view(np.uint64)
+    exp = [(int(wh[j + 1]) >> s) | ((int(wh[j]) << (64 - s)) & (2**64 - 1) if j else 0) for j in range(1000)]
+    assert [int(x) for x in right[:1000].cpu().numpy().view(np.uint64)] == exp
+    assert torch.equal(left[: c], words[: c]) and int(left[c]) == int(wh[1]) & ((1 << s) - 1)
+
+
 def test_analysis_full_scale(ctx, oracle):
     import torch
     dev = torch.device("cuda:0")

@@ -194,3 +194,32 @@ def test_analysis_vectors(oracle, golden):
     a, b = RNG.integers(0, 1 << 63, size=100, dtype=np.uint64), RNG.integers(0, 1 << 63, size=100, dtype=np.uint64)
     d = oracle.hdist_pairs(a, b, 31)
     assert all(int(d[i]) == oracle.hdist_scalar(int(a[i]), int(b[i]), 31) for i in range(100))
+
+
+def test_split_packed_vectors(oracle, golden):
+    from oracle_py import OracleError
+    for v in golden["split_packed"]:
+        s = v["seq"].encode()
+        lo, ro = oracle.split_packed(oracle.encode(s), len(s), v["idx"])
+        assert (lo.size, ro.size) == (v["n_left"], v["n_right"]), v["src"]
+        assert oracle.decode(lo, len(v["left"])).tobytes() == v["left"].encode(), v["src"]
+        assert oracle.decode(ro, len(v["right"])).tobytes() == v["right"].encode(), v["src"]
+    e = golden["split_packed_err"]
+    with pytest.raises(OracleError) as ei:
+        oracle.split_packed(oracle.encode(e["seq"].encode()), len(e["seq"]), e["idx"])
+    assert (ei.value.kind, ei.value.index, ei.value.value) == (e["status"], e["index"], e["length"])
+    # as written: a split inside the last word, or on a word boundary, gives the shifted sequence ...
+    s = rand_seq(200)
+    w = oracle.encode(s)
+    for idx in (32, 64, 160, 192, 195, 199):
+        lo, ro = oracle.split_packed(w, 200, idx)
+        assert oracle.decode(lo, idx).tobytes() == s[:idx].tobytes()
+        assert oracle.decode(ro, 200 - idx).tobytes() == s[idx:].tobytes()
+    # ... and a longer one with a shift carries the previous word's low bits (split.rs:84-94)
+    lo, ro = oracle.split_packed(w, 200, 5)
+    assert lo.size == 1 and ro.size == 7
+    assert int(ro[0]) == int(w[0]) >> 10 and int(ro[1]) == ((int(w[1]) >> 10) | ((int(w[0]) << 54) & (2**64 - 1)))
+    # a buffer that does not reach the split word panics (split.rs:78)
+    with pytest.raises(OracleError) as ei:
+        oracle.split_packed(w[:2], 200, 100)
+    assert ei.value.kind == "Panic"
