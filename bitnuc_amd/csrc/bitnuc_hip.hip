@@ -24,7 +24,6 @@ constexpr int kSlots = 4096;                    // data-error slots between two 
 constexpr size_t kHostChunk = (size_t)128 << 20; // bases per staged chunk on the host-pointer path
 
 struct Pending {
-    const uint8_t *src;        // device pointer the slot's byte index is relative to
     unsigned long long base;   // added to the slot's index (host path chunk offset)
 };
 
@@ -112,14 +111,10 @@ int drain(bitnuc_ctx *c, bitnuc_err *err) {
         if (c->h_slots[i] != kNoBad) { hit = i; break; }
     bitnuc_err found;
     memset(&found, 0, sizeof found);
-    if (hit >= 0) {
-        const unsigned long long idx = c->h_slots[hit];
-        uint8_t byte = 0;
-        HIPCHK(hipMemcpyAsync(&byte, c->pending[hit].src + idx, 1, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+    if (hit >= 0) { // slot = (byte index << 8) | byte, codec_device.h latch_bad
         found.status = BITNUC_INVALID_BASE;
-        found.byte = byte;
-        found.index = c->pending[hit].base + idx;
+        found.byte = (uint8_t)(c->h_slots[hit] & 0xFF);
+        found.index = c->pending[hit].base + (c->h_slots[hit] >> 8);
         HIPCHK(hipMemsetAsync(c->d_slots, 0xFF, sizeof(unsigned long long) * n, c->stream));
     }
     c->n_pending = 0;
@@ -140,14 +135,14 @@ int flush_pending(bitnuc_ctx *c, bitnuc_err *err) {
 }
 
 // Reserve the error slot of the next launch (drains implicitly when the ring is full).
-int take_slot(bitnuc_ctx *c, const uint8_t *src, unsigned long long base, unsigned long long **slot, bitnuc_err *err) {
+int take_slot(bitnuc_ctx *c, unsigned long long base, unsigned long long **slot, bitnuc_err *err) {
     if (c->n_pending == kSlots) {
         bitnuc_err e;
         int st = drain(c, &e);
         if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
         if (st != BITNUC_OK && !c->have_deferred) { c->have_deferred = true; c->deferred = e; }
     }
-    c->pending[c->n_pending] = Pending{src, base};
+    c->pending[c->n_pending] = Pending{base};
     *slot = c->d_slots + c->n_pending;
     c->n_pending++;
     return BITNUC_OK;
@@ -478,7 +473,7 @@ int bitnuc_encode_dev(bitnuc_ctx *c, const uint8_t *d_seq, size_t len, uint64_t 
     if (!d_seq || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
     unsigned long long *slot;
-    if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
     HIPCHK(launch_encode(c, d_seq, d_out, len, slot));
     return BITNUC_OK;
 }
@@ -508,7 +503,7 @@ int bitnuc_as_2bit_batch_dev(bitnuc_ctx *c, const uint8_t *d_kmers, size_t k, si
     }
     if (!d_kmers) return fail(err, BITNUC_UNSUPPORTED);
     unsigned long long *slot;
-    if (int st = take_slot(c, d_kmers, 0, &slot, err)) return st;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
     HIPCHK(launch_batch(c, d_kmers, k, stride, count, d_out, slot));
     return BITNUC_OK;
 }
@@ -521,7 +516,7 @@ int bitnuc_kmer_hdist_scan_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, si
     if (!d_ref || !d_dist) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
     unsigned long long *slot;
-    if (int st = take_slot(c, d_ref, 0, &slot, err)) return st;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
     HIPCHK(launch_scan(c, d_ref, n, k, query, d_dist, slot));
     return BITNUC_OK;
 }
@@ -610,7 +605,7 @@ int bitnuc_encode(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, 
         const size_t nw = (n + 31) / 32;
         HIPCHK(hipMemcpyAsync(c->scratch[0], seq + off, n, hipMemcpyHostToDevice, c->stream));
         unsigned long long *slot;
-        if (int st = take_slot(c, c->scratch[0], off, &slot, err)) return st;
+        if (int st = take_slot(c, off, &slot, err)) return st;
         HIPCHK(launch_encode(c, c->scratch[0], reinterpret_cast<uint64_t *>(c->scratch[1]), n, slot));
         HIPCHK(hipMemcpyAsync(out + off / 32, c->scratch[1], nw * 8, hipMemcpyDeviceToHost, c->stream));
         // the chunk's slot must be resolved before scratch[0] is overwritten (its byte is read back from there)
@@ -668,7 +663,7 @@ int bitnuc_as_2bit_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t s
         const size_t bytes = (m - 1) * stride + k;
         HIPCHK(hipMemcpyAsync(c->scratch[0], kmers + j0 * stride, bytes, hipMemcpyHostToDevice, c->stream));
         unsigned long long *slot;
-        if (int st = take_slot(c, c->scratch[0], (unsigned long long)j0 * stride, &slot, err)) return st;
+        if (int st = take_slot(c, (unsigned long long)j0 * stride, &slot, err)) return st;
         HIPCHK(launch_batch(c, c->scratch[0], k, stride, m, reinterpret_cast<uint64_t *>(c->scratch[1]), slot));
         HIPCHK(hipMemcpyAsync(out + j0, c->scratch[1], m * 8, hipMemcpyDeviceToHost, c->stream));
         bitnuc_err e;
@@ -695,7 +690,7 @@ int bitnuc_kmer_hdist_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k
         const size_t bytes = w + k - 1;
         HIPCHK(hipMemcpyAsync(c->scratch[0], ref + off, bytes, hipMemcpyHostToDevice, c->stream));
         unsigned long long *slot;
-        if (int st = take_slot(c, c->scratch[0], off, &slot, err)) return st;
+        if (int st = take_slot(c, off, &slot, err)) return st;
         HIPCHK(launch_scan(c, c->scratch[0], bytes, k, query, c->scratch[2], slot));
         HIPCHK(hipMemcpyAsync(dist + off, c->scratch[2], w, hipMemcpyDeviceToHost, c->stream));
         bitnuc_err e;
@@ -799,7 +794,7 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t 
     const TileRec *recs;
     if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
     unsigned long long *slot;
-    if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
     const size_t per_block = (size_t)kBatchTile * kBatchWaves * kBatchInFlight;
     const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
     if (c->batch_stream)
@@ -900,7 +895,7 @@ int bitnuc_encode_fixed_dev(bitnuc_ctx *c, const uint8_t *d_seq, size_t read_len
     const unsigned wpr = (unsigned)((read_len + 31) / 32);
     const unsigned long long total = (unsigned long long)count * wpr;
     unsigned long long *slot;
-    if (int st = take_slot(c, d_seq, 0, &slot, err)) return st;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
     const size_t per_block = (size_t)kBatchTile * kBatchWaves;
     const unsigned grid = grid_for(c, (total + per_block - 1) / per_block);
     unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);

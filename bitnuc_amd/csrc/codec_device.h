@@ -17,7 +17,7 @@
 //     same word carries the code (bits 0-1) and the validity residue (bits 2-7);
 //     v_dot4_u32_u8 with weights {1,4,16,64} compacts 4 codes into one byte;
 //   * an invalid byte is rare: lanes that see a residue take a slow path that
-//     atomicMin's the absolute byte index into a per-launch slot, which gives the
+//     atomicMin's (absolute byte index << 8 | byte) into a per-launch slot, which gives the
 //     reference's "first invalid byte in sequence order" (avx.rs:86-91) without
 //     serialising the stream;
 //   * optional wave-private LDS transpose (XPOSE) turns 4 coalesced 4-byte
@@ -71,12 +71,19 @@ __device__ __forceinline__ uint32_t code_of(uint32_t b) { return ((b >> 1) ^ (b 
 // slow path (rare): re-read `nbytes` bytes starting at absolute index `start` and latch
 // the first invalid one.  One non-unrolled copy per kernel keeps the hot loop's
 // register/SGPR footprint small.
+// The slot holds (absolute byte index << 8) | offending byte: atomicMin orders by index, and the
+// byte travels with it, so reporting never has to re-read an input the caller may have reused.
+__device__ __forceinline__ void latch_bad(unsigned long long *slot, unsigned long long index, uint32_t byte) {
+    atomicMin(slot, (index << 8) | (byte & 0xFFu));
+}
+
 __device__ __forceinline__ void rescan_bytes(const uint8_t *seq, unsigned long long start, unsigned nbytes,
                                              unsigned long long *slot) {
 #pragma unroll 1
     for (unsigned i = 0; i < nbytes; ++i) {
-        if (!valid_base(seq[start + i])) {
-            atomicMin(slot, start + i);
+        const uint32_t b = seq[start + i];
+        if (!valid_base(b)) {
+            latch_bad(slot, start + i, b);
             return;
         }
     }
@@ -229,7 +236,7 @@ encode_kernel(const uint8_t *__restrict__ seq, uint32_t *__restrict__ out32, uns
                 for (unsigned i = 0; i < rem; ++i) {
                     const uint32_t b = seq[(n16 << 4) + i];
                     if (!valid_base(b) && !flagged) {
-                        atomicMin(slot, (n16 << 4) + i);
+                        latch_bad(slot, (n16 << 4) + i, b);
                         flagged = true;
                     }
                     r |= code_of(b) << (2 * i);
@@ -283,7 +290,7 @@ encode_ballot_kernel(const uint8_t *__restrict__ seq, unsigned long long *__rest
             const uint32_t c = code_of(b[u]);
             const unsigned long long p0 = __ballot(c & 1u), p1 = __ballot(c >> 1);
             const unsigned long long invalid = __ballot(!valid_base(b[u]));
-            if (invalid && lane == 0) atomicMin(slot, base + (unsigned long long)__builtin_ctzll(invalid));
+            if (invalid && lane == (unsigned)__builtin_ctzll(invalid)) latch_bad(slot, base + lane, b[u]); // the first invalid lane reports its own byte
             const unsigned long long w0 = morton_spread32(p0) | (morton_spread32(p1) << 1);
             const unsigned long long w1 = morton_spread32(p0 >> 32) | (morton_spread32(p1 >> 32) << 1);
             if (lane == 0) {

@@ -87,7 +87,7 @@ kmer_batch_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
         if (__builtin_expect(residue_is_bad(bad), 0)) {
             for (unsigned b = 0; b < k; ++b) {
                 const uint32_t byte = (x[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                if (!valid_base(byte)) { atomicMin(slot, index_base + j * stride + b); break; }
+                if (!valid_base(byte)) { latch_bad(slot, index_base + j * stride + b, byte); break; }
             }
         }
         out[j] = ((unsigned long long)hi << 32) | lo;
@@ -251,7 +251,7 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
         bool flagged = false;
         for (unsigned b = 0; b < k; ++b) {
             const uint32_t byte = ref[i + b];
-            if (!valid_base(byte) && !flagged) { atomicMin(slot, i + b); flagged = true; }
+            if (!valid_base(byte) && !flagged) { latch_bad(slot, i + b, byte); flagged = true; }
             w |= (unsigned long long)code_of(byte) << (2 * b);
         }
         const unsigned long long x = (w ^ query) & kmask;

@@ -676,6 +676,33 @@ def test_hdist_pairs_and_query(ctx, oracle):
     assert ei.value.kind == "InvalidLength" and ei.value.len == 33
 
 
+def test_invalid_base_reported_after_input_is_overwritten(ctx):
+    """The latched error carries the byte itself: the input may be reused before the sync."""
+    import torch
+    import bitnuc_amd as bn
+    dev = torch.device("cuda:0")
+    n = 1_000_003
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, n, 7)
+    ctx.sync()
+    seq[777_777] = ord("N")
+    seq[900_000] = ord("X")
+    torch.cuda.synchronize()
+    words = torch.empty((n + 31) // 32, dtype=torch.int64, device=dev)
+    dist = torch.empty(n - 30, dtype=torch.uint8, device=dev)
+    launches = [lambda t: ctx.encode_dev(t, n, words), lambda t: ctx.kmer_hdist_scan_dev(t, n, 31, 0, dist),
+                lambda t: ctx.as_2bit_batch_dev(t, 31, 31, n // 31, words), lambda t: ctx.as_2bit_batch_dev(t, 31, 37, n // 37, words),
+                lambda t: ctx.encode_fixed_dev(t, 150, 151, n // 151, words)]
+    for launch in launches:
+        work = seq.clone()
+        torch.cuda.synchronize()
+        launch(work)
+        ctx.nucgen_dev(work, n, 9)  # stream-ordered overwrite of the input, before anything is reported
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.sync()
+        assert (ei.value.kind, ei.value.byte, ei.value.index) == ("InvalidBase", ord("N"), 777_777)
+
+
 def test_split_packed_golden(ctx, oracle, golden):
     import bitnuc_amd as bn
     for canonical in (False, True):
