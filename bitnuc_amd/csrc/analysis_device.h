@@ -22,7 +22,8 @@ __device__ __forceinline__ void count_word(unsigned long long w, uint32_t &c, ui
 
 __global__ void __launch_bounds__(kBlock)
 base_counts_kernel(const unsigned long long *__restrict__ words, unsigned long long n_bases,
-                   unsigned long long *__restrict__ counts /* [A,C,G,T], pre-zeroed */) {
+                   unsigned long long *__restrict__ counts /* [A,C,G,T] */, unsigned long long *__restrict__ acc /* C,G,T: zero between launches */,
+                   unsigned *__restrict__ ticket) {
     const unsigned long long full = n_bases >> 5;
     const unsigned rem = (unsigned)(n_bases & 31);
     const unsigned long long gt = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
@@ -60,13 +61,16 @@ base_counts_kernel(const unsigned long long *__restrict__ words, unsigned long l
     if (threadIdx.x < 3) {
         unsigned long long s = 0;
         for (int i = 0; i < kBlock / 64; ++i) s += part[i][threadIdx.x];
-        if (s) atomicAdd(counts + 1 + threadIdx.x, s);
+        if (s) add_performed(acc + threadIdx.x, s);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counts, n_bases); // A = n - C - G - T, fixed up below
-}
-
-__global__ void base_counts_finish(unsigned long long *__restrict__ counts) {
-    counts[0] -= counts[1] + counts[2] + counts[3];
+    __syncthreads();
+    if (threadIdx.x == 0 && draw_last_ticket(ticket)) {
+        const unsigned long long cs = atomicExch(acc, 0ull), gs = atomicExch(acc + 1, 0ull), ts = atomicExch(acc + 2, 0ull);
+        counts[0] = n_bases - (cs + gs + ts); // A: the zero padding of the last word is not a base
+        counts[1] = cs;
+        counts[2] = gs;
+        counts[3] = ts;
+    }
 }
 
 // one lane -> 4 consecutive words (two dwordx4 loads per operand) -> 4 distance bytes (one dword store)

@@ -43,6 +43,9 @@ struct bitnuc_ctx {
     uint8_t *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[6] = {0, 0, 0, 0, 0, 0};
     uint32_t *d_sink = nullptr;
+    unsigned long long *d_acc = nullptr; // accumulators of the single-launch reductions, zero between launches: [0..2] base_counts C,G,T; [4] hdist (u32)
+    unsigned *d_tickets = nullptr;       // [0] base_counts, [1] hdist: arrival counters, zero between launches
+    unsigned reduce_blocks = 2048;
     int enc_variant = 14, dec_variant = 22; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
@@ -158,6 +161,8 @@ unsigned grid_for(const bitnuc_ctx *c, unsigned long long tiles, int block = kBl
     if (cap == 0) cap = 1;
     return (unsigned)(tiles < cap ? tiles : cap);
 }
+
+inline size_t words_for(size_t n_bases) { return n_bases / 32 + (n_bases % 32 != 0); } // ceil(n/32) without overflow
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -378,7 +383,7 @@ int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, 
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail_hip(err, hipErrorInvalidDevice);
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard g(device);
     bitnuc_ctx *c = new bitnuc_ctx();
     c->device = device;
     c->stream = static_cast<hipStream_t>(hip_stream);
@@ -391,6 +396,11 @@ int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, 
     if (rc == hipSuccess) rc = hipMalloc(&c->d_sink, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_slots, 0xFF, sizeof(unsigned long long) * kSlots);
     if (rc == hipSuccess) rc = hipMemset(c->d_sink, 0, 64);
+    c->reduce_blocks = (unsigned)c->num_cu * 8; // a resident grid: 8 workgroups of 256 threads per CU
+    if (rc == hipSuccess) rc = hipMalloc(&c->d_acc, 64);
+    if (rc == hipSuccess) rc = hipMemset(c->d_acc, 0, 64);
+    if (rc == hipSuccess) rc = hipMalloc(&c->d_tickets, 64);
+    if (rc == hipSuccess) rc = hipMemset(c->d_tickets, 0, 64);
     if (rc != hipSuccess) {
         bitnuc_ctx_destroy(c);
         return fail_hip(err, rc);
@@ -406,7 +416,7 @@ int bitnuc_ctx_create(int device, bitnuc_ctx **out, bitnuc_err *err) {
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail_hip(err, hipErrorInvalidDevice);
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard g(device);
     hipStream_t s = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     int st = bitnuc_ctx_create_on_stream(device, s, out, err);
@@ -417,13 +427,15 @@ int bitnuc_ctx_create(int device, bitnuc_ctx **out, bitnuc_err *err) {
 
 void bitnuc_ctx_destroy(bitnuc_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard g(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 6; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->h_slots) (void)hipHostFree(c->h_slots);
     if (c->d_sink) (void)hipFree(c->d_sink);
+    if (c->d_acc) (void)hipFree(c->d_acc);
+    if (c->d_tickets) (void)hipFree(c->d_tickets);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -482,7 +494,7 @@ int bitnuc_decode_dev(bitnuc_ctx *c, const uint64_t *d_ebuf, size_t n_words, siz
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
     // unpacking/mod.rs:40-45: missing words -> InvalidLength(n_bases)
-    if (n_words < (n_bases + 31) / 32) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (n_words < words_for(n_bases)) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
     if (n_bases == 0) return BITNUC_OK; // unpacking/avx.rs:134-145: nothing appended
     if (!d_ebuf || !d_out || (reinterpret_cast<uintptr_t>(d_ebuf) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
@@ -524,18 +536,19 @@ int bitnuc_kmer_hdist_scan_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, si
 int bitnuc_hdist_dev(bitnuc_ctx *c, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, size_t n_bases, uint32_t *d_result, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
-    const size_t need = (n_bases + 31) / 32;
+    const size_t need = words_for(n_bases);
     if (na < need || nb < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases); // hamming/multi.rs:124-127
     if (!d_result) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    HIPCHK(hipMemsetAsync(d_result, 0, sizeof(uint32_t), c->stream));
-    if (n_bases == 0) return BITNUC_OK;
+    if (n_bases == 0) {
+        HIPCHK(hipMemsetAsync(d_result, 0, sizeof(uint32_t), c->stream));
+        return BITNUC_OK;
+    }
     if (!d_a || !d_b) return fail(err, BITNUC_UNSUPPORTED);
-    unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1; // resident grid: one atomic per workgroup
-    const unsigned long long cap = (unsigned long long)c->num_cu * 8;
-    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+    const unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1;
+    const unsigned grid = (unsigned)(tiles < c->reduce_blocks ? tiles : c->reduce_blocks);
     hdist_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
-                                                 reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result);
+                                                 reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result, reinterpret_cast<unsigned *>(c->d_acc + 4), c->d_tickets + 1);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
@@ -599,16 +612,16 @@ int bitnuc_encode(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, 
     if (int st = flush_pending(c, err)) return st;
     const size_t chunk = len < kHostChunk ? len : kHostChunk;
     if (int st = ensure_scratch(c, 0, chunk + 16, err)) return st;
-    if (int st = ensure_scratch(c, 1, ((chunk + 31) / 32) * 8 + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, words_for(chunk) * 8 + 16, err)) return st;
     for (size_t off = 0; off < len; off += chunk) {
         const size_t n = len - off < chunk ? len - off : chunk;
-        const size_t nw = (n + 31) / 32;
+        const size_t nw = words_for(n);
         HIPCHK(hipMemcpyAsync(c->scratch[0], seq + off, n, hipMemcpyHostToDevice, c->stream));
         unsigned long long *slot;
         if (int st = take_slot(c, off, &slot, err)) return st;
         HIPCHK(launch_encode(c, c->scratch[0], reinterpret_cast<uint64_t *>(c->scratch[1]), n, slot));
         HIPCHK(hipMemcpyAsync(out + off / 32, c->scratch[1], nw * 8, hipMemcpyDeviceToHost, c->stream));
-        // the chunk's slot must be resolved before scratch[0] is overwritten (its byte is read back from there)
+        // the call is synchronous and stops at the first failing chunk (the words before it are the caller's)
         bitnuc_err e;
         int st = drain(c, &e);
         if (st != BITNUC_OK) {
@@ -617,23 +630,23 @@ int bitnuc_encode(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, 
             return st;
         }
     }
-    if (n_words) *n_words = (len + 31) / 32;
+    if (n_words) *n_words = words_for(len);
     return BITNUC_OK;
 }
 
 int bitnuc_decode(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_words, size_t n_bases, uint8_t *out, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
-    if (n_words < (n_bases + 31) / 32) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (n_words < words_for(n_bases)) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
     if (n_bases == 0) return BITNUC_OK;
     if (!ebuf || !out) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
     const size_t chunk = n_bases < kHostChunk ? n_bases : kHostChunk;
     if (int st = ensure_scratch(c, 0, chunk + 16, err)) return st;
-    if (int st = ensure_scratch(c, 1, ((chunk + 31) / 32) * 8 + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, words_for(chunk) * 8 + 16, err)) return st;
     for (size_t off = 0; off < n_bases; off += chunk) {
         const size_t n = n_bases - off < chunk ? n_bases - off : chunk;
-        const size_t nw = (n + 31) / 32;
+        const size_t nw = words_for(n);
         HIPCHK(hipMemcpyAsync(c->scratch[1], ebuf + off / 32, nw * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(launch_decode(c, reinterpret_cast<const uint64_t *>(c->scratch[1]), c->scratch[0], n));
         HIPCHK(hipMemcpyAsync(out + off, c->scratch[0], n, hipMemcpyDeviceToHost, c->stream));
@@ -703,7 +716,7 @@ int bitnuc_kmer_hdist_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k
 int bitnuc_hdist(bitnuc_ctx *c, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, size_t n_bases, uint32_t *out, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
-    const size_t need = (n_bases + 31) / 32;
+    const size_t need = words_for(n_bases);
     if (na < need || nb < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
     if (!out) return fail(err, BITNUC_UNSUPPORTED);
     if (n_bases == 0) { *out = 0; return BITNUC_OK; }
@@ -892,7 +905,7 @@ int bitnuc_encode_fixed_dev(bitnuc_ctx *c, const uint8_t *d_seq, size_t read_len
     if (stride < read_len || read_len > 0xFFFFFFFFull - 64) return fail(err, BITNUC_UNSUPPORTED);
     if (!d_seq || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const unsigned wpr = (unsigned)((read_len + 31) / 32);
+    const unsigned wpr = (unsigned)words_for(read_len);
     const unsigned long long total = (unsigned long long)count * wpr;
     unsigned long long *slot;
     if (int st = take_slot(c, 0, &slot, err)) return st;
@@ -914,7 +927,7 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
     if (stride < read_len || read_len > 0xFFFFFFFFull - 64) return fail(err, BITNUC_UNSUPPORTED);
     if (!d_words || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const unsigned wpr = (unsigned)((read_len + 31) / 32);
+    const unsigned wpr = (unsigned)words_for(read_len);
     const unsigned long long total = (unsigned long long)count * wpr;
     const size_t per_block = (size_t)kBatchTile * kBatchWaves;
     const unsigned grid = grid_for(c, (total + per_block - 1) / per_block);
@@ -933,7 +946,7 @@ int bitnuc_encode_fixed(bitnuc_ctx *c, const uint8_t *seq, size_t read_len, size
     if (stride < read_len || !seq || !out) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
     if (int st = flush_pending(c, err)) return st;
-    const size_t wpr = (read_len + 31) / 32;
+    const size_t wpr = words_for(read_len);
     size_t per = kHostChunk / stride; // reads per staged chunk
     if (per == 0) per = 1;
     if (per > count) per = count;
@@ -959,7 +972,7 @@ int bitnuc_decode_fixed(bitnuc_ctx *c, const uint64_t *words, size_t read_len, s
     if (count == 0 || read_len == 0) return BITNUC_OK;
     if (stride < read_len || !words || !out) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const size_t wpr = (read_len + 31) / 32;
+    const size_t wpr = words_for(read_len);
     size_t per = kHostChunk / stride;
     if (per == 0) per = 1;
     if (per > count) per = count;
@@ -982,16 +995,17 @@ int bitnuc_decode_fixed(bitnuc_ctx *c, const uint64_t *words, size_t read_len, s
 int bitnuc_base_counts_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t n_words, size_t n_bases, uint64_t *d_counts, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
-    if (n_words < (n_bases + 31) / 32) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (n_words < words_for(n_bases)) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
     if (!d_counts || (n_bases && (!d_words || (reinterpret_cast<uintptr_t>(d_words) & 7)))) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    HIPCHK(hipMemsetAsync(d_counts, 0, 4 * sizeof(uint64_t), c->stream));
-    if (n_bases == 0) return BITNUC_OK;
-    const unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1, cap = (unsigned long long)c->num_cu * 8;
-    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap); // resident grid: 3 atomics per workgroup
+    if (n_bases == 0) {
+        HIPCHK(hipMemsetAsync(d_counts, 0, 4 * sizeof(uint64_t), c->stream));
+        return BITNUC_OK;
+    }
+    const unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1;
+    const unsigned grid = (unsigned)(tiles < c->reduce_blocks ? tiles : c->reduce_blocks);
     base_counts_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words), n_bases,
-                                                       reinterpret_cast<unsigned long long *>(d_counts));
-    base_counts_finish<<<1, 1, 0, c->stream>>>(reinterpret_cast<unsigned long long *>(d_counts));
+                                                       reinterpret_cast<unsigned long long *>(d_counts), c->d_acc, c->d_tickets);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
@@ -999,7 +1013,7 @@ int bitnuc_base_counts_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t n_word
 int bitnuc_base_counts(bitnuc_ctx *c, const uint64_t *words, size_t n_words, size_t n_bases, uint64_t counts[4], bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
-    const size_t need = (n_bases + 31) / 32;
+    const size_t need = words_for(n_bases);
     if (n_words < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
     if (!counts || (n_bases && !words)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
@@ -1088,7 +1102,7 @@ int split_plan(size_t n_words, size_t slen, size_t idx, int flags, SplitPlan *p,
         if (err) err->index = idx;
         return BITNUC_INDEX_OUT_OF_BOUNDS;
     }
-    const size_t need = slen / 32 + (slen % 32 != 0);
+    const size_t need = words_for(slen);
     p->c = idx / 32;
     p->s = (unsigned)(idx % 32) * 2;
     if (flags == BITNUC_SPLIT_CANONICAL) {

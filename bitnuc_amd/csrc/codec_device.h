@@ -89,6 +89,25 @@ __device__ __forceinline__ void rescan_bytes(const uint8_t *seq, unsigned long l
     }
 }
 
+// Single-launch grid reductions: every workgroup adds its partial to context-owned accumulators
+// with device-scope atomics (performed at the coherence point, so they need no cache fences --
+// an agent-scope __threadfence() per workgroup costs an L2 write-back and made these kernels 5x
+// slower), then one thread draws a ticket; whoever draws the last one swaps the accumulators
+// back to zero (ready for the next launch on the stream) and writes the result.  No memset
+// before, no finishing launch after.
+// Call draw_last_ticket from ONE thread, after a __syncthreads() that follows the workgroup's
+// add_performed() calls.
+template <class T> __device__ __forceinline__ void add_performed(T *acc, T v) {
+    const T prev = atomicAdd(acc, v); // returning form: the value can only arrive once the add has been performed
+    if constexpr (sizeof(T) == 8) asm volatile("" ::"v"((uint32_t)prev), "v"((uint32_t)(prev >> 32)));
+    else asm volatile("" ::"v"(prev));
+}
+__device__ __forceinline__ bool draw_last_ticket(unsigned *ticket) {
+    if (atomicAdd(ticket, 1u) != gridDim.x - 1) return false;
+    atomicExch(ticket, 0u);
+    return true;
+}
+
 // 8 bits (4 codes) -> 4 ASCII bytes.
 __device__ __forceinline__ uint32_t dec4(uint32_t v) {
     uint32_t s = (v | (v << 12)) & 0x000F000Fu;

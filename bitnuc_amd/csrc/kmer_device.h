@@ -264,10 +264,11 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 hdist_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
-             unsigned long long n_bases, uint32_t *__restrict__ result) {
+             unsigned long long n_bases, uint32_t *__restrict__ result, unsigned *__restrict__ total /* zero between launches */,
+             unsigned *__restrict__ ticket) {
     // 16 B algorithmic per 32-base word pair.  Grid-stride over word PAIRS with dwordx4
     // loads when both buffers are 16-byte aligned, u64 loads otherwise; a fixed, resident
-    // grid keeps the number of same-address atomics to one per workgroup (~2048).
+    // grid adds one partial per workgroup to a context-owned accumulator; the last to finish publishes it.
     const unsigned long long full = n_bases >> 5;
     const unsigned rem = (unsigned)(n_bases & 31);
     const unsigned long long gt = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
@@ -303,7 +304,8 @@ hdist_kernel(const unsigned long long *__restrict__ a, const unsigned long long 
     if (threadIdx.x == 0) {
         uint32_t s = 0;
         for (int i = 0; i < kBlock / 64; ++i) s += part[i];
-        if (s) atomicAdd(result, s);
+        if (s) add_performed(total, s); // u32 wrap-around like the reference's accumulator (multi.rs:130)
+        if (draw_last_ticket(ticket)) *result = atomicExch(total, 0u);
     }
 }
 
