@@ -373,7 +373,7 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
                     unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     constexpr int U = kBatchInFlight;
     __shared__ BatchLds lds[kBatchWaves][U];
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
     const unsigned long long seq_end = offsets[count]; // end of the sequence buffer: bounds the 2 KiB tile fetch
     for (unsigned long long t0 = ((unsigned long long)blockIdx.x * kBatchWaves + wave) * U; t0 < ntiles;
@@ -496,10 +496,10 @@ encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned
                     unsigned long long total_words, unsigned long long seq_end /* bytes in the buffer */, int use_stream,
                     unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     __shared__ BatchLds lds[kBatchWaves];
-    BatchLds &my = lds[threadIdx.x >> 6];
+    BatchLds &my = lds[wave_in_block()];
     const unsigned lane = threadIdx.x & 63;
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
-    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + (threadIdx.x >> 6); tile < ntiles;
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave_in_block(); tile < ntiles;
          tile += (unsigned long long)gridDim.x * kBatchWaves) {
         const unsigned long long wb = tile * kBatchTile, w = wb + lane;
         const bool active = w < total_words;
@@ -575,10 +575,10 @@ __global__ void __launch_bounds__(kBlock)
 decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned long long stride, unsigned wpr,
                     unsigned magic, unsigned long long total_words, uint8_t *__restrict__ out) {
     __shared__ BatchLds lds[kBatchWaves];
-    BatchLds &my = lds[threadIdx.x >> 6];
+    BatchLds &my = lds[wave_in_block()];
     const unsigned lane = threadIdx.x & 63;
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
-    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + (threadIdx.x >> 6); tile < ntiles;
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave_in_block(); tile < ntiles;
          tile += (unsigned long long)gridDim.x * kBatchWaves) {
         const unsigned long long wb = tile * kBatchTile, w = wb + lane;
         const bool active = w < total_words;

@@ -89,6 +89,11 @@ __device__ __forceinline__ void rescan_bytes(const uint8_t *seq, unsigned long l
     }
 }
 
+// threadIdx.x >> 6 is the same in all lanes of a wave; reading it through readfirstlane tells the
+// compiler, so everything derived from it (tile index, tile base address, record loads) is
+// computed once on the scalar unit instead of per lane in 64-bit VALU arithmetic.
+__device__ __forceinline__ unsigned wave_in_block() { return (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // Single-launch grid reductions: every workgroup adds its partial to context-owned accumulators
 // with device-scope atomics (performed at the coherence point, so they need no cache fences --
 // an agent-scope __threadfence() per workgroup costs an L2 write-back and made these kernels 5x

@@ -110,7 +110,7 @@ kmer_dense_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
                   unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     __shared__ uint32_t strips[kBlock / 64][UNROLL][132];
     const unsigned lane = threadIdx.x & 63;
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; // blockDim <= kBlock
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block(); // blockDim <= kBlock
     const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
     const unsigned ngroups = 4 * k; // 16-byte groups per 64 k-mers
     const unsigned bit = 2 * k * lane, d = bit >> 5, sh = bit & 31;
@@ -132,7 +132,7 @@ kmer_dense_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
         for (int u = 0; u < UNROLL; ++u) {
             if (it0 + u >= nwave_items) break; // wave-uniform
             const unsigned long long it = it0 + u;
-            uint32_t *ws = strips[threadIdx.x >> 6][u];
+            uint32_t *ws = strips[wave_in_block()][u];
             uint32_t bad = 0;
             ws[lane] = enc16(v0[u], bad);
             ws[lane + 64] = enc16(v1[u], bad);
@@ -164,7 +164,7 @@ kmer_dense_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
 // the 30-base halo, so there is no separate halo load and consecutive waves overlap by
 // 32 bytes (3 % re-read, served by L2).  Per lane: 16 bases -> two 16-bit planes
 // (v_perm LUT + validity residue as in enc4, v_dot4 with weights {1,2,4,8} gathers one bit
-// per byte), planes of lanes l+1, l+2 arrive by two lane shifts, window j is a
+// per byte, chained over two dwords), planes of lanes l+1, l+2 arrive by two lane shifts, window j is a
 // v_alignbit_b32 of each plane pair by j.  16 distance bytes per lane, one dwordx4 store.
 // Needs bytes [wb, wb+1024) in bounds; the leftover windows go through the tail loop.
 constexpr unsigned kScanWaveWindows = 992;
@@ -174,13 +174,15 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
 }
 
-__device__ __forceinline__ void planes4(uint32_t x, uint32_t &bad, uint32_t &lnib, uint32_t &hnib2) {
-    const uint32_t sel = x & 0x07070707u;
-    const uint32_t t = __builtin_amdgcn_perm(0x42040453u, 0x41044004u, sel); // same LUT as enc4
-    const uint32_t dd = t ^ (x & 0xD8D8D8D8u);
-    bad |= dd;
-    lnib = __builtin_amdgcn_udot4(dd & 0x01010101u, 0x08040201u, 0u, false);  // low code bits of 4 bases
-    hnib2 = __builtin_amdgcn_udot4(dd & 0x02020202u, 0x08040201u, 0u, false); // 2 x (high code bits)
+// 8 bases (two dwords) -> 8 low-plane bits and 2 x 8 high-plane bits: the second v_dot4 carries
+// weights {16,32,64,128} and accumulates onto the first, so no shift/or is needed to join nibbles.
+__device__ __forceinline__ void planes8(uint32_t x0, uint32_t x1, uint32_t &bad, uint32_t &l8, uint32_t &h8x2) {
+    const uint32_t t0 = __builtin_amdgcn_perm(0x42040453u, 0x41044004u, x0 & 0x07070707u);
+    const uint32_t t1 = __builtin_amdgcn_perm(0x42040453u, 0x41044004u, x1 & 0x07070707u);
+    const uint32_t d0 = t0 ^ (x0 & 0xD8D8D8D8u), d1 = t1 ^ (x1 & 0xD8D8D8D8u);
+    bad |= d0 | d1;
+    l8 = __builtin_amdgcn_udot4(d1 & 0x01010101u, 0x80402010u, __builtin_amdgcn_udot4(d0 & 0x01010101u, 0x08040201u, 0u, false), false);
+    h8x2 = __builtin_amdgcn_udot4(d1 & 0x02020202u, 0x80402010u, __builtin_amdgcn_udot4(d0 & 0x02020202u, 0x08040201u, 0u, false), false);
 }
 
 template <bool ALIGNED, bool NTLD, bool NTST, int UNROLL>
@@ -190,7 +192,8 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
     const unsigned long long nwin = n - k + 1; // host guarantees 1 <= k <= 32, n >= k
     const unsigned long long rounds = n >= 1024 ? (n - 1024) / kScanWaveWindows + 1 : 0;
     const unsigned lane = threadIdx.x & 63;
-    const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; // blockDim <= kBlock
+    // scalar wave index: the per-round 64-bit address arithmetic becomes scalar ops + one constant lane offset
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block(); // blockDim <= kBlock
     const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
     // ql / qh: the query's bit-planes (bit i = low / high code bit of base i), split on the host
     const uint32_t km = k == 32 ? ~0u : ((1u << k) - 1u);
@@ -207,14 +210,10 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
         for (int u = 0; u < UNROLL; ++u) {
             if (r0 + u >= rounds) break; // wave-uniform
             const unsigned long long wb = (r0 + u) * kScanWaveWindows;
-            uint32_t bad = 0, l0, l1, l2, l3, h0, h1, h2, h3;
-            planes4(v[u].x, bad, l0, h0);
-            planes4(v[u].y, bad, l1, h1);
-            planes4(v[u].z, bad, l2, h2);
-            planes4(v[u].w, bad, l3, h3);
-            const uint32_t L16 = l0 | (l1 << 4) | (l2 << 8) | (l3 << 12);
-            const uint32_t H16x2 = h0 | (h1 << 4) | (h2 << 8) | (h3 << 12);
-            const uint32_t pl = L16 | (H16x2 << 15); // low half: L plane, high half: H plane (16 bases)
+            uint32_t bad = 0, la, lb, ha, hb;
+            planes8(v[u].x, v[u].y, bad, la, ha);
+            planes8(v[u].z, v[u].w, bad, lb, hb);
+            const uint32_t pl = (la | (lb << 8)) | ((ha | (hb << 8)) << 15); // low half: L plane, high half: H plane (16 bases)
             if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(ref, wb + 16 * lane, 16, slot);
             // planes of lanes l+1 and l+2: whole-wave DPP shifts (v_mov_b32 wave_shl:1), no LDS round trip
             const uint32_t n1 = wave_shl1(pl), n2 = wave_shl1(n1);
