@@ -754,6 +754,7 @@ def test_split_packed_vs_oracle(ctx, oracle):
             nl, nr = ctx.split_packed_sizes(w.size, n, idx, canonical=canonical)
             for off in (0, 1):  # all operands misaligned, then only the source
                 lt, rt = torch.zeros(nl + 1, dtype=torch.int64, device=dev), torch.zeros(nr + 1, dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()  # the fills run on torch's stream, the split on the context's
                 ctx.split_packed_dev(buf[1:], w.size, n, idx, lt[1 - off:], rt[1 - off:], canonical=canonical)
                 ctx.sync()
                 got_l = lt[1 - off: 1 - off + nl].cpu().numpy().view(np.uint64)
@@ -1032,6 +1033,32 @@ def test_fixed_reads_vs_oracle_loop(ctx, oracle, read_len, stride):
     with pytest.raises(bn.NucleotideError) as ei:
         ctx.encode_fixed(buf, read_len, stride, count)
     assert (ei.value.byte, ei.value.index) == (ord("N"), pos)
+
+
+def test_decode_fixed_contiguous_every_alignment(ctx, oracle):
+    """Back-to-back reads: whole output compared, at several output alignments, with junk in the pad bits of each
+    read's last word, and with guard bytes around the run."""
+    import torch
+    dev = torch.device("cuda:0")
+    if True:
+        for read_len, count in [(16, 700), (17, 333), (31, 500), (32, 129), (33, 257), (47, 100), (64, 65), (100, 1001), (150, 777),
+                                (250, 300), (2048, 9), (2049, 9), (5000, 7), (100003, 3), (20, 1), (150, 1)]:
+            wpr = (read_len + 31) // 32
+            seq = rand_seq(read_len * count, ALPHA)
+            words = np.stack([oracle.encode(seq[r * read_len:(r + 1) * read_len]) for r in range(count)]).reshape(-1).copy()
+            rem = read_len % 32
+            if rem:  # bits above a read's last base are ignored by decode (from_2bit's expected_size semantics)
+                words[wpr - 1::wpr] |= np.uint64((0xDEADBEEFCAFEF00D << (2 * rem)) & (2**64 - 1))
+            d_words = torch.from_numpy(words.view(np.int64)).to(dev)
+            for a in (0, 1, 7, 8, 15):
+                buf = torch.full((read_len * count + 64,), ord("#"), dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()  # the fill runs on torch's stream, the decode on the context's
+                ctx.decode_fixed_dev(d_words, read_len, read_len, count, buf[16 + a:])
+                ctx.sync()
+                got = buf.cpu().numpy()
+                assert bytes(got[:16 + a]) == b"#" * (16 + a), (read_len, count, a)
+                assert bytes(got[16 + a + read_len * count:]) == b"#" * (48 - a), (read_len, count, a)
+                assert np.array_equal(got[16 + a: 16 + a + read_len * count], seq), (read_len, count, a)
 
 
 def test_fixed_reads_full_scale(ctx, oracle):
