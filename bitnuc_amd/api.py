@@ -233,6 +233,8 @@ class Context:
         stride = k if stride is None else stride
         if count is None:
             count = 0 if s.size < k else (s.size - k) // stride + 1
+        elif count and 0 < k <= 32 and (count - 1) * stride + k > s.size:  # the C ABI trusts the caller's sizes
+            raise ValueError("kmers holds fewer than (count-1)*stride + k bytes")
         out = np.empty(count, dtype=np.uint64)
         err = L.BitnucErr()
         if self._lib.bitnuc_as_2bit_batch(self._h, _ptr(s), int(k), int(stride), int(count), _ptr(out), C.byref(err)) != L.OK:
@@ -334,6 +336,8 @@ class Context:
         count = off.size - 1
         if count < 0:
             raise ValueError("offsets needs count+1 entries")
+        if count and int(off.max()) > s.size:
+            raise ValueError("offsets point past the end of seq")
         cap = int((int(off[-1]) - int(off[0])) // 32 + count) if count else 0
         out = np.empty(cap, dtype=np.uint64)
         wo = np.zeros(count + 1, dtype=np.uint64)
@@ -352,6 +356,8 @@ class Context:
         stride = read_len if stride is None else stride
         if count is None:
             count = 0 if s.size < read_len else (s.size - read_len) // stride + 1
+        elif count and (count - 1) * stride + read_len > s.size:
+            raise ValueError("seq holds fewer than (count-1)*stride + read_len bytes")
         wpr = (read_len + 31) // 32
         out = np.empty((count, wpr), dtype=np.uint64)
         err = L.BitnucErr()
@@ -369,6 +375,8 @@ class Context:
         nbytes = (count - 1) * stride + read_len if count else 0
         if out is None:
             out = np.zeros(nbytes, dtype=np.uint8)
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags.c_contiguous and out.size >= nbytes):
+            raise ValueError("out must be a contiguous uint8 array of at least (count-1)*stride + read_len bytes")
         err = L.BitnucErr()
         if self._lib.bitnuc_decode_fixed(self._h, _ptr(w), int(read_len), int(stride), int(count), _ptr(out), C.byref(err)) != L.OK:
             _raise(err)
@@ -396,7 +404,11 @@ class Context:
         wo = np.ascontiguousarray(word_offsets, dtype=np.uint64)
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         count = off.size - 1
-        out = np.zeros(int(off[-1]) if count >= 0 and off.size else 0, dtype=np.uint8)
+        if count < 0 or wo.size != off.size:
+            raise ValueError("offsets and word_offsets need count+1 entries each")
+        if w.size < int(wo[-1]):
+            raise ValueError("words holds fewer than word_offsets[-1] entries")
+        out = np.zeros(int(off[-1]), dtype=np.uint8)
         err = L.BitnucErr()
         if self._lib.bitnuc_decode_batch(self._h, _ptr(w), _ptr(wo), _ptr(off), count, _ptr(out), C.byref(err)) != L.OK:
             if err.status == L.INVALID_RANGE:

@@ -879,6 +879,13 @@ int bitnuc_decode_batch(bitnuc_ctx *c, const uint64_t *words, const uint64_t *wo
     if (count == 0) return BITNUC_OK;
     if (!offsets || !word_offsets) return fail(err, BITNUC_UNSUPPORTED);
     if (int st = check_offsets(offsets, count, err)) return st;
+    // the kernels index both buffers through these tables: a table that does not match the offsets
+    // (word_offsets[i+1] - word_offsets[i] == ceil(len_i / 32), starting at 0) is refused here rather
+    // than turned into an out-of-bounds device access (argument check only, not codec arithmetic)
+    if (word_offsets[0] != 0) return fail(err, BITNUC_INVALID_RANGE, 0);
+    for (size_t i = 0; i < count; ++i)
+        if (word_offsets[i + 1] - word_offsets[i] != words_for((size_t)(offsets[i + 1] - offsets[i])) || word_offsets[i + 1] < word_offsets[i])
+            return fail(err, BITNUC_INVALID_RANGE, i + 1);
     const uint64_t b0 = offsets[0], nbytes = offsets[count] - b0, total = word_offsets[count];
     if (total == 0) return BITNUC_OK;
     if (!words || !out) return fail(err, BITNUC_UNSUPPORTED);

@@ -137,7 +137,9 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *ctx, const uint8_t *d_seq, const uint64_
 int bitnuc_decode_batch_dev(bitnuc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_word_offsets, const uint64_t *d_offsets, size_t count, size_t total_words, uint8_t *d_out, bitnuc_err *err);
 /* Host-pointer forms (synchronous).  encode: out must hold sum ceil(len_i/32) words
  * (<= (offsets[count]-offsets[0])/32 + count); word_offsets (count+1 entries) is an output.
- * offsets that decrease -> INVALID_RANGE{value = index of the offending entry}. */
+ * offsets that decrease -> INVALID_RANGE{value = index of the offending entry}; decode: a word_offsets
+ * table that is not the one encode_batch produces for these offsets -> INVALID_RANGE likewise (the
+ * _dev forms trust their tables: they are the caller's device memory). */
 int bitnuc_encode_batch(bitnuc_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, size_t count, uint64_t *out, size_t out_cap_words, uint64_t *word_offsets, size_t *n_words, bitnuc_err *err);
 int bitnuc_decode_batch(bitnuc_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets, const uint64_t *offsets, size_t count, uint8_t *out, bitnuc_err *err);
 

@@ -429,6 +429,21 @@ def test_batch_offsets_base_and_errors(ctx, oracle):
     with pytest.raises(bn.NucleotideError) as ei:
         ctx.encode_batch(seq, off_bad)
     assert ei.value.kind == "InvalidRange"
+    # a word-offsets table that does not belong to these offsets is refused, not dereferenced
+    w, wo = ctx.encode_batch(seq, off)
+    wo_bad = wo.copy()
+    wo_bad[20:] += np.uint64(3)
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.decode_batch(np.concatenate([w, np.zeros(3, np.uint64)]), wo_bad, off)
+    assert ei.value.kind == "InvalidRange" and ei.value.index == 20
+    with pytest.raises(ValueError):
+        ctx.decode_batch(w[:-1], wo, off)
+    with pytest.raises(ValueError):
+        ctx.encode_batch(seq[:-1], off)
+    with pytest.raises(ValueError):
+        ctx.as_2bit_batch(seq[:100], 31, 31, 4)
+    with pytest.raises(ValueError):
+        ctx.encode_fixed(seq[:100], 30, 30, 4)
     # empty batch
     w, wo = ctx.encode_batch(b"", np.zeros(1, np.uint64))
     assert w.size == 0 and list(wo) == [0]
