@@ -45,6 +45,7 @@ struct NucleotideError {
     static NucleotideError invalid_base(uint8_t b) { NucleotideError e; e.kind = InvalidBase; e.base = b; return e; }
     static NucleotideError sequence_too_long(size_t n) { NucleotideError e; e.kind = SequenceTooLong; e.len = n; return e; }
     static NucleotideError invalid_length(size_t n) { NucleotideError e; e.kind = InvalidLength; e.len = n; return e; }
+    static NucleotideError unsupported() { NucleotideError e; e.kind = Unsupported; return e; }
 
     // derive(PartialEq, Eq): variant + payload
     bool operator==(const NucleotideError &o) const {
@@ -226,6 +227,7 @@ class Context {
     Result<std::vector<uint64_t>> as_2bit_batch(Bytes kmers, size_t k, size_t stride, size_t count) const {
         std::vector<uint64_t> out(count);
         bitnuc_err e;
+        if (count && k && k <= 32 && (count - 1) * stride + k > kmers.len) return NucleotideError::unsupported(); // slice too short for the batch
         if (bitnuc_as_2bit_batch(ctx_, kmers.ptr, k, stride, count, out.data(), &e) != BITNUC_OK) return NucleotideError::from_c(e);
         return out;
     }
@@ -246,6 +248,7 @@ class Context {
         std::vector<uint64_t> out(count ? (size_t)((offsets[count] - offsets[0]) / 32 + count) : 0);
         size_t nw = 0;
         bitnuc_err e;
+        if (count && seq.len < offsets[count]) return NucleotideError::unsupported(); // offsets point past the slice
         int st = bitnuc_encode_batch(ctx_, seq.ptr, offsets.data(), count, out.data(), out.size(), word_offsets.data(), &nw, &e);
         if (st != BITNUC_OK) return NucleotideError::from_c(e);
         out.resize(nw);
@@ -256,6 +259,7 @@ class Context {
     Result<std::vector<uint64_t>> encode_fixed(Bytes seq, size_t read_len, size_t stride, size_t count) const {
         std::vector<uint64_t> out(count * ((read_len + 31) / 32));
         bitnuc_err e;
+        if (count && (stride < read_len || (count - 1) * stride + read_len > seq.len)) return NucleotideError::unsupported();
         if (bitnuc_encode_fixed(ctx_, seq.ptr, read_len, stride, count, out.data(), &e) != BITNUC_OK) return NucleotideError::from_c(e);
         return out;
     }
@@ -265,6 +269,7 @@ class Context {
         const size_t count = offsets.empty() ? 0 : offsets.size() - 1;
         std::vector<uint8_t> out(count ? (size_t)offsets[count] : 0);
         bitnuc_err e;
+        if (word_offsets.size() != offsets.size() || (count && words.len < word_offsets[count])) return NucleotideError::unsupported();
         if (bitnuc_decode_batch(ctx_, words.ptr, word_offsets.data(), offsets.data(), count, out.data(), &e) != BITNUC_OK)
             return NucleotideError::from_c(e);
         return out;
