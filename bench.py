@@ -100,10 +100,20 @@ def main():
     import torch
     import torch.distributed as dist
     import bitnuc_amd
+    from bitnuc_amd import build as bn_build
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # a fresh checkout has no libbitnuc_hip.so (git-ignored): local rank 0 compiles it, the others wait for the file
+    if local_rank == 0:
+        bn_build.ensure_built()
+    else:
+        t_wait = time.time()
+        while not os.path.exists(bn_build.LIB):
+            if time.time() - t_wait > 600:
+                raise RuntimeError(f"{bn_build.LIB} did not appear: there is no CPU fallback")
+            time.sleep(1.0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")

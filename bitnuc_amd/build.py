@@ -34,12 +34,25 @@ def is_stale():
 def build_library(force=False, verbose=True, extra_flags=()):
     if not force and not is_stale():
         return LIB
+    tmp = f"{LIB}.tmp.{os.getpid()}"  # other processes (bench ranks) only ever see a complete library
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-           *extra_flags, "-o", LIB, *SOURCES, "-ldl"]
+           "-Wall", "-Wno-unused-function", "-fno-gpu-rdc", *extra_flags, "-o", tmp, *SOURCES, "-ldl"]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=HERE)
+        print(" ".join(cmd).replace(tmp, LIB), file=sys.stderr)
+    try:
+        subprocess.run(cmd, check=True, cwd=HERE)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+    return LIB
+
+
+def ensure_built():
+    """Build libbitnuc_hip.so only if it is missing (a fresh checkout: the .so is git-ignored).  An existing
+    library is used as is -- file times do not survive every copy, so staleness is `build_library`'s business."""
+    if not os.path.exists(LIB):
+        build_library(force=True)
     return LIB
 
 

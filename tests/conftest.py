@@ -31,6 +31,8 @@ def ctx():
     """Default GPU context (gpu-marked tests only).  The HIP library must load and a
     device must be present: there is no CPU fallback to hide behind."""
     import bitnuc_amd
+    from bitnuc_amd import build
+    build.ensure_built()  # a fresh checkout has no .so (git-ignored): compile the product, never substitute it
     c = bitnuc_amd.Context(0)
     yield c
     c.close()
