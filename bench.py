@@ -214,6 +214,30 @@ def main():
             extra["allgather_packed"] = {"ms": round(ag * 1e3, 3), "bytes_received_per_gpu": nw * 8 * (world - 1),
                                          "gb_s_per_gpu": round(nw * 8 * (world - 1) / ag / 1e9, 2),
                                          "note": "RCCL all-gather of the packed u64 buffer over xGMI; fabric-bound, outside the timed step"}
+            # encode + concatenation end to end, one shot vs chunked overlap (8 pieces: the
+            # fabric moves piece c while the GPU encodes piece c+1)
+            from bitnuc_amd.dist import encode_allgather_overlapped
+
+            def enc_chunk(w0, w1):
+                ctx.encode_dev(seqs[0][32 * w0:], min(n, 32 * w1) - 32 * w0, words[0][w0:])
+                return words[0][w0:w1]
+
+            def one_shot():
+                ctx.encode_dev(seqs[0], n, words[0])
+                return allgather_packed(words[0])
+            e2e = {}
+            for name, fn in (("one_shot", one_shot), ("overlap8", lambda: encode_allgather_overlapped(enc_chunk, nw, 8, words[0]))):
+                ref_full = fn()
+                fence()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    full = fn()
+                fence()
+                e2e[name + "_ms"] = round((time.perf_counter() - t) / reps * 1e3, 3)
+                e2e[name + "_ok"] = bool(torch.equal(full, ref_full))
+                del full, ref_full
+            e2e["note"] = "encode of this rank's 10^9-base shard + all-gather of the packed words; fabric-bound, so it cannot scale like the step"
+            extra["encode_allgather_end_to_end"] = e2e
         except Exception as e:  # noqa: BLE001 -- a side measurement must never cost the headline line
             extra["allgather_packed"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_extras:

@@ -54,3 +54,31 @@ def encode_sharded(encode_fn, seq_shard, n_total, group=None):
     counts = shard_word_counts(n_total, world)
     words = encode_fn(seq_shard)
     return allgather_packed(words, counts, group)
+
+
+def encode_allgather_overlapped(encode_chunk, shard_words, n_chunks, like, group=None):
+    """BASELINE config 4 end to end with chunked overlap (SURVEY 8e iii): the shard is encoded in
+    `n_chunks` pieces; as soon as piece c is enqueued its all-gather is issued asynchronously, so
+    the fabric moves piece c while the GPU encodes piece c+1 (with backend "nccl" torch runs the
+    collective on its own stream, ordered after the encode by an event).
+
+    encode_chunk(w0, w1) -> 1-D int64 tensor holding words [w0, w1) of this rank's shard (on the
+    GPU: a view of the shard's word buffer after Context.encode_dev of bases [32*w0, 32*w1) on the
+    current stream).  Every rank must have the same `shard_words`.  `like` gives dtype/device.
+    Returns the concatenation [world * shard_words], bit-identical to allgather_packed(words)."""
+    world = dist.get_world_size(group)
+    bounds = [shard_words * c // n_chunks for c in range(n_chunks + 1)]
+    pieces, works = [], []
+    for c in range(n_chunks):
+        w0, w1 = bounds[c], bounds[c + 1]
+        if w1 == w0:
+            continue
+        local = encode_chunk(w0, w1)
+        tmp = torch.empty(world * (w1 - w0), dtype=like.dtype, device=like.device)  # [world][w1-w0]
+        works.append(dist.all_gather_into_tensor(tmp, local.contiguous(), group=group, async_op=True))
+        pieces.append((w0, w1, tmp))
+    out = torch.empty(world, shard_words, dtype=like.dtype, device=like.device)
+    for work, (w0, w1, tmp) in zip(works, pieces):
+        work.wait()  # nccl: orders the current stream after the collective; gloo: blocks
+        out[:, w0:w1].copy_(tmp.view(world, w1 - w0))
+    return out.reshape(world * shard_words)

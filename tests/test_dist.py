@@ -61,3 +61,40 @@ def test_two_rank_sharded_encode_equals_single(n):
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def _worker_overlap(rank, world, port, shard_words, n_chunks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_py
+        from bitnuc_amd.dist import allgather_packed, encode_allgather_overlapped
+        n = 32 * shard_words
+        shard = oracle_py.nucgen(n, 0xB17C0DE, first=rank * n)
+        words = torch.zeros(shard_words, dtype=torch.int64)
+
+        def enc(w0, w1):  # the per-rank encoder is injected: the oracle here, Context.encode_dev on a GPU
+            words[w0:w1] = torch.from_numpy(oracle_py.encode(shard[32 * w0:32 * w1]).view(np.int64).copy())
+            return words[w0:w1]
+        full = encode_allgather_overlapped(enc, shard_words, n_chunks, words)
+        expect = oracle_py.encode(oracle_py.nucgen(world * n, 0xB17C0DE))
+        same_as_plain = torch.equal(full, allgather_packed(words))
+        q.put((rank, bool(np.array_equal(full.numpy().view(np.uint64), expect)) and same_as_plain))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard_words,n_chunks", [(1000, 8), (7, 8), (64, 1), (1001, 3)])
+def test_two_rank_overlapped_allgather_equals_single(shard_words, n_chunks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + shard_words) % 2000
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, shard_words, n_chunks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(2))
+    assert res == {0: True, 1: True}
