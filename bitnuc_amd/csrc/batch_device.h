@@ -138,7 +138,7 @@ __device__ __forceinline__ WordLoc locate_word(const unsigned long long *__restr
                                                const unsigned long long *__restrict__ word_offsets,
                                                unsigned long long count, unsigned long long sb, unsigned long long wb,
                                                unsigned long long w, bool active, unsigned long long *win_wo,
-                                               unsigned long long *win_so) {
+                                               unsigned long long *win_so, unsigned hi0) {
     const unsigned lane = threadIdx.x & 63;
     unsigned filled = 64;
     while (filled <= (unsigned)kBatchWin && win_wo[filled - 1] <= wb + kBatchTile - 1) { // wave-uniform, rare
@@ -153,7 +153,11 @@ __device__ __forceinline__ WordLoc locate_word(const unsigned long long *__restr
     }
     WordLoc loc{0, 0};
     if (!active) return loc;
-    unsigned lo = 0, hi = filled; // upper_bound in the window
+    // upper_bound in the window.  Entry 0 (the tile's owner) starts at or before every word of the
+    // tile, and the caller knows the first entry that starts past the tile (hi0, from one ballot over
+    // the entries while they were still in registers): the search runs over the handful of
+    // sequences that really start inside the tile, not over all 64 entries.
+    unsigned lo = 1, hi = filled == 64 ? hi0 : filled;
     while (lo < hi) {
         const unsigned mid = (lo + hi) >> 1;
         if (win_wo[mid] <= w) lo = mid + 1; else hi = mid;
@@ -169,6 +173,12 @@ __device__ __forceinline__ WordLoc locate_word(const unsigned long long *__restr
     const unsigned long long left = s1 - loc.base;
     loc.nb = left < 32 ? (unsigned)left : 32u;
     return loc;
+}
+
+// index of the first of the wave's 64 window entries that starts past the tile's last word (64 if none)
+__device__ __forceinline__ unsigned first_entry_past(unsigned long long entry, unsigned long long last_word) {
+    const unsigned long long m = __ballot(entry > last_word);
+    return m ? (unsigned)__builtin_ctzll(m) : 64u;
 }
 
 // ---------------------------------------------------------------------------------
@@ -436,7 +446,8 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
                 my.win_so[lane] = so_r[u];
                 stream_fill(st[u], nchunk[u], lo16[u], seq, seq_end, strip, slot);
                 wave_lds_fence();
-                const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so);
+                const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so,
+                                                 first_entry_past(wo_r[u], wb + kBatchTile - 1));
                 if (!active) continue;
                 const unsigned long long word = stream_cut(strip, (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]), loc.nb);
                 __builtin_nontemporal_store(word, out + w);
@@ -450,7 +461,8 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
                     if (c < nchunk[u]) *reinterpret_cast<u32x4 *>(my.stage + 16 * c) = st[u][j];
                 }
                 wave_lds_fence();
-                const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so);
+                const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so,
+                                                 first_entry_past(wo_r[u], wb + kBatchTile - 1));
                 if (!active) continue;
                 const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]);
                 // The word's bytes start at any byte offset: read the 9 ALIGNED LDS dwords that cover 32
@@ -659,9 +671,12 @@ __device__ __forceinline__ WordLoc locate_word_block(const unsigned long long *_
         __syncthreads();
         if (filled > (unsigned)kBatchBlockWin || win_wo[filled - 1] > wb + kBatchDecBlock - 1) break; // uniform
     }
+    // first of the first 64 entries that starts past the workgroup's last word: bounds the search (every
+    // wave computes the same value from LDS with one ballot; 150-base reads: 27 instead of 64 entries)
+    const unsigned hi0 = first_entry_past(win_wo[threadIdx.x & 63], wb + kBatchDecBlock - 1);
     WordLoc loc{0, 0};
     if (!active) return loc;
-    unsigned lo = 0, hi = filled; // upper_bound in the window
+    unsigned lo = 1, hi = hi0 < 64 ? hi0 : filled; // upper_bound in the window; entry 0 (the owner) never starts past w
     while (lo < hi) {
         const unsigned mid = (lo + hi) >> 1;
         if (win_wo[mid] <= w) lo = mid + 1; else hi = mid;
