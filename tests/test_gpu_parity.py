@@ -836,6 +836,7 @@ def test_analysis_full_scale(ctx, oracle):
     words = torch.empty(nw, dtype=torch.int64, device=dev)
     ctx.encode_dev(seq, n, words)
     counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the kernels on the context's
     ctx.base_counts_dev(words, nw, n, counts)
     ctx.sync()
     expect = [int((seq == ord(c)).sum()) for c in "ACGT"]  # independent: counted on the ASCII side by torch
@@ -944,10 +945,12 @@ def test_rccl_comm_single_rank(oracle):
     c.nucgen_dev(seq, n, 5)
     allw = torch.zeros(n // 32, dtype=torch.int64, device=dev)
     c.sync()
+    torch.cuda.synchronize()
     comm.encode_sharded_allgather_dev(seq, n, allw)
     c.sync()
     assert np.array_equal(allw.cpu().numpy().view(np.uint64), oracle.encode(seq.cpu().numpy()))
     out = torch.zeros(n // 32, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
     comm.allgather_words_dev(allw, n // 32, out)
     c.sync()
     assert torch.equal(out, allw)
