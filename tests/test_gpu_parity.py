@@ -579,6 +579,55 @@ def test_beyond_4gib_indexing(ctx, oracle):
     assert (ei.value.byte, ei.value.index) == (ord("N"), pos)
 
 
+def test_beyond_4gib_batches(ctx, oracle):
+    """Byte offsets past 2^32 in the batch kernels: dense and strided k-mer batches, fixed-length reads, ragged batches."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = (1 << 32) + 150 * 1000
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(seq, n, 0xB17C0DE)
+    ctx.sync()
+    # k-mer batches: dense (stride == k) and strided, k-mers that start beyond 2^32
+    for k, stride in ((31, 31), (31, 40)):
+        count = (n - k) // stride + 1
+        out = torch.empty(count, dtype=torch.int64, device=dev)
+        ctx.as_2bit_batch_dev(seq, k, stride, count, out)
+        ctx.sync()
+        for j in (0, (1 << 32) // stride - 2, (1 << 32) // stride + 3, count - 1):
+            h = seq[j * stride: j * stride + k].cpu().numpy()
+            assert int(out[j].item()) & (2**64 - 1) == oracle.as_2bit(h), (k, stride, j)
+        del out
+    # fixed-length reads == ragged batch of the same reads; decode of both is the input
+    L = 150
+    count = n // L
+    wpr = (L + 31) // 32
+    words = torch.empty(count * wpr, dtype=torch.int64, device=dev)
+    ctx.encode_fixed_dev(seq, L, L, count, words)
+    off = torch.arange(0, count + 1, dtype=torch.int64, device=dev) * L
+    wo = torch.empty(count + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    total = ctx.batch_word_offsets_dev(off, count, wo)
+    assert total == count * wpr
+    w2 = torch.empty(total, dtype=torch.int64, device=dev)
+    ctx.encode_batch_dev(seq, off, wo, count, total, w2)
+    ctx.sync()
+    assert torch.equal(words, w2)
+    r = (1 << 32) // L  # the read that straddles byte 2^32
+    for rr in (r - 1, r, r + 1, count - 1):
+        h = seq[rr * L:(rr + 1) * L].cpu().numpy()
+        assert np.array_equal(words[rr * wpr:(rr + 1) * wpr].cpu().numpy().view(np.uint64), oracle.encode(h)), rr
+    del w2
+    back = torch.empty(count * L, dtype=torch.uint8, device=dev)
+    ctx.decode_fixed_dev(words, L, L, count, back)
+    ctx.sync()
+    assert torch.equal(back, seq[: count * L])
+    back.zero_()
+    torch.cuda.synchronize()
+    ctx.decode_batch_dev(words, wo, off, count, total, back)
+    ctx.sync()
+    assert torch.equal(back, seq[: count * L])
+
+
 def test_two_contexts_interleaved(oracle):
     import threading
     import bitnuc_amd as bn
