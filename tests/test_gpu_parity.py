@@ -628,6 +628,43 @@ def test_beyond_4gib_batches(ctx, oracle):
     assert torch.equal(back, seq[: count * L])
 
 
+def test_hbm_scale_round_trip(ctx, oracle):
+    """One sequence sized for the 288 GB of HBM: up to 10^11 bases (100 GB ASCII + 25 GB packed + 100 GB decoded),
+    scaled down to what the box has free.  Round-trip identity, spot blocks against the oracle, error index."""
+    import torch
+    import bitnuc_amd as bn
+    dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    n = min(10**11, int(free * 0.40)) // 32 * 32 + 17
+    nw = (n + 31) // 32
+    seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    words = torch.empty(nw, dtype=torch.int64, device=dev)
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.nucgen_dev(seq, n, 0xB17C0DE)
+    ctx.encode_dev(seq, n, words)
+    ctx.decode_dev(words, nw, n, back)
+    ctx.sync()
+    step = 1 << 31  # torch.equal materialises a temporary as large as its operands: compare 2 GiB at a time
+    assert all(torch.equal(seq[i:i + step], back[i:i + step]) for i in range(0, n, step))
+    del back
+    for off in (0, n // 3 // 32 * 32, n - 32 * 1000 - 17):
+        m = n - off if off + 32 * 1000 + 17 == n else 32 * 1000  # whole words, except at the very end (17-base tail)
+        h = seq[off:off + m].cpu().numpy()
+        assert np.array_equal(h, oracle.nucgen(m, 0xB17C0DE, first=off))
+        assert np.array_equal(words[off // 32: off // 32 + (m + 31) // 32].cpu().numpy().view(np.uint64), oracle.encode(h))
+    pos = n - 12345
+    seq[pos] = ord("n")
+    torch.cuda.synchronize()
+    ctx.encode_dev(seq, n, words)
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.sync()
+    assert (ei.value.byte, ei.value.index) == (ord("n"), pos)
+    del seq, words
+    torch.cuda.empty_cache()
+
+
 def test_two_contexts_interleaved(oracle):
     import threading
     import bitnuc_amd as bn
