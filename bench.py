@@ -266,6 +266,16 @@ def main():
                                    "ms": round(ms, 4), "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": count * (k + 8)}}
             del kseq, kout
+            # every window of a sequence (`seq.windows(k)` + as_2bit, src/lib.rs:170-173): stride 1, 1 B read + 8 B written per window
+            nwin = n - k + 1
+            wout = torch.empty(nwin, dtype=torch.int64, device=dev)
+            ms = timed(lambda: ctx.as_2bit_batch_dev(seqs[0], k, 1, nwin, wout), reps=6)
+            gbs = 9 * nwin / (ms * 1e-3) / 1e9
+            extra["kmer_windows"] = {"workload": "as_2bit of every 31-base window of 10^9 bases (stride 1) -> u64 per window", "ms": round(ms, 4),
+                                     "gwindows_s": round(nwin / (ms * 1e-3) / 1e9, 2),
+                                     "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 9 * nwin}}
+            del wout
             dist_out = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
             q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
             ms = timed(lambda: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, dist_out))

@@ -49,6 +49,7 @@ struct bitnuc_ctx {
     int enc_variant = 14, dec_variant = 22; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
+    int batch_slide = 1;                 // stride == 1 batches (every window of a sequence) use kmer_slide_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
     int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
     int batch_stream = 0;                  // encode_batch: 1 = cut the tile's 2-bit stream, 0 = funnel raw bytes per word
@@ -317,6 +318,17 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         done = items * 64;
         if (done == count) return hipSuccess;
     }
+    if (stride == 1 && done == 0 && c->batch_slide && aligned16(kmers) && aligned16(out) && count - 1 + k >= 1024) {
+        // every window of a sequence: whole 1 KiB wave rounds through the sliding kernel, 992 windows each
+        const unsigned long long rounds = (count - 1 + k - 1024) / kScanWaveWindows + 1;
+        const unsigned grid = grid_for(c, (rounds + kBlock / 64 - 1) / (kBlock / 64));
+        if (c->dense_policy & 2) kmer_slide_kernel<true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot);
+        else kmer_slide_kernel<false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot);
+        hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+        done = (size_t)(rounds * kScanWaveWindows);
+        if (done >= count) return hipSuccess;
+    }
     // general strides, and the < 64 k-mers a dense batch leaves over.  The error slot holds
     // byte offsets relative to `kmers`, so the leftover launch passes the offset it starts at.
     const size_t rest = count - done;
@@ -465,6 +477,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0 && value < kNumVariants) c->dec_variant = value; }
     else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
+    else if (!strcmp(key, "batch_slide")) { prev = c->batch_slide; if (value >= 0 && value <= 1) c->batch_slide = value; }
     else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
     else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
     else if (!strcmp(key, "fixed_stream")) { prev = c->fixed_stream; if (value == 0 || value == 1) c->fixed_stream = value; }

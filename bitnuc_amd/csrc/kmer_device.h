@@ -259,6 +259,61 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
 }
 
 // ---------------------------------------------------------------------------------
+// every window of a sequence: as_2bit over seq.windows(k)  (stride == 1, src/lib.rs:170-173)
+// ---------------------------------------------------------------------------------
+// out[i] = as_2bit(seq[i .. i+k]) for consecutive i: 1 B read + 8 B written per window, so the kernel is
+// bound by its output.  Same tiling as the scan: a wave reads 1024 consecutive bytes (dwordx4 per lane),
+// every lane packs its 16 bases into one 32-bit code word, the next two lanes' words arrive by DPP, and
+// window j of a lane is the 2k bits at bit 2j of that 96-bit run (two v_alignbit + a mask).  A lane's 16
+// windows are consecutive in memory (128 B), so they cross a wave-private LDS strip once (padded to 144 B
+// per lane: conflict-free both ways) and leave as dwordx4 stores of 1 KiB contiguous per instruction.
+// 992 windows per wave round (lanes 62/63 only supply the halo); needs bytes [wb, wb+1024) in bounds,
+// the leftover windows go through kmer_batch_kernel.
+constexpr int kSlideLaneWords = 18; // u64 slots per lane in the strip: 16 windows + 2 of padding
+
+template <bool NTST>
+__global__ void __launch_bounds__(kBlock)
+kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long long rounds, unsigned long long *__restrict__ out,
+                  unsigned long long *__restrict__ slot) {
+    __shared__ __attribute__((aligned(16))) unsigned long long strips[kBlock / 64][64 * kSlideLaneWords];
+    const unsigned lane = threadIdx.x & 63;
+    unsigned long long *strip = strips[wave_in_block()];
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (kBlock / 64) + wave_in_block();
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * (kBlock / 64);
+    const uint32_t mlo = k >= 16 ? ~0u : (1u << (2 * k)) - 1u;
+    const uint32_t mhi = k <= 16 ? 0u : (k == 32 ? ~0u : (1u << (2 * k - 32)) - 1u);
+    for (unsigned long long r = wave; r < rounds; r += nwaves) {
+        const unsigned long long wb = r * kScanWaveWindows;
+        const u32x4 v = load_group<true, true>(seq + wb + 16 * lane);
+        uint32_t bad = 0;
+        const uint32_t c0 = enc16(v, bad);
+        if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, wb + 16 * lane, 16, slot);
+        const uint32_t c1 = wave_shl1(c0), c2 = wave_shl1(c1);
+        wave_lds_fence(); // previous round's readers are done
+        u32x4 *mine = reinterpret_cast<u32x4 *>(strip + kSlideLaneWords * lane);
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const uint32_t lo0 = (j ? __builtin_amdgcn_alignbit(c1, c0, 2 * j) : c0) & mlo;
+            const uint32_t hi0 = (j ? __builtin_amdgcn_alignbit(c2, c1, 2 * j) : c1) & mhi;
+            const uint32_t lo1 = __builtin_amdgcn_alignbit(c1, c0, 2 * j + 2) & mlo;
+            const uint32_t hi1 = __builtin_amdgcn_alignbit(c2, c1, 2 * j + 2) & mhi;
+            mine[j >> 1] = u32x4{lo0, hi0, lo1, hi1};
+        }
+        wave_lds_fence();
+        // 992 windows = 496 pairs; pair p = windows 2p, 2p+1 of lane p / 8
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const unsigned p = lane + 64 * m;
+            if (p < kScanWaveWindows / 2) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + kSlideLaneWords * (p >> 3) + 2 * (p & 7));
+                u32x4 *dst = reinterpret_cast<u32x4 *>(out + wb) + p;
+                if constexpr (NTST) __builtin_nontemporal_store(t, dst); else *dst = t;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // bulk hdist: sum over words of the per-word mismatch count (u32, wraps like Rust release)
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)

@@ -319,6 +319,61 @@ def test_kmer_batch_vs_oracle(ctx, oracle, k, stride):
         assert np.array_equal(got, oracle.as_2bit_batch(s, k, stride, count)), (k, stride, count)
 
 
+@pytest.mark.parametrize("k", [1, 2, 4, 15, 16, 17, 21, 31, 32])
+def test_kmer_windows_stride1_vs_oracle(ctx, oracle, k):
+    """`for w in seq.windows(k) { as_2bit(w) }` (src/lib.rs:170-173): the sliding kernel (whole 1 KiB rounds) plus
+    the generic kernel for the leftover windows, against the oracle's loop; sizes around the round boundaries."""
+    import torch
+    dev = torch.device("cuda:0")
+    for n in [k, 1023, 1024, 1025, 1024 + 991, 1024 + 992, 1024 + 993, 3000, 5 * 992 + 1024, 200003]:
+        if n < k:
+            continue
+        s = rand_seq(n)
+        count = n - k + 1
+        exp = oracle.as_2bit_batch(s, k, 1, count)
+        assert np.array_equal(ctx.as_2bit_batch(s, k, 1, count), exp), (k, n)
+    # device path at 16-byte and odd alignment (the latter takes the generic kernel), guard words around the output
+    n = 100003
+    s = rand_seq(n)
+    count = n - k + 1
+    exp = oracle.as_2bit_batch(s, k, 1, count)
+    for in_off, out_off in ((0, 0), (16, 2), (5, 0), (0, 1)):
+        buf = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+        buf[in_off:in_off + n] = torch.from_numpy(s).to(dev)
+        out = torch.zeros(count + 4, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        ctx.as_2bit_batch_dev(buf.data_ptr() + in_off, k, 1, count, out.data_ptr() + 8 * out_off)
+        ctx.sync()
+        o = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(o[out_off:out_off + count], exp), (k, in_off, out_off)
+        assert not o[:out_off].any() and not o[out_off + count:].any()
+    # sliding kernel off == on
+    prev = ctx.set_variant("batch_slide", 0)
+    try:
+        assert np.array_equal(ctx.as_2bit_batch(s, k, 1, count), exp)
+    finally:
+        ctx.set_variant("batch_slide", prev)
+
+
+def test_kmer_windows_stride1_first_invalid_byte(ctx, oracle):
+    import bitnuc_amd as bn
+    k, n = 31, 50000
+    s = rand_seq(n).copy()
+    for pos in (0, 15, 16, 991, 992, 1023, 1024, 20000, n - 1):
+        t = s.copy()
+        t[pos] = ord("N")
+        if pos + 7 < n:
+            t[pos + 7] = ord("X")  # a later invalid byte never wins
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.as_2bit_batch(t, k, 1, n - k + 1)
+        with pytest.raises(oracle.OracleError) as oe:
+            oracle.as_2bit_batch(t, k, 1, n - k + 1)
+        assert (ei.value.byte, ei.value.index) == (oe.value.byte, oe.value.index) == (ord("N"), pos)
+    # a byte past the last window is never examined
+    t = np.concatenate([s, np.frombuffer(b"N", dtype=np.uint8)])
+    assert np.array_equal(ctx.as_2bit_batch(t, k, 1, n - k + 1), oracle.as_2bit_batch(s, k, 1, n - k + 1))
+
+
 def test_kmer_batch_errors(ctx, oracle):
     import bitnuc_amd as bn
     k, stride, count = 31, 40, 3000

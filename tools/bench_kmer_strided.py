@@ -30,6 +30,15 @@ def timed(fn, reps=8):
     return statistics.median(ev[i].elapsed_time(ev[i + 1]) for i in range(2, reps))
 
 
+# every window of a sequence (`for w in seq.windows(k) { as_2bit(w) }`, src/lib.rs:170-173): stride 1, 9 B per window
+nwin = 5 * 10**8
+wout = torch.empty(nwin, dtype=torch.int64, device=dev)
+for k in (31, 21, 4):
+    a = timed(lambda: ctx.as_2bit_batch_dev(seq, k, 1, nwin, wout))
+    ctx.sync()
+    print(f"k={k} stride=1 ({nwin} windows): as_2bit_batch {a:.4f} ms {nwin * 9 / a / 1e6:6.0f} GB/s (1 B read + 8 B written per window)", flush=True)
+del wout
+
 for k, stride in [(31, 31), (31, 32), (21, 22), (32, 33), (31, 64), (16, 17)]:
     a = timed(lambda: ctx.as_2bit_batch_dev(seq, k, stride, count, out))
     b = timed(lambda: ctx.encode_fixed_dev(seq, k, stride, count, out2))
