@@ -49,7 +49,7 @@ struct bitnuc_ctx {
     int enc_variant = 14, dec_variant = 22; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
-    int batch_slide = 1;                 // stride == 1 batches (every window of a sequence) use kmer_slide_kernel
+    int batch_slide = 1;                 // stride 1 (every window of a sequence), 2, 4, 8, 16 batches use kmer_slide_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
     int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
     int batch_stream = 0;                  // encode_batch: 1 = cut the tile's 2-bit stream, 0 = funnel raw bytes per word
@@ -318,15 +318,28 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         done = items * 64;
         if (done == count) return hipSuccess;
     }
-    if (stride == 1 && done == 0 && c->batch_slide && aligned16(kmers) && aligned16(out) && count - 1 + k >= 1024) {
-        // every window of a sequence: whole 1 KiB wave rounds through the sliding kernel, 992 windows each
-        const unsigned long long rounds = (count - 1 + k - 1024) / kScanWaveWindows + 1;
+    // (k >= stride: every byte of the span belongs to some k-mer, so validating whole 16-byte groups examines no byte the
+    // reference's loop would not; with gaps between k-mers the general kernel looks at each k-mer's own bytes only)
+    if ((stride == 1 || stride == 2 || stride == 4 || stride == 8 || stride == 16) && k >= stride && done == 0 && c->batch_slide &&
+        aligned16(kmers) && aligned16(out) && (count - 1) * stride + k >= 1024) {
+        // windows at a small power-of-two stride (1 = every window of a sequence): whole 1 KiB wave rounds through the
+        // sliding kernel, 992 / stride windows each; the round that would read past the batch's last byte is left over
+        const unsigned long long rounds = ((count - 1) * stride + k - 1024) / kScanWaveWindows + 1;
         const unsigned grid = grid_for(c, (rounds + kBlock / 64 - 1) / (kBlock / 64));
-        if (c->dense_policy & 2) kmer_slide_kernel<true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot);
-        else kmer_slide_kernel<false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot);
+        const bool nts = (c->dense_policy & 2) != 0;
+#define SLIDE(S) do { if (nts) kmer_slide_kernel<S, true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); \
+                      else kmer_slide_kernel<S, false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); } while (0)
+        switch (stride) {
+        case 1: SLIDE(1); break;
+        case 2: SLIDE(2); break;
+        case 4: SLIDE(4); break;
+        case 8: SLIDE(8); break;
+        default: SLIDE(16); break;
+        }
+#undef SLIDE
         hipError_t rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
-        done = (size_t)(rounds * kScanWaveWindows);
+        done = (size_t)(rounds * (kScanWaveWindows / stride));
         if (done >= count) return hipSuccess;
     }
     // general strides, and the < 64 k-mers a dense batch leaves over.  The error slot holds

@@ -269,13 +269,18 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
 // per lane: conflict-free both ways) and leave as dwordx4 stores of 1 KiB contiguous per instruction.
 // 992 windows per wave round (lanes 62/63 only supply the halo); needs bytes [wb, wb+1024) in bounds,
 // the leftover windows go through kmer_batch_kernel.
-constexpr int kSlideLaneWords = 18; // u64 slots per lane in the strip: 16 windows + 2 of padding
-
-template <bool NTST>
+//
+// The same tiling serves the power-of-two strides 2, 4, 8, 16 (a lane then owns 16/S windows, every S-th bit
+// position; 992 is a multiple of 16, so rounds stay aligned to the stride): S <= 4 crosses the strip, S >= 8
+// stores its 16 or 8 bytes per lane directly (already contiguous across lanes).
+template <int S, bool NTST>
 __global__ void __launch_bounds__(kBlock)
 kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long long rounds, unsigned long long *__restrict__ out,
                   unsigned long long *__restrict__ slot) {
-    __shared__ __attribute__((aligned(16))) unsigned long long strips[kBlock / 64][64 * kSlideLaneWords];
+    constexpr int W = 16 / S;                 // windows per lane and round
+    constexpr int LW = W + 2;                 // u64 slots per lane in the strip (padding: conflict-free both ways)
+    constexpr unsigned RW = kScanWaveWindows / S; // windows per wave round
+    __shared__ __attribute__((aligned(16))) unsigned long long strips[kBlock / 64][W >= 4 ? 64 * LW : 2];
     const unsigned lane = threadIdx.x & 63;
     unsigned long long *strip = strips[wave_in_block()];
     const unsigned long long wave = (unsigned long long)blockIdx.x * (kBlock / 64) + wave_in_block();
@@ -283,31 +288,46 @@ kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long lon
     const uint32_t mlo = k >= 16 ? ~0u : (1u << (2 * k)) - 1u;
     const uint32_t mhi = k <= 16 ? 0u : (k == 32 ? ~0u : (1u << (2 * k - 32)) - 1u);
     for (unsigned long long r = wave; r < rounds; r += nwaves) {
-        const unsigned long long wb = r * kScanWaveWindows;
+        const unsigned long long wb = r * kScanWaveWindows; // first base of the round
+        unsigned long long *dst = out + r * RW;              // its first window
         const u32x4 v = load_group<true, true>(seq + wb + 16 * lane);
         uint32_t bad = 0;
         const uint32_t c0 = enc16(v, bad);
         if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, wb + 16 * lane, 16, slot);
         const uint32_t c1 = wave_shl1(c0), c2 = wave_shl1(c1);
-        wave_lds_fence(); // previous round's readers are done
-        u32x4 *mine = reinterpret_cast<u32x4 *>(strip + kSlideLaneWords * lane);
+        uint32_t lo[W], hi[W];
 #pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            const uint32_t lo0 = (j ? __builtin_amdgcn_alignbit(c1, c0, 2 * j) : c0) & mlo;
-            const uint32_t hi0 = (j ? __builtin_amdgcn_alignbit(c2, c1, 2 * j) : c1) & mhi;
-            const uint32_t lo1 = __builtin_amdgcn_alignbit(c1, c0, 2 * j + 2) & mlo;
-            const uint32_t hi1 = __builtin_amdgcn_alignbit(c2, c1, 2 * j + 2) & mhi;
-            mine[j >> 1] = u32x4{lo0, hi0, lo1, hi1};
+        for (int i = 0; i < W; ++i) {
+            const int j = i * S; // base offset of the lane's i-th window
+            lo[i] = (j ? __builtin_amdgcn_alignbit(c1, c0, 2 * j) : c0) & mlo;
+            hi[i] = (j ? __builtin_amdgcn_alignbit(c2, c1, 2 * j) : c1) & mhi;
         }
-        wave_lds_fence();
-        // 992 windows = 496 pairs; pair p = windows 2p, 2p+1 of lane p / 8
+        if constexpr (W == 1) {
+            if (lane < 62) {
+                const unsigned long long w = ((unsigned long long)hi[0] << 32) | lo[0];
+                if constexpr (NTST) __builtin_nontemporal_store(w, dst + lane); else dst[lane] = w;
+            }
+        } else if constexpr (W == 2) {
+            if (lane < 62) {
+                const u32x4 t = {lo[0], hi[0], lo[1], hi[1]};
+                u32x4 *d = reinterpret_cast<u32x4 *>(dst) + lane;
+                if constexpr (NTST) __builtin_nontemporal_store(t, d); else *d = t;
+            }
+        } else {
+            wave_lds_fence(); // previous round's readers are done
+            u32x4 *mine = reinterpret_cast<u32x4 *>(strip + LW * lane);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const unsigned p = lane + 64 * m;
-            if (p < kScanWaveWindows / 2) {
-                const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + kSlideLaneWords * (p >> 3) + 2 * (p & 7));
-                u32x4 *dst = reinterpret_cast<u32x4 *>(out + wb) + p;
-                if constexpr (NTST) __builtin_nontemporal_store(t, dst); else *dst = t;
+            for (int i = 0; i < W; i += 2) mine[i >> 1] = u32x4{lo[i], hi[i], lo[i + 1], hi[i + 1]};
+            wave_lds_fence();
+            // RW windows = RW/2 pairs; pair p = windows 2p, 2p+1, held by lane p / (W/2)
+#pragma unroll
+            for (int m = 0; m < W / 2; ++m) {
+                const unsigned p = lane + 64 * m;
+                if (p < RW / 2) {
+                    const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + LW * (p / (W / 2)) + 2 * (p % (W / 2)));
+                    u32x4 *d = reinterpret_cast<u32x4 *>(dst) + p;
+                    if constexpr (NTST) __builtin_nontemporal_store(t, d); else *d = t;
+                }
             }
         }
     }

@@ -355,6 +355,31 @@ def test_kmer_windows_stride1_vs_oracle(ctx, oracle, k):
         ctx.set_variant("batch_slide", prev)
 
 
+@pytest.mark.parametrize("stride", [2, 4, 8, 16])
+@pytest.mark.parametrize("k", [1, 7, 8, 16, 17, 31, 32])
+def test_kmer_windows_small_power_of_two_strides(ctx, oracle, k, stride):
+    import bitnuc_amd as bn
+    for count in [1, 63, 64, 65, 991 // stride, 1024 // stride + 1, 2016 // stride + 3, 10007, 100003]:
+        n = (count - 1) * stride + k
+        s = rand_seq(n)
+        assert np.array_equal(ctx.as_2bit_batch(s, k, stride, count), oracle.as_2bit_batch(s, k, stride, count)), (k, stride, count)
+    # error position and gaps: with k < stride the bytes between k-mers are never examined
+    count = 5000
+    n = (count - 1) * stride + k
+    s = rand_seq(n).copy()
+    if k < stride:
+        s[stride * 100 + k] = ord("N")  # first byte of a gap
+        assert np.array_equal(ctx.as_2bit_batch(s, k, stride, count), oracle.as_2bit_batch(s, k, stride, count))
+    pos = stride * 3000 + min(k, stride) - 1
+    s[pos] = ord("N")
+    s[pos + stride] = ord("X")
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.as_2bit_batch(s, k, stride, count)
+    with pytest.raises(oracle.OracleError) as oe:
+        oracle.as_2bit_batch(s, k, stride, count)
+    assert (ei.value.byte, ei.value.index) == (oe.value.byte, oe.value.index) == (ord("N"), pos)
+
+
 def test_kmer_windows_stride1_first_invalid_byte(ctx, oracle):
     import bitnuc_amd as bn
     k, n = 31, 50000
