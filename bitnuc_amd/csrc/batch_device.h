@@ -181,6 +181,32 @@ __device__ __forceinline__ unsigned first_entry_past(unsigned long long entry, u
     return m ? (unsigned)__builtin_ctzll(m) : 64u;
 }
 
+// Tile-relative lookup for the common case that the wave's 64 window entries reach past the tile (hi0 < 64).
+// Entry i is kept as two 32-bit numbers relative to the tile: its first word minus the tile's first word, and its
+// first byte minus base0 (the byte of the tile's first base); the owner (entry 0) starts at or before the tile and
+// is entered as (0, 0).  The search, the byte offset and the length are then 32-bit arithmetic on 32-bit LDS
+// entries.  Returns the word's first byte relative to base0 and its base count.
+struct RelLoc { unsigned base, nb; };
+__device__ __forceinline__ RelLoc locate_word_rel(unsigned long long wo_r, unsigned long long so_r, unsigned long long wb,
+                                                  unsigned long long base0, unsigned hi0, uint32_t *win /* 128 entries */) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long dw = wo_r - wb, ds = so_r - base0; // entries >= 1 start after the tile's first word / base
+    win[lane] = lane == 0 ? 0u : (dw < 0xFFFFull ? (unsigned)dw : 0xFFFFu);
+    win[64 + lane] = lane == 0 ? 0u : (ds < 0x7FFFFFFFull ? (unsigned)ds : 0x7FFFFFFFu);
+    wave_lds_fence();
+    unsigned lo = 1, hi = hi0; // upper_bound over the entries that start inside the tile
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (win[mid] <= lane) lo = mid + 1; else hi = mid;
+    }
+    const unsigned w0 = win[lo - 1], s0 = win[64 + lo - 1], s1 = win[64 + lo];
+    RelLoc loc;
+    loc.base = s0 + ((lane - w0) << 5);
+    const unsigned left = s1 - loc.base;
+    loc.nb = left < 32 ? left : 32u;
+    return loc;
+}
+
 // ---------------------------------------------------------------------------------
 // word offsets: exclusive scan of ceil(len_i / 32), three small kernels
 // ---------------------------------------------------------------------------------
@@ -453,18 +479,29 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
                 __builtin_nontemporal_store(word, out + w);
             } else {
                 wave_lds_fence(); // previous trip's LDS readers are done
-                my.win_wo[lane] = wo_r[u];
-                my.win_so[lane] = so_r[u];
     #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const unsigned c = lane + 64 * j;
                     if (c < nchunk[u]) *reinterpret_cast<u32x4 *>(my.stage + 16 * c) = st[u][j];
                 }
-                wave_lds_fence();
-                const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so,
-                                                 first_entry_past(wo_r[u], wb + kBatchTile - 1));
+                const unsigned hi0 = first_entry_past(wo_r[u], wb + kBatchTile - 1);
+                unsigned off, nb;
+                unsigned long long base; // absolute byte offset of the word's first base (error reporting only)
+                if (hi0 < 64) { // the window reaches past the tile (always, unless > 63 sequences start inside it)
+                    const RelLoc rl = locate_word_rel(wo_r[u], so_r[u], wb, rec[u].base0, hi0, reinterpret_cast<uint32_t *>(my.win_wo));
+                    off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + rec[u].base0 - lo16[u]) + rl.base;
+                    nb = rl.nb;
+                    base = rec[u].base0 + rl.base;
+                } else {
+                    my.win_wo[lane] = wo_r[u];
+                    my.win_so[lane] = so_r[u];
+                    wave_lds_fence();
+                    const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so, hi0);
+                    off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]);
+                    nb = loc.nb;
+                    base = loc.base;
+                }
                 if (!active) continue;
-                const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]);
                 // The word's bytes start at any byte offset: read the 9 ALIGNED LDS dwords that cover 32
                 // bytes from there and funnel-shift (misaligned ds_read_b32 works on gfx950 but runs ~2x
                 // slower).  These kernels are VALU-issue bound (PMC), so there is no per-dword length
@@ -482,11 +519,11 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
                     const uint32_t r = enc4(__builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), bad);
                     if (i < 4) wlo |= r << (8 * i); else whi |= r << (8 * (i - 4));
                 }
-                const unsigned long long keep = loc.nb >= 32 ? ~0ull : ((1ull << (2 * loc.nb)) - 1);
+                const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
                 wlo &= (uint32_t)keep;
                 whi &= (uint32_t)(keep >> 32);
                 __builtin_nontemporal_store(((unsigned long long)whi << 32) | wlo, out + w);
-                if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, loc.base, loc.nb, slot);
+                if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, base, nb, slot);
             }
         }
     }
