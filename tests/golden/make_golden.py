@@ -117,6 +117,15 @@ V["packed_sequence"] = {
     "empty": {"seq": "", "len": 0, "to_vec": "", "src": "src/sequence.rs:42-46,80,250"},
 }
 
+# crate-level integration tests (src/lib.rs:222-265) and hashability (src/sequence.rs:328-338)
+V["crate_integration"] = {
+    "creation_and_analysis": {"seq": "ACGTACGT", "len": 8, "is_empty": False, "to_vec": "ACGTACGT", "gc": 50.0,
+                              "counts": [2, 2, 2, 2], "src": "src/lib.rs:226-240"},
+    "mutations": {"seq": "ACGTACGT", "slice": [2, 6, "GTAC"], "get": [[0, "A"], [7, "T"]], "src": "src/lib.rs:242-253"},
+    "error_handling": {"invalid": "ACGN", "seq": "ACGT", "get_oob": 4, "slice_oob": [2, 5], "src": "src/lib.rs:255-264"},
+    "hashability": {"in_set": ["ACGT", "ACGT"], "not_in_set": "TGCA", "src": "src/sequence.rs:328-338"},
+}
+
 # --- split_packed -----------------------------------------------------------
 # each case: encode(seq), split at idx -> word counts the test asserts, and the decoded halves
 V["split_packed"] = [

@@ -1078,6 +1078,34 @@ def test_packed_sequence_golden(ctx, golden, oracle):
     assert all(p.get(i) == up[i] for i in (0, 1, 31, 32, 33, 4999))
 
 
+def test_crate_integration_cases(ctx, golden):
+    """src/lib.rs:222-265 (the crate's own end-to-end tests) and src/sequence.rs:328-338 through the Python mirror."""
+    import bitnuc_amd as bn
+    g = golden["crate_integration"]
+    v = g["creation_and_analysis"]
+    seq = bn.PackedSequence.new(v["seq"].encode(), ctx)
+    assert seq.len() == v["len"] and seq.is_empty() == v["is_empty"] and seq.to_vec() == v["to_vec"].encode()
+    assert seq.gc_content() == v["gc"] and seq.base_counts() == v["counts"]
+    v = g["mutations"]
+    seq = bn.PackedSequence.new(v["seq"].encode(), ctx)
+    assert seq.slice(v["slice"][0], v["slice"][1]) == v["slice"][2].encode()
+    assert all(seq.get(i) == ord(b) for i, b in v["get"])
+    v = g["error_handling"]
+    with pytest.raises(bn.NucleotideError):
+        bn.PackedSequence.new(v["invalid"].encode(), ctx)
+    seq = bn.PackedSequence.new(v["seq"].encode(), ctx)
+    with pytest.raises(bn.NucleotideError) as ei:
+        seq.get(v["get_oob"])
+    assert ei.value.kind == "IndexOutOfBounds"
+    with pytest.raises(bn.NucleotideError) as ei:
+        seq.slice(*v["slice_oob"])
+    assert ei.value.kind == "InvalidRange"
+    v = g["hashability"]
+    held = {bn.PackedSequence.new(v["in_set"][0].encode(), ctx)}
+    assert bn.PackedSequence.new(v["in_set"][1].encode(), ctx) in held
+    assert bn.PackedSequence.new(v["not_in_set"].encode(), ctx) not in held
+
+
 def test_hip_graph_capture_of_a_step(oracle):
     """The _dev entry points allocate nothing and never synchronise, so an encode+decode step
     can be captured into a hipGraph and replayed on new data (launch-bound pipelines)."""
