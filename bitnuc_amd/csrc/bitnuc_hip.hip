@@ -45,7 +45,7 @@ struct bitnuc_ctx {
     uint32_t *d_sink = nullptr;
     unsigned long long *d_acc = nullptr; // accumulators of the single-launch reductions, zero between launches: [0..2] base_counts C,G,T; [4] hdist (u32)
     unsigned *d_tickets = nullptr;       // [0] base_counts, [1] hdist: arrival counters, zero between launches
-    unsigned reduce_blocks = 2048;
+    unsigned reduce_blocks = 512;
     int enc_variant = 14, dec_variant = 22; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
@@ -421,7 +421,7 @@ int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, 
     if (rc == hipSuccess) rc = hipMalloc(&c->d_sink, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_slots, 0xFF, sizeof(unsigned long long) * kSlots);
     if (rc == hipSuccess) rc = hipMemset(c->d_sink, 0, 64);
-    c->reduce_blocks = (unsigned)c->num_cu * 8; // a resident grid: 8 workgroups of 256 threads per CU
+    c->reduce_blocks = (unsigned)c->num_cu * 2; // a resident grid of 2 workgroups of 256 threads per CU (profiles/r01_sweep13_reduce_grid.txt: the tail of atomics + ticket grows with the grid)
     if (rc == hipSuccess) rc = hipMalloc(&c->d_acc, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_acc, 0, 64);
     if (rc == hipSuccess) rc = hipMalloc(&c->d_tickets, 64);
@@ -498,6 +498,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
     else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
+    else if (!strcmp(key, "reduce_mult")) { prev = (int)(c->reduce_blocks / (unsigned)c->num_cu); if (value >= 1 && value <= 32) c->reduce_blocks = (unsigned)c->num_cu * (unsigned)value; }
     else if (!strcmp(key, "num_variants")) { prev = kNumVariants; }
     else if (!strcmp(key, "num_cu")) { prev = c->num_cu; }
     return prev;
