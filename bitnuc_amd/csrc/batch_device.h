@@ -681,6 +681,73 @@ decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_
     }
 }
 
+// ---------------------------------------------------------------------------------
+// bit-strip decode of back-to-back fixed-length reads (stride == read_len)
+// ---------------------------------------------------------------------------------
+// The tile's output is one contiguous byte run and 16 bytes of it are exactly 32 bits of the run's 2-bit stream.
+// So the wave first rebuilds that stream, pad bits squeezed out, in an LDS strip indexed from the run's 16-byte
+// aligned start: lane = one word, masked to its 2*nb bits and OR-ed in at bit 2*(byte offset) with three
+// ds_or_b32 (the strip is zeroed first).  Strip dword c then IS output chunk c: a lane reads one dword, decodes 16
+// bases and issues one coalesced dwordx4 store -- the store pattern of the bulk decode, no byte staging and no
+// predicated LDS stores.  Only the run's first / last chunk (shared with the neighbouring tiles) is written
+// byte-wise, through the wave's stage buffer and store_stage_chunk.
+constexpr int kStripDwords = kBatchTile * 2 + 8; // 64 words x 64 bits + the <= 15-byte lead + slack
+
+__global__ void __launch_bounds__(kBlock)
+decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned wpr, unsigned magic,
+                          unsigned long long total_words, uint8_t *__restrict__ out) {
+    __shared__ uint32_t strips[kBatchWaves][kStripDwords];
+    __shared__ __attribute__((aligned(16))) uint8_t edge[kBatchWaves][2][16];
+    uint32_t *strip = strips[wave_in_block()];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave_in_block(); tile < ntiles;
+         tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        const unsigned long long wb = tile * kBatchTile;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        const bool active = lane <= last;
+        const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last));
+        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic);
+        const unsigned long long base = pos.r * read_len + 32ull * pos.j; // stride == read_len
+        const unsigned left = read_len - 32 * pos.j, nb = left < 32 ? left : 32u;
+        const unsigned long long span_lo = read_lane_u64(base, 0), span_hi = read_lane_u64(base + nb, last);
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + span_lo, hi = reinterpret_cast<uintptr_t>(out) + span_hi;
+        const uintptr_t lo16 = lo & ~(uintptr_t)15;
+        wave_lds_fence(); // previous trip's readers are done
+#pragma unroll
+        for (int j = 0; j < (kStripDwords + 63) / 64; ++j)
+            if (lane + 64 * j < (unsigned)kStripDwords) strip[lane + 64 * j] = 0u;
+        wave_lds_fence();
+        if (active) {
+            const unsigned bit = 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16); // < 2 * (15 + 2048)
+            const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
+            const unsigned long long v = word & keep;
+            const unsigned sh = bit & 31;
+            const unsigned long long t = v << sh; // bits 0..63 of the 96-bit shifted value; the rest is the third dword
+            uint32_t *dst = strip + (bit >> 5);
+            atomicOr(dst, (uint32_t)t);
+            atomicOr(dst + 1, (uint32_t)(t >> 32));
+            atomicOr(dst + 2, sh ? (uint32_t)(v >> 32) >> (32 - sh) : 0u);
+        }
+        wave_lds_fence();
+        const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4); // <= 130
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned c = lane + 64 * j;
+            if (c >= nchunk) break;
+            const u32x4 d = dec16(strip[c]);
+            const uintptr_t g = lo16 + 16 * (uintptr_t)c;
+            if (g >= lo && g + 16 <= hi) {
+                __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
+            } else { // the run's first or last chunk: only its own bytes
+                uint8_t *e = edge[wave_in_block()][c ? 1 : 0];
+                *reinterpret_cast<u32x4 *>(e) = d;
+                store_stage_chunk(e, g, lo, hi);
+            }
+        }
+    }
+}
+
 // The decode side keeps a workgroup-level tile (128 words, 128 threads, workgroup barriers):
 // measured faster than the wave-private form for decode (0.35 vs 0.47 ms on 150-base reads),
 // while encode is faster wave-private with the tile records (0.33 vs 0.33-0.35 ms).
@@ -765,45 +832,45 @@ decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned
             continue;
         }
         __syncthreads();
+        // The tile's output is one contiguous byte run, 16 bytes of which are 32 bits of its 2-bit stream: rebuild that
+        // stream (pad bits squeezed out) in an LDS strip indexed from the run's 16-byte aligned start, as in
+        // decode_fixed_strip_kernel -- zero, three ds_or_b32 per word, then strip dword c IS output chunk c.
+        uint32_t *strip = reinterpret_cast<uint32_t *>(stage);
+        constexpr unsigned kStrip = kBatchDecBlock * 2 + 8;
+        for (unsigned i = t; i < kStrip; i += kBatchDecBlock) strip[i] = 0u;
         const WordLoc loc = locate_word_block(offsets, word_offsets, count, rec.owner, wb, w, active, win_wo, win_so);
         if (t == 0) span[0] = loc.base;
         if (active && (w + 1 == total_words || t == kBatchDecBlock - 1)) span[1] = loc.base + loc.nb;
-        __syncthreads();
+        __syncthreads(); // also orders the zeroing before the ORs
         const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + span[0], hi = reinterpret_cast<uintptr_t>(out) + span[1];
         const uintptr_t lo16 = lo & ~(uintptr_t)15;
         if (active) {
-            const unsigned off = (unsigned)(reinterpret_cast<uintptr_t>(out) + loc.base - lo16);
-            const u32x4 a = dec16((uint32_t)word), b = dec16((uint32_t)(word >> 32));
-            const uint32_t d[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0u};
-            // write the lane's nb bytes at byte offset `off`: <= 3 head bytes up to the next
-            // 4-byte boundary, then ALIGNED dwords re-cut from d[] with v_alignbyte, then <= 3
-            // tail bytes (misaligned ds_write_b32 works on gfx950 but runs ~2x slower)
-            // Branch-free placement (these kernels are VALU/SALU-issue bound): <= 3 predicated byte
-            // stores for the head, 8 predicated aligned dword stores, <= 3 predicated byte stores
-            // for the tail, whose bytes are re-decoded straight from the packed word.
-            const unsigned head = (4u - (off & 3u)) & 3u; // bytes before the first aligned dword
-            const unsigned hb = head < loc.nb ? head : loc.nb;
-            const unsigned body = loc.nb - hb, ndw = body >> 2, tb = body & 3;
-            if (hb > 0) stage[off] = (uint8_t)d[0];
-            if (hb > 1) stage[off + 1] = (uint8_t)(d[0] >> 8);
-            if (hb > 2) stage[off + 2] = (uint8_t)(d[0] >> 16);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(stage + off + hb);
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-                if ((unsigned)m < ndw) dst[m] = __builtin_amdgcn_alignbyte(d[m + 1], d[m], head); // lane bytes [head+4m, head+4m+4)
-            const unsigned q = hb + 4 * ndw;                               // first tail base
-            const uint32_t tv = dec4((uint32_t)(word >> (2 * q)) & 0xFFu); // bases q..q+3 as ASCII
-            uint8_t *tp = stage + off + q;
-            if (tb > 0) tp[0] = (uint8_t)tv;
-            if (tb > 1) tp[1] = (uint8_t)(tv >> 8);
-            if (tb > 2) tp[2] = (uint8_t)(tv >> 16);
+            const unsigned bit = 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + loc.base - lo16);
+            const unsigned long long keep = loc.nb >= 32 ? ~0ull : ((1ull << (2 * loc.nb)) - 1);
+            const unsigned long long v = word & keep;
+            const unsigned sh = bit & 31;
+            const unsigned long long tv = v << sh; // bits 0..63 of the 96-bit shifted value; the rest is the third dword
+            uint32_t *dst = strip + (bit >> 5);
+            atomicOr(dst, (uint32_t)tv);
+            atomicOr(dst + 1, (uint32_t)(tv >> 32));
+            atomicOr(dst + 2, sh ? (uint32_t)(v >> 32) >> (32 - sh) : 0u);
         }
         __syncthreads();
         // coalesced write-out; the first/last 16-byte chunk may be shared with a neighbouring
-        // workgroup's span, so only this span's bytes are written there
+        // workgroup's span, so only this span's bytes are written there (through a 16-byte LDS slot)
+        uint8_t *edge = stage + 4 * kStrip; // two 16-byte slots behind the strip
         const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
-        for (unsigned c = t; c < nchunk; c += kBatchDecBlock)
-            store_stage_chunk(stage + 16 * c, lo16 + 16 * (uintptr_t)c, lo, hi);
+        for (unsigned c = t; c < nchunk; c += kBatchDecBlock) {
+            const u32x4 d = dec16(strip[c]);
+            const uintptr_t g = lo16 + 16 * (uintptr_t)c;
+            if (g >= lo && g + 16 <= hi) {
+                __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
+            } else {
+                uint8_t *e = edge + (c ? 16 : 0);
+                *reinterpret_cast<u32x4 *>(e) = d;
+                store_stage_chunk(e, g, lo, hi);
+            }
+        }
     }
 }
 

@@ -52,6 +52,7 @@ struct bitnuc_ctx {
     int batch_slide = 1;                 // stride 1 (every window of a sequence), 2, 4, 8, 16 batches use kmer_slide_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
     int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
+    int fixed_dec_strip = 1;               // decode_fixed (back-to-back reads): 1 = rebuild the tile's 2-bit stream in LDS, decode aligned chunks
     int batch_stream = 0;                  // encode_batch: 1 = cut the tile's 2-bit stream, 0 = funnel raw bytes per word
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
@@ -494,6 +495,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
     else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
     else if (!strcmp(key, "fixed_stream")) { prev = c->fixed_stream; if (value == 0 || value == 1) c->fixed_stream = value; }
+    else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value == 0 || value == 1) c->fixed_dec_strip = value; }
     else if (!strcmp(key, "batch_stream")) { prev = c->batch_stream; if (value == 0 || value == 1) c->batch_stream = value; }
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
@@ -967,7 +969,8 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
     const unsigned grid = grid_for(c, (total + per_block - 1) / per_block);
     const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
     const unsigned magic = (unsigned)((0x100000000ull + wpr - 1) / wpr);
-    if (stride == read_len) decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, total, d_out);
+    if (stride == read_len && c->fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, total, d_out);
+    else if (stride == read_len) decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, total, d_out);
     else decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, total, d_out);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
