@@ -748,125 +748,93 @@ decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned
     }
 }
 
-// The decode side keeps a workgroup-level tile (128 words, 128 threads, workgroup barriers):
-// measured faster than the wave-private form for decode (0.35 vs 0.47 ms on 150-base reads),
-// while encode is faster wave-private with the tile records (0.33 vs 0.33-0.35 ms).
-constexpr int kBatchDecBlock = 128;
-constexpr int kBatchWinStep = 64;
-constexpr int kBatchBlockWin = 192;
-constexpr int kBatchDecStage = kBatchDecBlock * 32 + 64;
-
-// Fills the LDS window for the workgroup that starts at word wb (whose owner is sb) and
-// resolves this lane's word.  The window grows in steps of 64 sequences until it covers
-// the workgroup's last word (150-base reads need 27 entries; 1-word sequences need 129).
-__device__ __forceinline__ WordLoc locate_word_block(const unsigned long long *__restrict__ offsets,
-                                               const unsigned long long *__restrict__ word_offsets,
-                                               unsigned long long count, unsigned long long sb, unsigned long long wb,
-                                               unsigned long long w, bool active, unsigned long long *win_wo,
-                                               unsigned long long *win_so) {
-    unsigned filled = 0;
-    for (;;) {
-        for (unsigned i = filled + threadIdx.x; i < filled + kBatchWinStep && i <= (unsigned)kBatchBlockWin; i += kBatchDecBlock) {
-            const unsigned long long s = sb + i < count ? sb + i : count;
-            win_wo[i] = word_offsets[s];
-            win_so[i] = offsets[s];
-        }
-        filled = filled + kBatchWinStep <= (unsigned)kBatchBlockWin + 1 ? filled + kBatchWinStep : kBatchBlockWin + 1;
-        __syncthreads();
-        if (filled > (unsigned)kBatchBlockWin || win_wo[filled - 1] > wb + kBatchDecBlock - 1) break; // uniform
-    }
-    // first of the first 64 entries that starts past the workgroup's last word: bounds the search (every
-    // wave computes the same value from LDS with one ballot; 150-base reads: 27 instead of 64 entries)
-    const unsigned hi0 = first_entry_past(win_wo[threadIdx.x & 63], wb + kBatchDecBlock - 1);
-    WordLoc loc{0, 0};
-    if (!active) return loc;
-    unsigned lo = 1, hi = hi0 < 64 ? hi0 : filled; // upper_bound in the window; entry 0 (the owner) never starts past w
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (win_wo[mid] <= w) lo = mid + 1; else hi = mid;
-    }
-    unsigned long long w0, s0, s1;
-    if (lo < filled) {
-        w0 = win_wo[lo - 1]; s0 = win_so[lo - 1]; s1 = win_so[lo];
-    } else { // more sequences start inside this workgroup than the window holds
-        const unsigned long long s = owner_of_word(word_offsets, count, w);
-        w0 = word_offsets[s]; s0 = offsets[s]; s1 = offsets[s + 1];
-    }
-    loc.base = s0 + ((w - w0) << 5);
-    const unsigned long long left = s1 - loc.base;
-    loc.nb = left < 32 ? (unsigned)left : 32u;
-    return loc;
-}
-
 // ---------------------------------------------------------------------------------
 // batched decode: sequence i's bases go to out[offsets[i] .. offsets[i+1])
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBatchDecBlock)
+// Wave-private, like encode_batch: the tile is the wave's 64 words (same records, same tile-relative lookup), the
+// output run is rebuilt as a 2-bit stream in the wave's bit strip (see decode_fixed_strip_kernel) and leaves as
+// aligned dwordx4 stores; no workgroup barrier.  (A 128-word workgroup tile with a byte scatter was the faster
+// form until the bit strip: profiles/r01_ab_decode_batch_wave_private.txt.)
+__global__ void __launch_bounds__(kBlock)
 decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ word_offsets,
-                    const unsigned long long *__restrict__ offsets, unsigned long long count,
-                    unsigned long long total_words, const TileRec *__restrict__ recs,
-                    uint8_t *__restrict__ out) {
-    __shared__ unsigned long long win_wo[kBatchBlockWin + 1], win_so[kBatchBlockWin + 1];
-    __shared__ unsigned long long span[2];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kBatchDecStage];
-    const unsigned t = threadIdx.x;
-    for (unsigned long long wb = (unsigned long long)blockIdx.x * kBatchDecBlock; wb < total_words;
-         wb += (unsigned long long)gridDim.x * kBatchDecBlock) {
-        const unsigned long long w = wb + t;
-        const bool active = w < total_words;
-        const unsigned long long word = active ? __builtin_nontemporal_load(words + w) : 0ull; // independent of the lookup: issued first
-        const TileRec rec = recs[wb / kBatchTile]; // block-uniform
-        if (rec.avail >= kBatchDecBlock * 32 && ((reinterpret_cast<uintptr_t>(out) + rec.base0) & 15) == 0) {
-            // fast tile (block-uniform): 128 full words inside one sequence = a plain 4 KiB bulk
-            // decode.  The words cross LDS once so that thread t owns 16-base groups t and t+128:
-            // every dwordx4 store of a wave is then one contiguous 1 KiB span.
-            unsigned long long *xw = reinterpret_cast<unsigned long long *>(stage);
-            __syncthreads(); // previous trip's LDS readers are done
-            xw[t] = word;
-            __syncthreads();
-            const uint32_t *x32 = reinterpret_cast<const uint32_t *>(stage);
-            const uint32_t h0 = x32[t], h1 = x32[kBatchDecBlock + t];
+                         const unsigned long long *__restrict__ offsets, unsigned long long count,
+                         unsigned long long total_words, const TileRec *__restrict__ recs, uint8_t *__restrict__ out) {
+    __shared__ uint32_t strips[kBatchWaves][kStripDwords];
+    __shared__ unsigned long long wins[kBatchWaves][2 * (kBatchWin + 1)];
+    __shared__ __attribute__((aligned(16))) uint8_t edge[kBatchWaves][2][16];
+    const unsigned wv = wave_in_block(), lane = threadIdx.x & 63;
+    uint32_t *strip = strips[wv];
+    unsigned long long *win_wo = wins[wv], *win_so = wins[wv] + kBatchWin + 1;
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wv; tile < ntiles;
+         tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        const unsigned long long wb = tile * kBatchTile;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        const bool active = lane <= last;
+        const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last)); // independent of the lookup
+        const TileRec rec = recs[tile];
+        if (rec.avail >= kBatchTile * 32 && ((reinterpret_cast<uintptr_t>(out) + rec.base0) & 15) == 0) {
+            // fast tile (wave-uniform): 64 full words inside one sequence; the words cross the strip once so that
+            // lane l owns 16-base groups l and l+64
+            wave_lds_fence();
+            reinterpret_cast<unsigned long long *>(strip)[lane] = word;
+            wave_lds_fence();
+            const uint32_t h0 = strip[lane], h1 = strip[64 + lane];
             uint8_t *dst = out + rec.base0;
-            store_group<true, true>(dst + 16 * t, dec16(h0));
-            store_group<true, true>(dst + 16 * (t + kBatchDecBlock), dec16(h1));
+            store_group<true, true>(dst + 16 * lane, dec16(h0));
+            store_group<true, true>(dst + 16 * (lane + 64), dec16(h1));
             continue;
         }
-        __syncthreads();
-        // The tile's output is one contiguous byte run, 16 bytes of which are 32 bits of its 2-bit stream: rebuild that
-        // stream (pad bits squeezed out) in an LDS strip indexed from the run's 16-byte aligned start, as in
-        // decode_fixed_strip_kernel -- zero, three ds_or_b32 per word, then strip dword c IS output chunk c.
-        uint32_t *strip = reinterpret_cast<uint32_t *>(stage);
-        constexpr unsigned kStrip = kBatchDecBlock * 2 + 8;
-        for (unsigned i = t; i < kStrip; i += kBatchDecBlock) strip[i] = 0u;
-        const WordLoc loc = locate_word_block(offsets, word_offsets, count, rec.owner, wb, w, active, win_wo, win_so);
-        if (t == 0) span[0] = loc.base;
-        if (active && (w + 1 == total_words || t == kBatchDecBlock - 1)) span[1] = loc.base + loc.nb;
-        __syncthreads(); // also orders the zeroing before the ORs
-        const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + span[0], hi = reinterpret_cast<uintptr_t>(out) + span[1];
+        const unsigned long long si = rec.owner + lane < count ? rec.owner + lane : count;
+        const unsigned long long wo_r = word_offsets[si], so_r = offsets[si];
+        const unsigned hi0 = first_entry_past(wo_r, wb + kBatchTile - 1);
+        wave_lds_fence(); // previous trip's readers are done
+#pragma unroll
+        for (int j = 0; j < (kStripDwords + 63) / 64; ++j)
+            if (lane + 64 * j < (unsigned)kStripDwords) strip[lane + 64 * j] = 0u;
+        unsigned long long base; // absolute byte offset of the lane's word
+        unsigned nb;
+        const unsigned long long wq = wb + (lane < last ? lane : last); // inactive lanes mirror the last word
+        if (hi0 < 64) {
+            const RelLoc rl = locate_word_rel(wo_r, so_r, wb, rec.base0, hi0, reinterpret_cast<uint32_t *>(win_wo));
+            // locate_word_rel resolves word wb + lane; an inactive lane's result is never used
+            base = rec.base0 + rl.base;
+            nb = rl.nb;
+        } else {
+            win_wo[lane] = wo_r;
+            win_so[lane] = so_r;
+            wave_lds_fence();
+            const WordLoc loc = locate_word(offsets, word_offsets, count, rec.owner, wb, wq, true, win_wo, win_so, hi0);
+            base = loc.base;
+            nb = loc.nb;
+        }
+        const unsigned long long span_hi = read_lane_u64(base + nb, last);
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + rec.base0, hi = reinterpret_cast<uintptr_t>(out) + span_hi;
         const uintptr_t lo16 = lo & ~(uintptr_t)15;
+        wave_lds_fence(); // zeroing (and the lookup's LDS traffic) before the ORs
         if (active) {
-            const unsigned bit = 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + loc.base - lo16);
-            const unsigned long long keep = loc.nb >= 32 ? ~0ull : ((1ull << (2 * loc.nb)) - 1);
+            const unsigned bit = 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16);
+            const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
             const unsigned long long v = word & keep;
             const unsigned sh = bit & 31;
-            const unsigned long long tv = v << sh; // bits 0..63 of the 96-bit shifted value; the rest is the third dword
+            const unsigned long long tv = v << sh;
             uint32_t *dst = strip + (bit >> 5);
             atomicOr(dst, (uint32_t)tv);
             atomicOr(dst + 1, (uint32_t)(tv >> 32));
             atomicOr(dst + 2, sh ? (uint32_t)(v >> 32) >> (32 - sh) : 0u);
         }
-        __syncthreads();
-        // coalesced write-out; the first/last 16-byte chunk may be shared with a neighbouring
-        // workgroup's span, so only this span's bytes are written there (through a 16-byte LDS slot)
-        uint8_t *edge = stage + 4 * kStrip; // two 16-byte slots behind the strip
+        wave_lds_fence();
         const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
-        for (unsigned c = t; c < nchunk; c += kBatchDecBlock) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned c = lane + 64 * j;
+            if (c >= nchunk) break;
             const u32x4 d = dec16(strip[c]);
             const uintptr_t g = lo16 + 16 * (uintptr_t)c;
             if (g >= lo && g + 16 <= hi) {
                 __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
             } else {
-                uint8_t *e = edge + (c ? 16 : 0);
+                uint8_t *e = edge[wv][c ? 1 : 0];
                 *reinterpret_cast<u32x4 *>(e) = d;
                 store_stage_chunk(e, g, lo, hi);
             }

@@ -859,8 +859,9 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64
     DeviceGuard g(c->device);
     const TileRec *recs;
     if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
-    const unsigned grid = grid_for(c, (total_words + kBatchDecBlock - 1) / kBatchDecBlock, kBatchDecBlock);
-    decode_batch_kernel<<<grid, kBatchDecBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words),
+    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
+    const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
+    decode_batch_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words),
                                                         reinterpret_cast<const unsigned long long *>(d_word_offsets),
                                                         reinterpret_cast<const unsigned long long *>(d_offsets), count, total_words, recs, d_out);
     HIPCHK(hipGetLastError());
