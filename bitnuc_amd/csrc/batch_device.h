@@ -338,7 +338,8 @@ word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned lon
 // strip[c] = codes of chunk c (already in registers: chunk lane+64r in v[r]); validates every
 // chunk byte that lies inside the buffer.  Wave-private; call between two wave_lds_fence()s.
 __device__ __forceinline__ void stream_fill(const u32x4 (&v)[3], unsigned nchunk, uintptr_t lo16, const uint8_t *__restrict__ seq,
-                                            unsigned long long seq_end, uint32_t *strip, unsigned long long *__restrict__ slot) {
+                                            unsigned long long seq_end, uint32_t *strip, unsigned long long *__restrict__ slot,
+                                            unsigned long long seq_begin = 0) {
     const unsigned lane = threadIdx.x & 63;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -348,8 +349,8 @@ __device__ __forceinline__ void stream_fill(const u32x4 (&v)[3], unsigned nchunk
             strip[c] = enc16(v[r], bad);
             if (__builtin_expect(residue_is_bad(bad), 0)) {
                 // a 16-byte aligned chunk may stick out of the buffer at either end: look only at bytes inside it
-                const uintptr_t g = lo16 + 16 * (uintptr_t)c, s0 = reinterpret_cast<uintptr_t>(seq), e0 = s0 + seq_end;
-                const uintptr_t a = g > s0 ? g : s0, b = g + 16 < e0 ? g + 16 : e0;
+                const uintptr_t g = lo16 + 16 * (uintptr_t)c, s0 = reinterpret_cast<uintptr_t>(seq), e0 = s0 + seq_end, b0 = s0 + seq_begin;
+                const uintptr_t a = g > b0 ? g : b0, b = g + 16 < e0 ? g + 16 : e0;
                 if (b > a) rescan_bytes(seq, (unsigned long long)(a - s0), (unsigned)(b - a), slot);
             }
         }
@@ -412,6 +413,7 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
     const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
     const unsigned long long seq_end = offsets[count]; // end of the sequence buffer: bounds the 2 KiB tile fetch
+    const unsigned long long seq_begin = offsets[0];   // bytes before the batch are never examined
     for (unsigned long long t0 = ((unsigned long long)blockIdx.x * kBatchWaves + wave) * U; t0 < ntiles;
          t0 += (unsigned long long)gridDim.x * kBatchWaves * U) {
         // (A) records
@@ -463,19 +465,50 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
                 }
             }
             if constexpr (STREAM) {
-                // The sequences are back to back, so the tile is a bulk encode whose 2-bit stream is cut at
-                // the word starts: chunks -> u32 code words in the wave's strip, then one 64-bit funnel per
-                // word (stream_fill / stream_cut).
+                // The sequences are back to back, so the tile is a bulk encode whose 2-bit stream is cut at the word
+                // starts (stream_fill / stream_cut).  The lookup runs first: it gives the exact end of the tile's last
+                // word, so only the chunks that hold the tile's bases are encoded (two rounds of enc16, not three).
                 uint32_t *strip = reinterpret_cast<uint32_t *>(my.stage);
+                const unsigned hi0 = first_entry_past(wo_r[u], wb + kBatchTile - 1);
                 wave_lds_fence(); // previous trip's LDS readers are done
-                my.win_wo[lane] = wo_r[u];
-                my.win_so[lane] = so_r[u];
-                stream_fill(st[u], nchunk[u], lo16[u], seq, seq_end, strip, slot);
+                // the first 2 KiB of chunks are needed by (almost) every tile: encode them while the lookup is in flight
+                const unsigned n01 = nchunk[u] < 128 ? nchunk[u] : 128u;
+                stream_fill(st[u], n01, lo16[u], seq, seq_end, strip, slot, seq_begin);
+                unsigned off, nb;
+                unsigned long long base;
+                const unsigned lastl = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+                if (hi0 < 64) {
+                    const RelLoc rl = locate_word_rel(wo_r[u], so_r[u], wb, rec[u].base0, hi0, reinterpret_cast<uint32_t *>(my.win_wo));
+                    nb = rl.nb;
+                    base = rec[u].base0 + rl.base;
+                } else {
+                    my.win_wo[lane] = wo_r[u];
+                    my.win_so[lane] = so_r[u];
+                    wave_lds_fence();
+                    const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, wb + (lane < lastl ? lane : lastl), true,
+                                                    my.win_wo, my.win_so, hi0);
+                    nb = loc.nb;
+                    base = loc.base;
+                }
+                off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + base - lo16[u]);
+                const unsigned long long span_hi = read_lane_u64(base + nb, lastl);
+                const unsigned need = (unsigned)((reinterpret_cast<uintptr_t>(seq) + span_hi - lo16[u] + 15) >> 4);
+                if (need > 128) { // wave-uniform and rare: the tile's last bases sit in the third round of chunks (<= 2 of them)
+                    const unsigned c = 128 + lane;
+                    if (c < need && c < nchunk[u]) {
+                        uint32_t bad = 0;
+                        strip[c] = enc16(st[u][2], bad);
+                        if (__builtin_expect(residue_is_bad(bad), 0)) {
+                            const uintptr_t g = lo16[u] + 16 * (uintptr_t)c, s0 = reinterpret_cast<uintptr_t>(seq), e0 = s0 + seq_end;
+                            const uintptr_t b = g + 16 < e0 ? g + 16 : e0;
+                            if (b > g) rescan_bytes(seq, (unsigned long long)(g - s0), (unsigned)(b - g), slot);
+                        }
+                    }
+                    if (lane < 4) strip[(need < nchunk[u] ? need : nchunk[u]) + lane] = 0; // the funnel may read 2 dwords past the last chunk
+                }
                 wave_lds_fence();
-                const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so,
-                                                 first_entry_past(wo_r[u], wb + kBatchTile - 1));
                 if (!active) continue;
-                const unsigned long long word = stream_cut(strip, (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]), loc.nb);
+                const unsigned long long word = stream_cut(strip, off, nb);
                 __builtin_nontemporal_store(word, out + w);
             } else {
                 wave_lds_fence(); // previous trip's LDS readers are done

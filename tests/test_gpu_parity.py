@@ -464,8 +464,16 @@ def _oracle_batch(oracle, seq, off):
     return (np.concatenate(words) if words else np.zeros(0, np.uint64)), np.array(wo, dtype=np.uint64)
 
 
+@pytest.fixture(params=[0, 1], ids=["byte-funnel", "stream-cut"])
+def batch_body(request, ctx):
+    """Both tile bodies of encode_batch (knob batch_stream): the raw-byte funnel and the stream cut."""
+    prev = ctx.set_variant("batch_stream", request.param)
+    yield request.param
+    ctx.set_variant("batch_stream", prev)
+
+
 @pytest.mark.parametrize("shape", ["reads150", "tiny", "mixed", "with_empties", "one_long", "many_empties"])
-def test_batch_encode_decode_vs_oracle_loop(ctx, oracle, shape):
+def test_batch_encode_decode_vs_oracle_loop(ctx, oracle, shape, batch_body):
     lengths = {
         "reads150": [150] * 3000,
         "tiny": list(RNG.integers(1, 5, size=5000)),
@@ -483,7 +491,7 @@ def test_batch_encode_decode_vs_oracle_loop(ctx, oracle, shape):
     assert bytes(back) == bytes(seq).upper(), shape
 
 
-def test_batch_offsets_base_and_errors(ctx, oracle):
+def test_batch_offsets_base_and_errors(ctx, oracle, batch_body):
     import bitnuc_amd as bn
     lengths = list(RNG.integers(1, 300, size=1500))
     seq, off = _ragged(lengths)
