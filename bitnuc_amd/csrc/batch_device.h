@@ -9,7 +9,9 @@
 //     contiguous span of at most 2 KiB because sequences and their words are contiguous;
 //     waves never wait for each other (no workgroup barrier anywhere in these kernels);
 //   * the span moves between HBM and LDS with coalesced 16-byte accesses; lanes touch their
-//     (unaligned, 1..32-byte) pieces in LDS only;
+//     (unaligned, 1..32-byte) pieces in LDS only: encode funnels them out of the staged bytes
+//     (or cuts the tile's 2-bit stream), decode ORs its words into a bit strip whose dwords are
+//     the output's aligned 16-byte chunks;
 //   * word -> sequence lookup: a small pre-kernel finds the owner of every tile's first word
 //     (one binary search per tile, all in parallel), then each lane searches the wave's LDS
 //     window of the next offsets (global fallback if a run of empty sequences overflows it).
