@@ -91,14 +91,22 @@ struct DeviceGuard { // hipSetDevice is per-thread state: every entry point sele
 
 int ensure_scratch(bitnuc_ctx *c, int which, size_t bytes, bitnuc_err *err) {
     if (bytes <= c->scratch_cap[which]) return BITNUC_OK;
+    const size_t old_cap = c->scratch_cap[which];
     if (c->scratch[which]) {
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipFree(c->scratch[which]));
         c->scratch[which] = nullptr;
         c->scratch_cap[which] = 0;
     }
-    size_t cap = (bytes + 4095) & ~(size_t)4095;
-    HIPCHK(hipMalloc(&c->scratch[which], cap));
+    // grow geometrically (a caller whose batches creep up in size should not reallocate every call), 4 KiB granules
+    size_t want = old_cap + old_cap / 2;
+    if (want < bytes) want = bytes;
+    size_t cap = (want + 4095) & ~(size_t)4095;
+    if (hipMalloc(&c->scratch[which], cap) != hipSuccess) { // not enough for the head-room: take exactly what is needed
+        (void)hipGetLastError();
+        cap = (bytes + 4095) & ~(size_t)4095;
+        HIPCHK(hipMalloc(&c->scratch[which], cap));
+    }
     c->scratch_cap[which] = cap;
     return BITNUC_OK;
 }
