@@ -351,6 +351,18 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         done = (size_t)(rounds * (kScanWaveWindows / stride));
         if (done >= count) return hipSuccess;
     }
+    if (stride >= 3 && stride < 32 && k >= stride && done == 0 && c->batch_slide && aligned16(kmers) &&
+        (count - 1) * stride + k >= 1024) {
+        // any other small stride with overlapping k-mers: the sliding round with per-lane window selection
+        const unsigned long long rounds = ((count - 1) * stride + k - 1024) / kScanWaveWindows + 1;
+        const unsigned grid = grid_for(c, (rounds + kBlock / 64 - 1) / (kBlock / 64));
+        const unsigned magic = (unsigned)((0x100000000ull + stride - 1) / stride); // exact floor(t / stride) for t < 2^16
+        kmer_slide_any_kernel<<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, (unsigned)stride, magic, rounds, o, slot);
+        hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+        done = (size_t)((rounds * kScanWaveWindows + stride - 1) / stride); // k-mers that start before the last round's end
+        if (done >= count) return hipSuccess;
+    }
     // general strides, and the < 64 k-mers a dense batch leaves over.  The error slot holds
     // byte offsets relative to `kmers`, so the leftover launch passes the offset it starts at.
     const size_t rest = count - done;

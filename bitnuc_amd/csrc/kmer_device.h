@@ -333,6 +333,53 @@ kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long lon
     }
 }
 
+// Any other stride 3 <= S < 32 with k >= S: the same round, but a lane keeps only the windows whose position is a
+// multiple of S (at most ceil(16/S) of its 16, found with one wave-uniform division for the round's first base and a
+// 32-bit multiply-high step per lane), shifts them out with a per-lane v_alignbit amount, and drops them into the
+// strip at their output index, so the strip holds the round's k-mers densely and in order; they leave as 8-byte
+// stores, 512 contiguous bytes per instruction.
+__global__ void __launch_bounds__(kBlock)
+kmer_slide_any_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned S, unsigned magic /* ceil(2^32 / S) */,
+                      unsigned long long rounds, unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
+    constexpr int kMaxOut = kScanWaveWindows / 3 + 2; // S >= 3
+    __shared__ unsigned long long strips[kBlock / 64][kMaxOut + 2];
+    const unsigned lane = threadIdx.x & 63;
+    unsigned long long *strip = strips[wave_in_block()];
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (kBlock / 64) + wave_in_block();
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * (kBlock / 64);
+    const uint32_t mlo = k >= 16 ? ~0u : (1u << (2 * k)) - 1u;
+    const uint32_t mhi = k <= 16 ? 0u : (k == 32 ? ~0u : (1u << (2 * k - 32)) - 1u);
+    for (unsigned long long r = wave; r < rounds; r += nwaves) {
+        const unsigned long long wb = r * kScanWaveWindows; // first base of the round (wave-uniform)
+        const unsigned long long q_w = wb / S;
+        const unsigned r_w = (unsigned)(wb - q_w * S);
+        const unsigned long long first_out = q_w + (r_w ? 1 : 0);                 // first k-mer that starts in this round
+        const unsigned n_out = (unsigned)((wb + kScanWaveWindows - 1) / S - first_out + 1); // k-mers that start in [wb, wb + 992)
+        const u32x4 v = load_group<true, true>(seq + wb + 16 * lane);
+        uint32_t bad = 0;
+        const uint32_t c0 = enc16(v, bad);
+        if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, wb + 16 * lane, 16, slot);
+        const uint32_t c1 = wave_shl1(c0), c2 = wave_shl1(c1);
+        const unsigned t = r_w + 16 * lane;              // position of the lane's first base, relative to q_w * S
+        const unsigned q_l = __umulhi(t, magic), r_l = t - q_l * S;
+        unsigned j = r_l ? S - r_l : 0u;                 // offset of the lane's first kept window
+        unsigned o = q_l + (r_l ? 1u : 0u) - (r_w ? 1u : 0u); // its index among the round's k-mers
+        wave_lds_fence(); // previous round's readers are done
+        if (lane < 62) {
+#pragma unroll 1
+            for (; j < 16; j += S, ++o) {
+                const uint32_t lo = (j ? __builtin_amdgcn_alignbit(c1, c0, 2 * j) : c0) & mlo;
+                const uint32_t hi = (j ? __builtin_amdgcn_alignbit(c2, c1, 2 * j) : c1) & mhi;
+                strip[o] = ((unsigned long long)hi << 32) | lo;
+            }
+        }
+        wave_lds_fence();
+        unsigned long long *dst = out + first_out;
+#pragma unroll 1
+        for (unsigned i = lane; i < n_out; i += 64) __builtin_nontemporal_store(strip[i], dst + i);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // bulk hdist: sum over words of the per-word mismatch count (u32, wraps like Rust release)
 // ---------------------------------------------------------------------------------

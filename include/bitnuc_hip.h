@@ -102,8 +102,8 @@ int bitnuc_hdist(bitnuc_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *
 /* Batched as_2bit over `count` k-mers, k-mer j at kmers + j*stride (README.md:52-56
  * host-loop idiom; stride 1 = every window of a sequence, src/lib.rs:170-173).
  * k > 32 -> SEQUENCE_TOO_LONG(k).  First invalid examined byte -> INVALID_BASE.
- * Any stride >= 1 works; stride == k (dense) and strides 1, 2, 4, 8, 16 with k >= stride (overlapping
- * windows) have dedicated kernels and run 3x faster than the general one. */
+ * Any stride >= 1 works; stride == k (dense) and every stride <= k below 32 (overlapping windows; 1 = all
+ * windows of a sequence) have dedicated kernels and run about 3x faster than the general one. */
 int bitnuc_as_2bit_batch(bitnuc_ctx *ctx, const uint8_t *kmers, size_t k, size_t stride, size_t count, uint64_t *out, bitnuc_err *err);
 /* Sliding-window k-mer pack + Hamming distance to a packed query: dist[i] =
  * hdist_scalar(as_2bit(ref[i..i+k]), query, k) for i in 0..n-k+1

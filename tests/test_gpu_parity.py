@@ -380,6 +380,34 @@ def test_kmer_windows_small_power_of_two_strides(ctx, oracle, k, stride):
     assert (ei.value.byte, ei.value.index) == (oe.value.byte, oe.value.index) == (ord("N"), pos)
 
 
+@pytest.mark.parametrize("k,stride", [(31, 3), (31, 5), (31, 6), (31, 7), (21, 12), (31, 24), (32, 31), (32, 17), (16, 9), (7, 3), (31, 30)])
+def test_kmer_windows_other_small_strides(ctx, oracle, k, stride):
+    """Overlapping k-mers at a stride that is not a power of two: the sliding round with per-lane window selection."""
+    import bitnuc_amd as bn
+    for count in [1, 40, 330 // max(1, stride // 3), 1024 // stride + 1, 2016 // stride + 3, 5 * 992 // stride + 7, 10007, 100003]:
+        n = (count - 1) * stride + k
+        s = rand_seq(n)
+        assert np.array_equal(ctx.as_2bit_batch(s, k, stride, count), oracle.as_2bit_batch(s, k, stride, count)), (k, stride, count)
+    count = 6000
+    n = (count - 1) * stride + k
+    s = rand_seq(n).copy()
+    pos = stride * 3777 + k - 1
+    s[pos] = ord("N")
+    s[min(n - 1, pos + 2 * stride)] = ord("X")
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.as_2bit_batch(s, k, stride, count)
+    with pytest.raises(oracle.OracleError) as oe:
+        oracle.as_2bit_batch(s, k, stride, count)
+    assert (ei.value.byte, ei.value.index) == (oe.value.byte, oe.value.index) == (ord("N"), pos)
+    prev = ctx.set_variant("batch_slide", 0)  # general kernel == sliding kernel
+    try:
+        t = rand_seq((20000 - 1) * stride + k)
+        ref = ctx.as_2bit_batch(t, k, stride, 20000)
+    finally:
+        ctx.set_variant("batch_slide", prev)
+    assert np.array_equal(ctx.as_2bit_batch(t, k, stride, 20000), ref)
+
+
 def test_kmer_windows_stride1_first_invalid_byte(ctx, oracle):
     import bitnuc_amd as bn
     k, n = 31, 50000
