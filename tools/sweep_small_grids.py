@@ -29,11 +29,12 @@ torch.cuda.synchronize()
 ops = (("hdist_query", 9 * nw, lambda i: ctx.hdist_query_dev(0x1B1B1B1B1B1B1B1B, w[i & 1], nw, 32, d)),
        ("hdist_pairs", 17 * nw, lambda i: ctx.hdist_pairs_dev(w[i & 1], w[2 + (i & 1)], nw, 32, d)),
        ("split_packed", 8 * (nw + nl + nr), lambda i: ctx.split_packed_dev(w[i & 1], nw, n, idx, sl, sr, canonical=True)))
-mults = (0, 2, 4, 8, 16, 32)
+KEY = sys.argv[1] if len(sys.argv) > 1 else "grid_mult"
+mults = tuple(int(x) for x in sys.argv[2:]) or (0, 2, 4, 8, 16, 32)
 rows = {}
 for rnd in range(7):
     for mult in mults:
-        ctx.set_variant("grid_mult", mult)
+        ctx.set_variant(KEY, mult)
         for name, _, fn in ops:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
             ev[0].record(stream)
@@ -46,4 +47,4 @@ ctx.sync()
 for name, nbytes, _ in ops:
     for mult in mults:
         ms = statistics.median(rows[(name, mult)])
-        print(f"{name:13s} grid_mult {mult:2d}: {ms * 1e3:7.1f} us  {nbytes / ms / 1e6:6.0f} GB/s", flush=True)
+        print(f"{name:13s} {KEY} {mult:2d}: {ms * 1e3:7.1f} us  {nbytes / ms / 1e6:6.0f} GB/s", flush=True)
