@@ -728,6 +728,43 @@ decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_
 // byte-wise, through the wave's stage buffer and store_stage_chunk.
 constexpr int kStripDwords = kBatchTile * 2 + 8; // 64 words x 64 bits + the <= 15-byte lead + slack
 
+// the three steps of a bit-strip tile, shared by decode_fixed_strip_kernel and decode_batch_kernel (wave-private)
+__device__ __forceinline__ void strip_zero(uint32_t *strip, unsigned lane) {
+#pragma unroll
+    for (int j = 0; j < (kStripDwords + 63) / 64; ++j)
+        if (lane + 64 * j < (unsigned)kStripDwords) strip[lane + 64 * j] = 0u;
+}
+// OR the low 2*nb bits of `word` into the strip at bit offset `bit` (even, < 32 * (kStripDwords - 2))
+__device__ __forceinline__ void strip_or_word(uint32_t *strip, unsigned bit, unsigned long long word, unsigned nb) {
+    const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
+    const unsigned long long v = word & keep;
+    const unsigned sh = bit & 31;
+    const unsigned long long t = v << sh; // bits 0..63 of the 96-bit shifted value; the rest is the third dword
+    uint32_t *dst = strip + (bit >> 5);
+    atomicOr(dst, (uint32_t)t);
+    atomicOr(dst + 1, (uint32_t)(t >> 32));
+    atomicOr(dst + 2, sh ? (uint32_t)(v >> 32) >> (32 - sh) : 0u);
+}
+// strip dword c is the 16-byte chunk at lo16 + 16c: decode and store it; the run's first / last chunk (shared with
+// the neighbouring tiles) only as far as [lo, hi) reaches, through a 16-byte LDS slot and store_stage_chunk
+__device__ __forceinline__ void strip_drain(const uint32_t *strip, uint8_t (*edge)[16], uintptr_t lo16, uintptr_t lo, uintptr_t hi, unsigned lane) {
+    const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4); // <= 130
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const unsigned c = lane + 64 * j;
+        if (c >= nchunk) break;
+        const u32x4 d = dec16(strip[c]);
+        const uintptr_t g = lo16 + 16 * (uintptr_t)c;
+        if (g >= lo && g + 16 <= hi) {
+            __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
+        } else {
+            uint8_t *e = edge[c ? 1 : 0];
+            *reinterpret_cast<u32x4 *>(e) = d;
+            store_stage_chunk(e, g, lo, hi);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned wpr, unsigned magic,
                           unsigned long long total_words, uint8_t *__restrict__ out) {
@@ -749,37 +786,11 @@ decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned
         const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + span_lo, hi = reinterpret_cast<uintptr_t>(out) + span_hi;
         const uintptr_t lo16 = lo & ~(uintptr_t)15;
         wave_lds_fence(); // previous trip's readers are done
-#pragma unroll
-        for (int j = 0; j < (kStripDwords + 63) / 64; ++j)
-            if (lane + 64 * j < (unsigned)kStripDwords) strip[lane + 64 * j] = 0u;
+        strip_zero(strip, lane);
         wave_lds_fence();
-        if (active) {
-            const unsigned bit = 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16); // < 2 * (15 + 2048)
-            const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
-            const unsigned long long v = word & keep;
-            const unsigned sh = bit & 31;
-            const unsigned long long t = v << sh; // bits 0..63 of the 96-bit shifted value; the rest is the third dword
-            uint32_t *dst = strip + (bit >> 5);
-            atomicOr(dst, (uint32_t)t);
-            atomicOr(dst + 1, (uint32_t)(t >> 32));
-            atomicOr(dst + 2, sh ? (uint32_t)(v >> 32) >> (32 - sh) : 0u);
-        }
+        if (active) strip_or_word(strip, 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16), word, nb);
         wave_lds_fence();
-        const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4); // <= 130
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const unsigned c = lane + 64 * j;
-            if (c >= nchunk) break;
-            const u32x4 d = dec16(strip[c]);
-            const uintptr_t g = lo16 + 16 * (uintptr_t)c;
-            if (g >= lo && g + 16 <= hi) {
-                __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
-            } else { // the run's first or last chunk: only its own bytes
-                uint8_t *e = edge[wave_in_block()][c ? 1 : 0];
-                *reinterpret_cast<u32x4 *>(e) = d;
-                store_stage_chunk(e, g, lo, hi);
-            }
-        }
+        strip_drain(strip, edge[wave_in_block()], lo16, lo, hi, lane);
     }
 }
 
@@ -824,9 +835,7 @@ decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned
         const unsigned long long wo_r = word_offsets[si], so_r = offsets[si];
         const unsigned hi0 = first_entry_past(wo_r, wb + kBatchTile - 1);
         wave_lds_fence(); // previous trip's readers are done
-#pragma unroll
-        for (int j = 0; j < (kStripDwords + 63) / 64; ++j)
-            if (lane + 64 * j < (unsigned)kStripDwords) strip[lane + 64 * j] = 0u;
+        strip_zero(strip, lane);
         unsigned long long base; // absolute byte offset of the lane's word
         unsigned nb;
         const unsigned long long wq = wb + (lane < last ? lane : last); // inactive lanes mirror the last word
@@ -847,33 +856,9 @@ decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned
         const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + rec.base0, hi = reinterpret_cast<uintptr_t>(out) + span_hi;
         const uintptr_t lo16 = lo & ~(uintptr_t)15;
         wave_lds_fence(); // zeroing (and the lookup's LDS traffic) before the ORs
-        if (active) {
-            const unsigned bit = 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16);
-            const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
-            const unsigned long long v = word & keep;
-            const unsigned sh = bit & 31;
-            const unsigned long long tv = v << sh;
-            uint32_t *dst = strip + (bit >> 5);
-            atomicOr(dst, (uint32_t)tv);
-            atomicOr(dst + 1, (uint32_t)(tv >> 32));
-            atomicOr(dst + 2, sh ? (uint32_t)(v >> 32) >> (32 - sh) : 0u);
-        }
+        if (active) strip_or_word(strip, 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16), word, nb);
         wave_lds_fence();
-        const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const unsigned c = lane + 64 * j;
-            if (c >= nchunk) break;
-            const u32x4 d = dec16(strip[c]);
-            const uintptr_t g = lo16 + 16 * (uintptr_t)c;
-            if (g >= lo && g + 16 <= hi) {
-                __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
-            } else {
-                uint8_t *e = edge[wv][c ? 1 : 0];
-                *reinterpret_cast<u32x4 *>(e) = d;
-                store_stage_chunk(e, g, lo, hi);
-            }
-        }
+        strip_drain(strip, edge[wv], lo16, lo, hi, lane);
     }
 }
 
