@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--dec-variant", type=int, default=-1)
     ap.add_argument("--grid-mult", type=int, default=-1)
     ap.add_argument("--cpu-sample", type=int, default=10**9, help="bases timed on the CPU (default: the whole configs[1] workload)")
-    ap.add_argument("--cpu-reps", type=int, default=7)
+    ap.add_argument("--cpu-reps", type=int, default=15, help="repetitions of the 10^9-base CPU round trip (median reported): about 12 s of single-core work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (k-mer batch) and config-5 (scan) side measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse the N>1 control flow")
