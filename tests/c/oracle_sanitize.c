@@ -53,6 +53,19 @@ int main(void) {
     CHECK(orc_hdist_scalar(0, 0, 33, &d, &e) == ORC_INVALID_LENGTH);
     uint8_t *g = malloc(1000);
     orc_nucgen(g, 1000, 7, 12345, 0);
+    /* split_packed with exact-size buffers: n_words + 1 words each (oracle contract), every split point */
+    {
+        uint64_t w[32], *l = malloc(33 * 8), *r = malloc(33 * 8);
+        size_t nw = 0, nl, nr;
+        CHECK(orc_encode(g, 1000, w, &nw, &e) == ORC_OK && nw == 32);
+        for (size_t idx = 0; idx <= 1000; idx++) {
+            CHECK(orc_split_packed(w, nw, 1000, idx, l, &nl, r, &nr, &e) == ORC_OK);
+            CHECK(nl <= 33 && nr <= 33);
+        }
+        CHECK(orc_split_packed(w, nw, 1000, 1001, l, &nl, r, &nr, &e) == ORC_INDEX_OUT_OF_BOUNDS);
+        CHECK(orc_split_packed(w, 2, 1000, 500, l, &nl, r, &nr, &e) == ORC_PANIC);
+        free(l); free(r);
+    }
     free(g);
     printf("sanitizer harness ok\n");
     return 0;
