@@ -99,10 +99,11 @@ struct WordLoc {
 // bytes straight after reading its 16-byte record.
 struct TileRec { unsigned long long owner, base0, avail; }; // avail = bases left in the owner sequence from base0
 
+template <int EST>
 __global__ void __launch_bounds__(kBlock)
 block_owner_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets,
                    unsigned long long count, unsigned long long total_words, unsigned long long ntiles,
-                   TileRec *__restrict__ recs) {
+                   unsigned long long ratio64 /* floor(2^64 * count / total_words), EST == 2 */, TileRec *__restrict__ recs) {
     const unsigned long long b = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     if (b >= ntiles) return;
     const unsigned long long wb = b * kBatchTile;
@@ -111,7 +112,15 @@ block_owner_kernel(const unsigned long long *__restrict__ offsets, const unsigne
     // dependent loads instead of log2(count).
     unsigned long long lo, hi; // invariant: word_offsets[lo] <= wb < word_offsets[hi]
     {
-        const unsigned long long est = (unsigned long long)(((unsigned __int128)wb * count) / total_words);
+        unsigned long long est;
+        if constexpr (EST == 0) est = (unsigned long long)(((unsigned __int128)wb * count) / total_words);
+        else if constexpr (EST == 1) est = (unsigned long long)((double)wb * ((double)count / (double)total_words));
+        else { // floor(wb * count / total_words) exactly, without a 128-bit division: the 0.64 fixed-point product is the
+               // floor or one below it, and the remainder (exact in wrapping 64-bit arithmetic: it is < 2 * total_words) tells which
+            est = (unsigned long long)(((unsigned __int128)wb * ratio64) >> 64);
+            const unsigned long long rem = wb * count - est * total_words;
+            if (rem >= total_words) ++est;
+        }
         unsigned long long p = est < count ? est : count - 1, step = 1;
         if (word_offsets[p] <= wb) {
             lo = p;
