@@ -53,7 +53,7 @@ struct bitnuc_ctx {
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
     int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
     int fixed_dec_strip = 1;               // decode_fixed (back-to-back reads): 1 = rebuild the tile's 2-bit stream in LDS, decode aligned chunks
-    int owner_est = -1;                    // block_owner_kernel's first guess: 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, -1 = by average sequence length
+    int owner_est = 3;                     // block_owner_kernel's first guess: 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, 3 = 2 or 0 by average sequence length
     int batch_stream = 0;                  // encode_batch: 1 = cut the tile's 2-bit stream, 0 = funnel raw bytes per word
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
@@ -517,7 +517,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
     else if (!strcmp(key, "fixed_stream")) { prev = c->fixed_stream; if (value == 0 || value == 1) c->fixed_stream = value; }
     else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value == 0 || value == 1) c->fixed_dec_strip = value; }
-    else if (!strcmp(key, "owner_est")) { prev = c->owner_est; if (value >= -1 && value <= 2) c->owner_est = value; }
+    else if (!strcmp(key, "owner_est")) { prev = c->owner_est; if (value >= 0 && value <= 3) c->owner_est = value; }
     else if (!strcmp(key, "batch_stream")) { prev = c->batch_stream; if (value == 0 || value == 1) c->batch_stream = value; }
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
@@ -811,7 +811,7 @@ static int batch_owners(bitnuc_ctx *c, const uint64_t *d_offsets, const uint64_t
     const unsigned long long ratio64 = count >= total_words ? ~0ull : (unsigned long long)((((unsigned __int128)count) << 64) / total_words);
     // measured (profiles/r01_ab_owner_estimate.txt): the multiply-high guess wins by 9 us of 17 for long sequences, the
     // 128-bit division by 6 of 28 for read-sized ones (same loads either way; the slower arithmetic spreads them out)
-    const int est_mode = c->owner_est >= 0 ? c->owner_est : (total_words >= 16 * (unsigned long long)count ? 2 : 0);
+    const int est_mode = c->owner_est < 3 ? c->owner_est : (total_words >= 16 * (unsigned long long)count ? 2 : 0);
     if (est_mode == 0) block_owner_kernel<0><<<og, kBlock, 0, c->stream>>>(po, pw, count, total_words, ntiles, ratio64, o);
     else if (est_mode == 1) block_owner_kernel<1><<<og, kBlock, 0, c->stream>>>(po, pw, count, total_words, ntiles, ratio64, o);
     else block_owner_kernel<2><<<og, kBlock, 0, c->stream>>>(po, pw, count, total_words, ntiles, ratio64, o);
