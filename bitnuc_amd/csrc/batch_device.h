@@ -80,8 +80,10 @@ __device__ __forceinline__ unsigned long long read_lane_u64(unsigned long long x
 // (t = j0 + lane < wpr + 64): multiply-high by the host's magic = ceil(2^32 / wpr) when
 // wpr <= 64, a single compare when wpr > 64.
 struct ReadPos { unsigned long long r; unsigned j; };
-__device__ __forceinline__ ReadPos fixed_read_pos(unsigned long long wb, unsigned lane, unsigned wpr, unsigned magic) {
-    const unsigned long long r0 = wb / wpr; // wave-uniform
+__device__ __forceinline__ ReadPos fixed_read_pos(unsigned long long wb, unsigned lane, unsigned wpr, unsigned magic, unsigned long long magic64) {
+    // wave-uniform floor(wb / wpr) as a multiply-high by the host's floor(2^64 / wpr) + 1 (exact while wb * wpr < 2^64;
+    // the host passes 0 for wpr == 1, where that constant would be 2^64)
+    const unsigned long long r0 = magic64 ? (unsigned long long)(((unsigned __int128)wb * magic64) >> 64) : wb;
     const unsigned j0 = (unsigned)(wb - r0 * wpr);
     const unsigned t = j0 + lane;
     const unsigned q = wpr > 64 ? (t >= wpr ? 1u : 0u) : (wpr == 1 ? t : __umulhi(t, magic)); // wpr == 1: magic would be 2^32
@@ -585,7 +587,7 @@ encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *_
 // residue of each dword is masked to the bytes that belong to the read.
 template <bool GAPS>
 __global__ void __launch_bounds__(kBlock)
-encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned long long stride, unsigned wpr, unsigned magic,
+encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned long long stride, unsigned wpr, unsigned magic, unsigned long long magic64,
                     unsigned long long total_words, unsigned long long seq_end /* bytes in the buffer */, int use_stream,
                     unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     __shared__ BatchLds lds[kBatchWaves];
@@ -597,7 +599,7 @@ encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned
         const unsigned long long wb = tile * kBatchTile, w = wb + lane;
         const bool active = w < total_words;
         const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
-        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic); // inactive lanes mirror the last word
+        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic, magic64); // inactive lanes mirror the last word
         const unsigned j = pos.j;
         const unsigned long long base = pos.r * stride + 32ull * j;
         const unsigned left = read_len - 32 * j, nb = left < 32 ? left : 32u;
@@ -666,7 +668,7 @@ encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned
 template <bool CONTIG>
 __global__ void __launch_bounds__(kBlock)
 decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned long long stride, unsigned wpr,
-                    unsigned magic, unsigned long long total_words, uint8_t *__restrict__ out) {
+                    unsigned magic, unsigned long long magic64, unsigned long long total_words, uint8_t *__restrict__ out) {
     __shared__ BatchLds lds[kBatchWaves];
     BatchLds &my = lds[wave_in_block()];
     const unsigned lane = threadIdx.x & 63;
@@ -677,7 +679,7 @@ decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_
         const bool active = w < total_words;
         const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
         const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last));
-        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic);
+        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic, magic64);
         const unsigned j = pos.j;
         const unsigned long long base = pos.r * stride + 32ull * j;
         const unsigned left = read_len - 32 * j, nb = left < 32 ? left : 32u;
@@ -775,7 +777,7 @@ __device__ __forceinline__ void strip_drain(const uint32_t *strip, uint8_t (*edg
 }
 
 __global__ void __launch_bounds__(kBlock)
-decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned wpr, unsigned magic,
+decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned wpr, unsigned magic, unsigned long long magic64,
                           unsigned long long total_words, uint8_t *__restrict__ out) {
     __shared__ uint32_t strips[kBatchWaves][kStripDwords];
     __shared__ __attribute__((aligned(16))) uint8_t edge[kBatchWaves][2][16];
@@ -788,7 +790,7 @@ decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned
         const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
         const bool active = lane <= last;
         const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last));
-        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic);
+        const ReadPos pos = fixed_read_pos(wb, lane < last ? lane : last, wpr, magic, magic64);
         const unsigned long long base = pos.r * read_len + 32ull * pos.j; // stride == read_len
         const unsigned left = read_len - 32 * pos.j, nb = left < 32 ? left : 32u;
         const unsigned long long span_lo = read_lane_u64(base, 0), span_hi = read_lane_u64(base + nb, last);

@@ -981,8 +981,9 @@ int bitnuc_encode_fixed_dev(bitnuc_ctx *c, const uint8_t *d_seq, size_t read_len
     unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
     const unsigned long long seq_end = (unsigned long long)(count - 1) * stride + read_len;
     const unsigned magic = (unsigned)((0x100000000ull + wpr - 1) / wpr); // ceil(2^32 / wpr): exact floor(t / wpr) for t < 2^16
-    if (stride == read_len) encode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, total, seq_end, c->fixed_stream, o, slot);
-    else encode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, total, seq_end, 0, o, slot);
+    const unsigned long long magic64 = wpr == 1 ? 0ull : ~0ull / wpr + 1;  // floor(2^64 / wpr) + 1: exact floor(w / wpr) by multiply-high while w * wpr < 2^64
+    if (stride == read_len) encode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, magic64, total, seq_end, c->fixed_stream, o, slot);
+    else encode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, magic64, total, seq_end, 0, o, slot);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
@@ -1000,9 +1001,10 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
     const unsigned grid = grid_for(c, (total + per_block - 1) / per_block);
     const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
     const unsigned magic = (unsigned)((0x100000000ull + wpr - 1) / wpr);
-    if (stride == read_len && c->fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, total, d_out);
-    else if (stride == read_len) decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, total, d_out);
-    else decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, total, d_out);
+    const unsigned long long magic64 = wpr == 1 ? 0ull : ~0ull / wpr + 1;
+    if (stride == read_len && c->fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
+    else if (stride == read_len) decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
+    else decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
