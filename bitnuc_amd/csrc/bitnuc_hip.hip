@@ -358,7 +358,8 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         const unsigned long long rounds = ((count - 1) * stride + k - 1024) / kScanWaveWindows + 1;
         const unsigned grid = grid_for(c, (rounds + kBlock / 64 - 1) / (kBlock / 64));
         const unsigned magic = (unsigned)((0x100000000ull + stride - 1) / stride); // exact floor(t / stride) for t < 2^16
-        kmer_slide_any_kernel<<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, (unsigned)stride, magic, rounds, o, slot);
+        const unsigned long long magic64 = ~0ull / stride + 1; // stride >= 3: no overflow
+        kmer_slide_any_kernel<<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, (unsigned)stride, magic, magic64, rounds, o, slot);
         hipError_t rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
         done = (size_t)((rounds * kScanWaveWindows + stride - 1) / stride); // k-mers that start before the last round's end

@@ -340,7 +340,7 @@ kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long lon
 // stores, 512 contiguous bytes per instruction.
 __global__ void __launch_bounds__(kBlock)
 kmer_slide_any_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned S, unsigned magic /* ceil(2^32 / S) */,
-                      unsigned long long rounds, unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
+                      unsigned long long magic64 /* floor(2^64 / S) + 1 */, unsigned long long rounds, unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     constexpr int kMaxOut = kScanWaveWindows / 3 + 2; // S >= 3
     __shared__ unsigned long long strips[kBlock / 64][kMaxOut + 2];
     const unsigned lane = threadIdx.x & 63;
@@ -351,10 +351,11 @@ kmer_slide_any_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned S, u
     const uint32_t mhi = k <= 16 ? 0u : (k == 32 ? ~0u : (1u << (2 * k - 32)) - 1u);
     for (unsigned long long r = wave; r < rounds; r += nwaves) {
         const unsigned long long wb = r * kScanWaveWindows; // first base of the round (wave-uniform)
-        const unsigned long long q_w = wb / S;
+        // wave-uniform divisions by S as multiply-highs (exact while x * S < 2^64)
+        const unsigned long long q_w = (unsigned long long)(((unsigned __int128)wb * magic64) >> 64);
         const unsigned r_w = (unsigned)(wb - q_w * S);
         const unsigned long long first_out = q_w + (r_w ? 1 : 0);                 // first k-mer that starts in this round
-        const unsigned n_out = (unsigned)((wb + kScanWaveWindows - 1) / S - first_out + 1); // k-mers that start in [wb, wb + 992)
+        const unsigned n_out = (unsigned)((unsigned long long)(((unsigned __int128)(wb + kScanWaveWindows - 1) * magic64) >> 64) - first_out + 1); // k-mers that start in [wb, wb + 992)
         const u32x4 v = load_group<true, true>(seq + wb + 16 * lane);
         uint32_t bad = 0;
         const uint32_t c0 = enc16(v, bad);
