@@ -789,6 +789,30 @@ def test_hbm_scale_round_trip(ctx, oracle):
     torch.cuda.empty_cache()
 
 
+def test_context_churn_releases_device_memory(oracle):
+    """Create / use / destroy many contexts: every device allocation of a context (slots, accumulators, scratch that
+    grew to 64 MiB) is released with it."""
+    import torch
+    import bitnuc_amd as bn
+    s = rand_seq(1 << 22)
+    exp = oracle.encode(s)
+    for _ in range(12):  # the runtime keeps a bounded pool of hardware queues for non-blocking streams (~150 MiB, reached
+        bn.Context(0).close()  # after < 10 streams): fill it first, it is not the contexts' memory
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(40):
+        c = bn.Context(0)
+        assert np.array_equal(c.encode_array(s), exp)
+        assert c.base_counts(exp, s.size) == oracle.base_counts(exp, s.size)
+        big = rand_seq(1 << 26) if i == 0 else None  # grow the staging scratch once per loop head
+        if big is not None:
+            c.encode_array(big)
+        c.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), f"{(free0 - free1) >> 20} MiB not returned"
+
+
 def test_two_contexts_interleaved(oracle):
     import threading
     import bitnuc_amd as bn
