@@ -198,8 +198,87 @@ def main():
     dec_ms = [e[1].elapsed_time(e[2]) for e in events]
     enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
 
+    def make_line(extra, with_cpu=True):
+        total_bases = world * 2 * n  # encoded + decoded, all ranks, per step
+        enc_gbs = n * BYTES_PER_BASE / (enc_avg * 1e-3) / 1e9
+        dec_gbs = n * BYTES_PER_BASE / (dec_avg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/prof_summary.py from a --pmc run
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("encode_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Gbases/s encode+decode on 10^9-base synthetic; % of HBM3E roofline",
+            "value": round(total_bases / sec_per_step / 1e9, 2),
+            "unit": "Gbases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the same measurement, three readings (value is the first): bases through the codec per
+            # second (encoded + decoded), and the per-kernel rates from the HIP events of rank 0
+            "codec_gbases_s": round(total_bases / sec_per_step / 1e9, 2),
+            "roundtrip_gbases_s": round(world * n / sec_per_step / 1e9, 2),
+            "encode_gbases_s": round(world * n / (enc_avg * 1e-3) / 1e9, 1),
+            "decode_gbases_s": round(world * n / (dec_avg * 1e-3) / 1e9, 1),
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident, bit-exact vs CPU oracle",
+                       "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
+                       "seed": hex(SEED), "rotating_buffer_sets": R,
+                       "decode_input": "words encoded in the same step (Infinity-Cache warm)" if args.warm_decode else f"words encoded {R - 1} steps earlier (HBM resident, cache cold)",
+                       "encode_variant": ctx.get("encode"), "decode_variant": ctx.get("decode"), "grid_mult": ctx.get("grid_mult"),
+                       "parallelism": f"shard{world}" if world > 1 else "single"},
+            "roofline": {"kernel": "encode_kernel", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(enc_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(enc_avg, 4),
+                         "gbases_s": round(n / (enc_avg * 1e-3) / 1e9, 1)},
+            "roofline_decode": {"kernel": "decode_kernel", "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(dec_avg, 4),
+                                "gbases_s": round(n / (dec_avg * 1e-3) / 1e9, 1)},
+        }
+        line.update(extra)
+        pr = extra.get("stream_probe_gb_s", {})
+        if "read" in pr:  # BASELINE.md: report % of nominal AND % of the box's measured streaming peak
+            best = max(pr["read"], pr["copy"], pr["fill"])
+            line["roofline"]["measured_stream_peak"] = best
+            line["roofline"]["frac_of_measured"] = round(enc_gbs / best, 4)
+            line["roofline_decode"]["measured_stream_peak"] = best
+            line["roofline_decode"]["frac_of_measured"] = round(dec_gbs / best, 4)
+        if with_cpu and world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(e)[:300]}
+        return line
+
+    emit_lock = threading.Lock()
+    emitted = []
+
+    def emit(extra_now, with_cpu=True):
+        """Print the one JSON line (rank 0), exactly once."""
+        with emit_lock:
+            if emitted:
+                return
+            emitted.append(True)
+            if rank == 0:
+                line = make_line(extra_now, with_cpu)
+                sys.stdout.flush()
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
     extra = {}
+    watchdog = None
     if use_dist and on_gpu_collectives:  # config 4's concatenation, reported beside the step, never inside it
+        # These side measurements are collectives: a rank that fails alone would leave the others waiting.  The headline
+        # must not depend on them, so a watchdog prints it without the side numbers and ends the process if they (or the
+        # process-group teardown after them) stall; it stays armed until main() returns.
+        def bail():
+            emit({"allgather_packed": {"error": "side measurement did not finish in 300 s; headline printed without it"}})
+            os._exit(0)
+        watchdog = threading.Timer(300.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             from bitnuc_amd.dist import allgather_packed
             allgather_packed(words[0])
@@ -378,64 +457,12 @@ def main():
             extra["stream_probe_gb_s"] = probe
         except Exception as e:  # noqa: BLE001
             extra["stream_probe_gb_s"] = {"error": repr(e)[:300]}
-    if rank == 0:
-        total_bases = world * 2 * n  # encoded + decoded, all ranks, per step
-        enc_gbs = n * BYTES_PER_BASE / (enc_avg * 1e-3) / 1e9
-        dec_gbs = n * BYTES_PER_BASE / (dec_avg * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/prof_summary.py from a --pmc run
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("encode_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "Gbases/s encode+decode on 10^9-base synthetic; % of HBM3E roofline",
-            "value": round(total_bases / sec_per_step / 1e9, 2),
-            "unit": "Gbases/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(sec_per_step * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            # the same measurement, three readings (value is the first): bases through the codec per
-            # second (encoded + decoded), and the per-kernel rates from the HIP events of rank 0
-            "codec_gbases_s": round(total_bases / sec_per_step / 1e9, 2),
-            "roundtrip_gbases_s": round(world * n / sec_per_step / 1e9, 2),
-            "encode_gbases_s": round(world * n / (enc_avg * 1e-3) / 1e9, 1),
-            "decode_gbases_s": round(world * n / (dec_avg * 1e-3) / 1e9, 1),
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident, bit-exact vs CPU oracle",
-                       "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
-                       "seed": hex(SEED), "rotating_buffer_sets": R,
-                       "decode_input": "words encoded in the same step (Infinity-Cache warm)" if args.warm_decode else f"words encoded {R - 1} steps earlier (HBM resident, cache cold)",
-                       "encode_variant": ctx.get("encode"), "decode_variant": ctx.get("decode"), "grid_mult": ctx.get("grid_mult"),
-                       "parallelism": f"shard{world}" if world > 1 else "single"},
-            "roofline": {"kernel": "encode_kernel", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(enc_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(enc_avg, 4),
-                         "gbases_s": round(n / (enc_avg * 1e-3) / 1e9, 1)},
-            "roofline_decode": {"kernel": "decode_kernel", "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
-                                "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(dec_avg, 4),
-                                "gbases_s": round(n / (dec_avg * 1e-3) / 1e9, 1)},
-        }
-        line.update(extra)
-        pr = extra.get("stream_probe_gb_s", {})
-        if "read" in pr:  # BASELINE.md: report % of nominal AND % of the box's measured streaming peak
-            best = max(pr["read"], pr["copy"], pr["fill"])
-            line["roofline"]["measured_stream_peak"] = best
-            line["roofline"]["frac_of_measured"] = round(enc_gbs / best, 4)
-            line["roofline_decode"]["measured_stream_peak"] = best
-            line["roofline_decode"]["frac_of_measured"] = round(dec_gbs / best, 4)
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)
-            except Exception as e:  # noqa: BLE001
-                line["cpu_baseline"] = {"error": repr(e)[:300]}
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    emit(extra)
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":
