@@ -122,13 +122,30 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    control_backend = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+        backend = args.backend
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=dev)  # eager: a broken RCCL setup fails here, not at the first barrier
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                # The step has no data-path collective: RCCL only carries the barrier and the max-reduce of the timing.
+                # If it cannot come up, the same control traffic goes over gloo and the measurement stays valid.
+                print(f"[bench] nccl unavailable ({e!r}); using gloo for the barrier / max-reduce", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
-            dist.init_process_group(args.backend)
-    on_gpu_collectives = args.backend == "nccl"
+            dist.init_process_group(backend)
+        control_backend = backend
+    on_gpu_collectives = use_dist and control_backend == "nccl"
 
     n = args.bases
     nw = (n + 31) // 32
@@ -228,7 +245,8 @@ def main():
                        "seed": hex(SEED), "rotating_buffer_sets": R,
                        "decode_input": "words encoded in the same step (Infinity-Cache warm)" if args.warm_decode else f"words encoded {R - 1} steps earlier (HBM resident, cache cold)",
                        "encode_variant": ctx.get("encode"), "decode_variant": ctx.get("decode"), "grid_mult": ctx.get("grid_mult"),
-                       "parallelism": f"shard{world}" if world > 1 else "single"},
+                       "parallelism": f"shard{world}" if world > 1 else "single",
+                       "control_backend": control_backend},
             "roofline": {"kernel": "encode_kernel", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(enc_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(enc_avg, 4),
