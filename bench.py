@@ -119,6 +119,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.share_gpu:
         local_rank = 0
+    # a launcher that narrows each rank's visible devices (HIP_VISIBLE_DEVICES per rank) leaves fewer devices than ranks
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
