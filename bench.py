@@ -13,12 +13,26 @@ concatenating all-gather of config 4 is timed separately, outside the step).
 value = bases pushed through the codec per second, whole job:
         N_gpus * (10^9 encoded + 10^9 decoded) / step time / 1e9   [Gbases/s]
         (x 1.25 algorithmic bytes per base = aggregate algorithmic GB/s).
+
+Process model
+  python bench.py --gpus N            (no launcher)  the parent touches no GPU: it starts
+        `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process,
+        relays rank 0's single JSON line and exits with the child's return code.
+  torchrun ... bench.py --gpus N      (the driver's form) WORLD_SIZE is set: this process is a rank.
+Failure is never silent: a stalled collective prints the line with "stalled": true and exits 3;
+RCCL that cannot come up on EVERY rank (decided collectively over a gloo group) is reported as
+top-level "rccl_ok": false.
 """
 import argparse
+import datetime
+import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -28,8 +42,172 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
 BYTES_PER_BASE = 1.25          # encode: 1 read + 0.25 write; decode: 0.25 read + 1 write
 SEED = 0xB17C0DE
+METRIC = "Gbases/s encode+decode on 10^9-base synthetic; % of HBM3E roofline"
+EXIT_STALLED = 3
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--bases", type=int, default=10**9, help="bases per GPU per step (BASELINE configs[1]: 1e9)")
+    ap.add_argument("--rotate", type=int, default=3, help="buffer sets rotated so the 256 MiB Infinity Cache cannot serve a step (>= 2)")
+    ap.add_argument("--enc-variant", type=int, default=-1)
+    ap.add_argument("--dec-variant", type=int, default=-1)
+    ap.add_argument("--grid-mult", type=int, default=-1)
+    ap.add_argument("--cpu-sample", type=int, default=10**9, help="bases timed on the CPU (default: the whole configs[1] workload)")
+    ap.add_argument("--cpu-reps", type=int, default=15, help="repetitions of the 10^9-base CPU round trip (median reported): about 12 s of single-core work")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (k-mer batch) and config-5 (scan) side measurements")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc pass that measures roofline.traffic (N=1 only)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse the N>1 control flow")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise torch.distributed and run the collectives even at world size 1")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box)")
+    ap.add_argument("--rehearse-cpu", action="store_true", help="rehearsal only (CPU, no GPU touched): exercise launcher, process groups, watchdog and the JSON relay; value is null")
+    ap.add_argument("--dist-timeout", type=float, default=600.0, help="seconds a rank may spend in process-group setup / a collective before it reports a stall")
+    ap.add_argument("--warm-decode", action="store_true", help="decode the words the same step just encoded (a literal round trip: 20 %% of decode's input then comes from the Infinity Cache)")
+    ap.add_argument("--probe", action="store_true", help="also time pure streaming kernels (the box's own HBM rates) when --no-extras is given")
+    ap.add_argument("--traffic-child", choices=["codec"], default=None, help=argparse.SUPPRESS)  # the workload run under rocprofv3 --pmc
+    ap.add_argument("--inject-stall", type=int, default=-1, help=argparse.SUPPRESS)  # test hook: this rank never joins the side collectives
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# parent mode: start the ranks (no GPU call in this process)
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher: spawn N fresh rank processes through
+    torch.distributed.run, relay rank 0's JSON line, return the children's worst return code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:  # rank 0 prints exactly one JSON line; anything else on stdout goes to stderr
+        if out.startswith('{"metric"') and line is None:
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    else:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "Gbases/s", "n_gpus": args.gpus, "error": f"ranks exited with code {rc} before printing a line"}), flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# roofline.traffic: HBM bytes per launch from PMC counters, measured for THIS run's kernels
+# ---------------------------------------------------------------------------------------------
+def csrc_sha16():
+    """Identity of the kernel sources: a stored traffic figure is only valid for the same sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bitnuc_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def measure_traffic_live(n):
+    """Run the codec pair under `rocprofv3 --pmc` in child processes (FETCH_SIZE and WRITE_SIZE in
+    separate passes, counters only: MI355X_MICROARCH.md section HBM) BEFORE this process touches the GPU,
+    and return HBM bytes per launch per kernel: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts half
+    of a wide coalesced read; WRITE_SIZE is exact for 16-B-per-lane stores)."""
+    import csv
+    import glob
+    import shutil
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="bitnuc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sums = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-child", "codec", "--bases", str(n)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr[-300:]}"}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != ctr:
+                    continue
+                k = row["Kernel_Name"]
+                name = "encode_kernel" if "encode_kernel" in k else "decode_kernel" if "decode_kernel" in k else None
+                if name:
+                    sums.setdefault((name, ctr), []).append(float(row["Counter_Value"]))
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), measured by this run before the timed region",
+           "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch (gfx950: FETCH_SIZE counts half of a wide coalesced read)"}
+    for name in ("encode_kernel", "decode_kernel"):
+        f, w = sums.get((name, "FETCH_SIZE")), sums.get((name, "WRITE_SIZE"))
+        if not f or not w:
+            return {"error": f"no PMC rows for {name}"}
+        res[name] = round((2 * sum(f) / len(f) + sum(w) / len(w)) * 1024)
+        res[name + "_launches"] = min(len(f), len(w))
+    return res
+
+
+def stored_traffic():
+    """profiles/hbm_traffic.json from an earlier PMC pass, accepted only for the same kernel sources."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return {"error": "no live PMC pass and no profiles/hbm_traffic.json"}
+    if t.get("csrc_sha16") != csrc_sha16():
+        return {"error": "profiles/hbm_traffic.json was measured on different kernel sources (csrc_sha16 mismatch): refused"}
+    return {"source": f"profiles/hbm_traffic.json (commit {t.get('commit')}, {t.get('date')}): NOT measured in this run",
+            "encode_kernel": round(t["encode_bytes_per_launch"]), "decode_kernel": round(t["decode_bytes_per_launch"])}
+
+
+def traffic_child(args):
+    """The workload profiled by measure_traffic_live: the same two launches as a step, cache-cold rotation."""
+    import torch
+    import bitnuc_amd
+    dev = torch.device("cuda", 0)
+    n, nw = args.bases, (args.bases + 31) // 32
+    stream = torch.cuda.current_stream()
+    ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+    R = 3
+    seqs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
+    words = [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)]
+    backs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
+    for r in range(R):
+        ctx.nucgen_dev(seqs[r], n, SEED + r)
+    for i in range(2 * R):
+        ctx.encode_dev(seqs[i % R], n, words[i % R])
+        ctx.decode_dev(words[(i + 1) % R], nw, n, backs[(i + 1) % R])
+    ctx.sync()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (oracle/bitnuc_avx2.c) -- the checker timed beside the product, never inside it
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(n_sample, reps, all_cores):
     """Reference-algorithm restatement (oracle/bitnuc_avx2.c, the reference's AVX2 path as
     written) timed on this host.  kind = "port": the Rust reference cannot be built here."""
@@ -46,7 +224,8 @@ def cpu_baseline(n_sample, reps, all_cores):
            "sample": f"{n_sample:.3g} bases of the same seeded stream, encode+decode, median of {reps}",
            "encode_gbases_s": round(n_sample / e1 / 1e9, 4), "decode_gbases_s": round(n_sample / d1 / 1e9, 4),
            "what": "C restatement of the reference's AVX2 path as written (oracle/bitnuc_avx2.c); "
-                   "the reference itself is single-threaded Rust and cannot be built in this image"}
+                   "the reference itself is single-threaded Rust and cannot be built in this image",
+           "build_flags": oracle_py.build_flags() if hasattr(oracle_py, "build_flags") else None}
     if all_cores:
         # a one-GPU box's CPU share is 16 cores (os.cpu_count() reports the whole host)
         cores = min(len(os.sched_getaffinity(0)), 16)
@@ -66,206 +245,306 @@ def cpu_baseline(n_sample, reps, all_cores):
     try:
         with open("/proc/cpuinfo") as f:
             out["cpu"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
-    except Exception:
+    except Exception:  # noqa: BLE001
         pass
     return out
 
 
-def main():
-    # stdout carries exactly ONE line (the JSON): libraries that print banners from C (RCCL does
-    # at communicator init) are sent to stderr by pointing fd 1 there and keeping the real stdout aside
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--bases", type=int, default=10**9, help="bases per GPU per step (BASELINE configs[1]: 1e9)")
-    ap.add_argument("--rotate", type=int, default=3, help="buffer sets rotated so the 256 MiB Infinity Cache cannot serve a step (>= 2)")
-    ap.add_argument("--enc-variant", type=int, default=-1)
-    ap.add_argument("--dec-variant", type=int, default=-1)
-    ap.add_argument("--grid-mult", type=int, default=-1)
-    ap.add_argument("--cpu-sample", type=int, default=10**9, help="bases timed on the CPU (default: the whole configs[1] workload)")
-    ap.add_argument("--cpu-reps", type=int, default=15, help="repetitions of the 10^9-base CPU round trip (median reported): about 12 s of single-core work")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (k-mer batch) and config-5 (scan) side measurements")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse the N>1 control flow")
-    ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise torch.distributed and run the collectives even at world size 1")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box)")
-    ap.add_argument("--warm-decode", action="store_true", help="decode the words the same step just encoded (a literal round trip: 20 %% of decode's input then comes from the Infinity Cache)")
-    ap.add_argument("--probe", action="store_true", help="also time pure read/copy/fill kernels (the box's own HBM ceiling)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------
+# rank mode
+# ---------------------------------------------------------------------------------------------
+class Watchdog:
+    """One deadline for everything a rank does together with other ranks.  When it fires the rank
+    prints what it has (rank 0: the JSON line with "stalled": true) and leaves with EXIT_STALLED, so a
+    hung collective is a visible failure, never rc 0."""
 
-    import torch
-    import torch.distributed as dist
-    import bitnuc_amd
-    from bitnuc_amd import build as bn_build
+    def __init__(self, on_fire):
+        self._on_fire = on_fire
+        self._timer = None
+        self.stage = "start"
 
+    def arm(self, seconds, stage):
+        self.disarm()
+        self.stage = stage
+        self._timer = threading.Timer(seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def _fire(self):
+        try:
+            self._on_fire(self.stage)
+        finally:
+            os._exit(EXIT_STALLED)
+
+
+def run_rank(args, real_stdout, traffic):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # a fresh checkout has no libbitnuc_hip.so (git-ignored): local rank 0 compiles it, the others wait for the file
-    if local_rank == 0:
-        bn_build.ensure_built()
-    else:
-        t_wait = time.time()
-        while not os.path.exists(bn_build.LIB):
-            if time.time() - t_wait > 600:
-                raise RuntimeError(f"{bn_build.LIB} did not appear: there is no CPU fallback")
-            time.sleep(1.0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if args.share_gpu:
-        local_rank = 0
-    # a launcher that narrows each rank's visible devices (HIP_VISIBLE_DEVICES per rank) leaves fewer devices than ranks
-    local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    state = {"line_extra": {}, "headline": None}  # headline = dict of measured step numbers once the timed loop is done
+    emit_lock = threading.Lock()
+    emitted = []
+
+    def emit(line):
+        with emit_lock:
+            if emitted:
+                return
+            emitted.append(True)
+            if rank == 0:
+                sys.stdout.flush()
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+    def on_stall(stage):
+        base = {"metric": METRIC, "value": None, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup}
+        if state["headline"] is not None:
+            base = state["headline"](dict(state["line_extra"]), with_cpu=False)
+        base["stalled"] = True
+        base["stalled_stage"] = stage
+        print(f"[bench] rank {rank}: stalled in '{stage}' after {args.dist_timeout:.0f} s; exiting {EXIT_STALLED}", file=sys.stderr)
+        emit(base)
+
+    wd = Watchdog(on_stall)
+
+    import torch
+    import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
+    rehearse = args.rehearse_cpu
+
+    if not rehearse:
+        import bitnuc_amd
+        from bitnuc_amd import build as bn_build
+        # a fresh checkout has no libbitnuc_hip.so (git-ignored): local rank 0 compiles it, the others wait for the file
+        if local_rank == 0:
+            bn_build.ensure_built()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(bn_build.LIB):
+                if time.time() - t_wait > 600:
+                    raise RuntimeError(f"{bn_build.LIB} did not appear: there is no CPU fallback")
+                time.sleep(1.0)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        ndev = torch.cuda.device_count()
+        if args.share_gpu:
+            local_rank = 0
+        elif local_rank >= ndev:
+            # fewer visible devices than ranks is only legitimate when a launcher narrowed each rank to its own device
+            narrowed = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+            if ndev == 1 and narrowed:
+                local_rank = 0
+            else:
+                raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} visible device(s); pass --share-gpu to rehearse on one GPU")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+
+    # ---- process groups: gloo carries the decision, RCCL carries the collectives iff EVERY rank has it ----
+    ctl = None           # group used for barrier / max-reduce / side collectives (None = default gloo group)
     control_backend = None
+    rccl_ok = None       # None = not attempted (single process, or --backend gloo)
+    probe_thread = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = args.backend
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)  # eager: a broken RCCL setup fails here, not at the first barrier
-                probe = torch.zeros(1, device=dev)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001
-                # The step has no data-path collective: RCCL only carries the barrier and the max-reduce of the timing.
-                # If it cannot come up, the same control traffic goes over gloo and the measurement stays valid.
-                print(f"[bench] nccl unavailable ({e!r}); using gloo for the barrier / max-reduce", file=sys.stderr)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")  # a hung probe must not abort the process: the watchdog reports it
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
+        wd.arm(args.dist_timeout, "init_process_group(gloo)")
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+        control_backend = "gloo"
+        if args.backend == "nccl" and not rehearse:
+            wd.arm(args.dist_timeout + 60, "rccl probe")
+            probe = {}
+
+            def try_nccl():
                 try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
-        control_backend = backend
+                    g = dist.new_group(backend="nccl", timeout=tmo)
+                    t = torch.ones(1, device=dev)
+                    dist.all_reduce(t, group=g)
+                    torch.cuda.synchronize()
+                    probe["ok"] = int(t.item()) == world
+                    probe["group"] = g
+                except Exception as e:  # noqa: BLE001
+                    probe["err"] = repr(e)[:300]
+            probe_thread = th = threading.Thread(target=try_nccl, daemon=True)
+            th.start()
+            th.join(min(args.dist_timeout, 180.0))
+            mine = 1 if probe.get("ok") else 0
+            if not mine:
+                print(f"[bench] rank {rank}: RCCL probe failed: {probe.get('err', 'timed out')}", file=sys.stderr)
+            flag = torch.tensor([mine], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # collective decision over gloo: all ranks or none
+            rccl_ok = bool(flag.item())
+            if rccl_ok:
+                ctl = probe["group"]
+                control_backend = "nccl"
+        wd.disarm()
     on_gpu_collectives = use_dist and control_backend == "nccl"
+
+    def barrier():
+        if use_dist:
+            dist.barrier(group=ctl)
+
+    def fence():
+        barrier()
+        if not rehearse:
+            torch.cuda.synchronize()
+
+    # physical identity of every rank's device: two ranks on one GPU would double-count the weak-scaling value
+    identities = None
+    if not rehearse:
+        p = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(p, "uuid", "")) or f"{getattr(p, 'pci_bus_id', '?')}:{getattr(p, 'pci_device_id', '?')}"
+        ident = f"{socket.gethostname()}/{ident}"
+        identities = [ident]
+        if use_dist:
+            wd.arm(args.dist_timeout, "all_gather(device identity)")
+            identities = [None] * world
+            dist.all_gather_object(identities, ident)
+            wd.disarm()
+        if len(set(identities)) != len(identities) and not args.share_gpu:
+            raise SystemExit(f"rank {rank}: ranks share a physical GPU ({identities}); pass --share-gpu to rehearse on one GPU")
 
     n = args.bases
     nw = (n + 31) // 32
-    stream = torch.cuda.current_stream()
-    ctx = bitnuc_amd.Context(local_rank, stream=stream.cuda_stream)
-    if args.enc_variant >= 0:
-        ctx.set_variant("encode", args.enc_variant)
-    if args.dec_variant >= 0:
-        ctx.set_variant("decode", args.dec_variant)
-    if args.grid_mult >= 0:
-        ctx.set_variant("grid_mult", args.grid_mult)
-
     R = max(2, args.rotate)
-    seqs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
-    words = [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)]
-    backs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
-    for r in range(R):  # rank-disjoint slices of one seeded stream, generated in place on the device
-        ctx.nucgen_dev(seqs[r], n, SEED + r, first=rank * n)
-    ctx.sync()
 
-    # Step i encodes buffer set r = i % R and decodes set (r + 1) % R, whose words were written
-    # R - 1 steps earlier: >= 2 x 2.25 GB of traffic ago, so no part of the decode's input can still
-    # sit in the 256 MiB Infinity Cache (decoding the words the same step just wrote would read
-    # 20 % of its bytes from cache and flatter the HBM fraction).
-    for r in range(R):
-        ctx.encode_dev(seqs[r], n, words[r])
-    ctx.sync()
+    if rehearse:
+        # no GPU: the "step" is a sleep; everything around it (barriers, max-reduce, side collective, relay) is real
+        def step(i, ev=None):
+            time.sleep(0.001)
+        ctx = stream = None
+    else:
+        stream = torch.cuda.current_stream()
+        ctx = bitnuc_amd.Context(local_rank, stream=stream.cuda_stream)
+        ctx.set_variant("force_gpu", 1)  # the bench measures kernels only; the small-input host path is reported separately
+        if args.enc_variant >= 0:
+            ctx.set_variant("encode", args.enc_variant)
+        if args.dec_variant >= 0:
+            ctx.set_variant("decode", args.dec_variant)
+        if args.grid_mult >= 0:
+            ctx.set_variant("grid_mult", args.grid_mult)
+        seqs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
+        words = [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)]
+        backs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
+        for r in range(R):  # rank-disjoint slices of one seeded stream, generated in place on the device
+            ctx.nucgen_dev(seqs[r], n, SEED + r, first=rank * n)
+        ctx.sync()
+        # Step i encodes buffer set r = i % R and decodes set (r + 1) % R, whose words were written
+        # R - 1 steps earlier: >= 2 x 2.25 GB of traffic ago, so no part of the decode's input can still
+        # sit in the 256 MiB Infinity Cache (decoding the words the same step just wrote would read
+        # 20 % of its bytes from cache and flatter the HBM fraction).
+        for r in range(R):
+            ctx.encode_dev(seqs[r], n, words[r])
+        ctx.sync()
 
-    def step(i, ev=None):
-        r = i % R
-        d = r if args.warm_decode else (r + 1) % R
-        if ev:
-            ev[0].record(stream)
-        ctx.encode_dev(seqs[r], n, words[r])
-        if ev:
-            ev[1].record(stream)
-        ctx.decode_dev(words[d], nw, n, backs[d])
-        if ev:
-            ev[2].record(stream)
+        def step(i, ev=None):
+            r = i % R
+            d = r if args.warm_decode else (r + 1) % R
+            if ev:
+                ev[0].record(stream)
+            ctx.encode_dev(seqs[r], n, words[r])
+            if ev:
+                ev[1].record(stream)
+            ctx.decode_dev(words[d], nw, n, backs[d])
+            if ev:
+                ev[2].record(stream)
 
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    wd.arm(args.dist_timeout, "timed loop")
     for i in range(args.warmup):
         step(i)
-    ctx.sync()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if ctx:
+        ctx.sync()
+    events = None if rehearse else [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, events[i])
+        step(i, events[i] if events else None)
     fence()
     t1 = time.perf_counter()
-    ctx.sync()  # raises if any launch latched an InvalidBase
-
-    # parity guard inside the bench: the last step's round trip must be the identity
-    r_last = (args.steps - 1) % R if args.warm_decode else ((args.steps - 1) % R + 1) % R
-    assert torch.equal(seqs[r_last], backs[r_last]), "decode(encode(x)) != x"
+    if ctx:
+        ctx.sync()  # raises if any launch latched an InvalidBase
+        # parity guard inside the bench: the last step's round trip must be the identity
+        r_last = (args.steps - 1) % R if args.warm_decode else ((args.steps - 1) % R + 1) % R
+        assert torch.equal(seqs[r_last], backs[r_last]), "decode(encode(x)) != x"
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if on_gpu_collectives else "cpu")
     if use_dist:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX, group=ctl)
+    wd.disarm()
     sec_per_step = float(elapsed.item()) / args.steps
-    enc_ms = [e[0].elapsed_time(e[1]) for e in events]
-    dec_ms = [e[1].elapsed_time(e[2]) for e in events]
-    enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
+    if events:
+        enc_ms = [e[0].elapsed_time(e[1]) for e in events]
+        dec_ms = [e[1].elapsed_time(e[2]) for e in events]
+        enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
+    else:
+        enc_avg = dec_avg = None
+
+    def roof(kernel, alg_bytes, ms, traffic_bytes=None, probe=None):
+        gbs = alg_bytes / (ms * 1e-3) / 1e9
+        r = {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic_bytes,
+             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4)}
+        if traffic_bytes:
+            r["traffic_over_algorithmic"] = round(traffic_bytes / alg_bytes, 4)
+        if probe:  # a pure-streaming kernel of the same access shape (no arithmetic): the box's rate for this pattern, not a bound
+            r["same_shape_stream_probe_gb_s"] = probe
+            r["frac_of_same_shape_probe"] = round(gbs / probe, 4)
+        return r
 
     def make_line(extra, with_cpu=True):
         total_bases = world * 2 * n  # encoded + decoded, all ranks, per step
-        enc_gbs = n * BYTES_PER_BASE / (enc_avg * 1e-3) / 1e9
-        dec_gbs = n * BYTES_PER_BASE / (dec_avg * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/prof_summary.py from a --pmc run
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("encode_bytes_per_launch")
-            except Exception:
-                traffic = None
         line = {
-            "metric": "Gbases/s encode+decode on 10^9-base synthetic; % of HBM3E roofline",
-            "value": round(total_bases / sec_per_step / 1e9, 2),
+            "metric": METRIC,
+            "value": None if rehearse else round(total_bases / sec_per_step / 1e9, 2),
             "unit": "Gbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            # the same measurement, three readings (value is the first): bases through the codec per
-            # second (encoded + decoded), and the per-kernel rates from the HIP events of rank 0
-            "codec_gbases_s": round(total_bases / sec_per_step / 1e9, 2),
-            "roundtrip_gbases_s": round(world * n / sec_per_step / 1e9, 2),
-            "encode_gbases_s": round(world * n / (enc_avg * 1e-3) / 1e9, 1),
-            "decode_gbases_s": round(world * n / (dec_avg * 1e-3) / 1e9, 1),
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident, bit-exact vs CPU oracle",
                        "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
                        "seed": hex(SEED), "rotating_buffer_sets": R,
                        "decode_input": "words encoded in the same step (Infinity-Cache warm)" if args.warm_decode else f"words encoded {R - 1} steps earlier (HBM resident, cache cold)",
-                       "encode_variant": ctx.get("encode"), "decode_variant": ctx.get("decode"), "grid_mult": ctx.get("grid_mult"),
                        "parallelism": f"shard{world}" if world > 1 else "single",
-                       "control_backend": control_backend},
-            "roofline": {"kernel": "encode_kernel", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(enc_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(enc_avg, 4),
-                         "gbases_s": round(n / (enc_avg * 1e-3) / 1e9, 1)},
-            "roofline_decode": {"kernel": "decode_kernel", "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
-                                "algorithmic_bytes_per_launch": n * BYTES_PER_BASE, "avg_launch_ms": round(dec_avg, 4),
-                                "gbases_s": round(n / (dec_avg * 1e-3) / 1e9, 1)},
+                       "control_backend": control_backend, "devices": identities,
+                       "commit": git_head(), "csrc_sha16": csrc_sha16()},
         }
-        line.update(extra)
+        if use_dist:
+            line["rccl_ok"] = rccl_ok
+        if rehearse:
+            line["rehearsal"] = "no GPU touched: launcher / process-group / relay rehearsal only, value is null"
+            line.update(extra)
+            return line
+        line["config"].update({"encode_variant": ctx.get("encode"), "decode_variant": ctx.get("decode"), "grid_mult": ctx.get("grid_mult")})
+        # the same measurement, three readings (value is the first): bases through the codec per
+        # second (encoded + decoded), and the per-kernel rates from the HIP events of rank 0
+        line.update({"codec_gbases_s": round(total_bases / sec_per_step / 1e9, 2),
+                     "roundtrip_gbases_s": round(world * n / sec_per_step / 1e9, 2),
+                     "encode_gbases_s": round(world * n / (enc_avg * 1e-3) / 1e9, 1),
+                     "decode_gbases_s": round(world * n / (dec_avg * 1e-3) / 1e9, 1)})
         pr = extra.get("stream_probe_gb_s", {})
-        if "read" in pr:  # report % of nominal AND % of the box's measured streaming peak
-            best = max(pr["read"], pr["copy"], pr["fill"])
-            line["roofline"]["measured_stream_peak"] = best
-            line["roofline"]["frac_of_measured"] = round(enc_gbs / best, 4)
-            line["roofline_decode"]["measured_stream_peak"] = best
-            line["roofline_decode"]["frac_of_measured"] = round(dec_gbs / best, 4)
+        tr = traffic or {}
+        alg = n * BYTES_PER_BASE
+        r_enc = roof("encode_kernel", alg, enc_avg, tr.get("encode_kernel"), pr.get("encode_shape"))
+        r_dec = roof("decode_kernel", alg, dec_avg, tr.get("decode_kernel"), pr.get("decode_shape"))
+        both = tr.get("encode_kernel") and tr.get("decode_kernel")
+        r_step = roof("encode_kernel + decode_kernel (the whole step)", 2 * alg, enc_avg + dec_avg,
+                      tr["encode_kernel"] + tr["decode_kernel"] if both else None)
+        dominant = r_dec if dec_avg >= enc_avg else r_enc  # the kernel that takes the larger share of the step
+        line["roofline"] = dict(dominant, dominant_because="largest share of the step's kernel time",
+                                traffic_source=tr.get("source") or tr.get("error"))
+        line["roofline_encode"], line["roofline_decode"], line["roofline_step"] = r_enc, r_dec, r_step
+        line.update(extra)
         if with_cpu and world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)
@@ -273,217 +552,321 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)[:300]}
         return line
 
-    emit_lock = threading.Lock()
-    emitted = []
+    state["headline"] = make_line
+    extra = state["line_extra"]
 
-    def emit(extra_now, with_cpu=True):
-        """Print the one JSON line (rank 0), exactly once."""
-        with emit_lock:
-            if emitted:
-                return
-            emitted.append(True)
-            if rank == 0:
-                line = make_line(extra_now, with_cpu)
-                sys.stdout.flush()
-                os.write(real_stdout, (json.dumps(line) + "\n").encode())
-
-    extra = {}
-    watchdog = None
-    if use_dist and on_gpu_collectives:  # config 4's concatenation, reported beside the step, never inside it
-        # These side measurements are collectives: a rank that fails alone would leave the others waiting.  The headline
-        # must not depend on them, so a watchdog prints it without the side numbers and ends the process if they (or the
-        # process-group teardown after them) stall; it stays armed until main() returns.
-        def bail():
-            emit({"allgather_packed": {"error": "side measurement did not finish in 300 s; headline printed without it"}})
-            os._exit(0)
-        watchdog = threading.Timer(300.0, bail)
-        watchdog.daemon = True
-        watchdog.start()
+    if use_dist and (on_gpu_collectives or rehearse or args.backend == "gloo"):
+        # config 4's concatenation, reported beside the step, never inside it.  These are collectives: a rank that
+        # fails alone leaves the others waiting, and the watchdog then prints the headline with "stalled": true and
+        # exits non-zero.
+        wd.arm(args.dist_timeout if args.inject_stall < 0 else min(args.dist_timeout, 20.0), "allgather_packed (config 4 side measurement)")
         try:
-            from bitnuc_amd.dist import allgather_packed
-            allgather_packed(words[0])
+            if args.inject_stall == rank:
+                time.sleep(10**6)
+            from bitnuc_amd.dist import allgather_packed, encode_allgather_overlapped
+            if rehearse:
+                local = torch.arange(1024, dtype=torch.int64) + rank
+            elif on_gpu_collectives:
+                local = words[0]
+            else:  # gloo rehearsal on a GPU box: a small CPU copy, the point is the control flow
+                local = words[0][:1 << 20].cpu()
+            lw = local.numel()
+            allgather_packed(local, group=ctl)
             fence()
             t = time.perf_counter()
             reps = 5
             for _ in range(reps):
-                full = allgather_packed(words[0])
+                full = allgather_packed(local, group=ctl)
             fence()
             ag = (time.perf_counter() - t) / reps
+            ok = bool(torch.equal(full[rank * lw:(rank + 1) * lw], local))
             del full
-            extra["allgather_packed"] = {"ms": round(ag * 1e3, 3), "bytes_received_per_gpu": nw * 8 * (world - 1),
-                                         "gb_s_per_gpu": round(nw * 8 * (world - 1) / ag / 1e9, 2),
-                                         "note": "RCCL all-gather of the packed u64 buffer over xGMI; fabric-bound, outside the timed step"}
-            # SURVEY 8e (iii): encode + concatenation end to end, one shot vs chunked overlap (8 pieces: the
-            # fabric moves piece c while the GPU encodes piece c+1)
-            from bitnuc_amd.dist import encode_allgather_overlapped
+            extra["allgather_packed"] = {"ms": round(ag * 1e3, 3), "bytes_received_per_gpu": lw * 8 * (world - 1),
+                                         "gb_s_per_gpu": round(lw * 8 * (world - 1) / ag / 1e9, 2), "own_slot_ok": ok, "backend": control_backend,
+                                         "note": "all-gather of the packed u64 buffer (RCCL over xGMI when backend is nccl); fabric-bound, outside the timed step"}
+            if on_gpu_collectives:
+                # encode + concatenation end to end, one shot vs chunked overlap (8 pieces: the
+                # fabric moves piece c while the GPU encodes piece c+1)
+                def enc_chunk(w0, w1):
+                    ctx.encode_dev(seqs[0][32 * w0:], min(n, 32 * w1) - 32 * w0, words[0][w0:])
+                    return words[0][w0:w1]
 
-            def enc_chunk(w0, w1):
-                ctx.encode_dev(seqs[0][32 * w0:], min(n, 32 * w1) - 32 * w0, words[0][w0:])
-                return words[0][w0:w1]
+                def one_shot():
+                    ctx.encode_dev(seqs[0], n, words[0])
+                    return allgather_packed(words[0], group=ctl)
+                e2e = {}
+                for name, fn in (("one_shot", one_shot), ("overlap8", lambda: encode_allgather_overlapped(enc_chunk, nw, 8, words[0], group=ctl))):
+                    ref_full = fn()
+                    fence()
+                    t = time.perf_counter()
+                    for _ in range(reps):
+                        full = fn()
+                    fence()
+                    e2e[name + "_ms"] = round((time.perf_counter() - t) / reps * 1e3, 3)
+                    e2e[name + "_ok"] = bool(torch.equal(full, ref_full))
+                    del full, ref_full
+                e2e["note"] = "encode of this rank's 10^9-base shard + all-gather of the packed words; fabric-bound, so it cannot scale like the step"
+                extra["encode_allgather_end_to_end"] = e2e
+            else:
+                extra["encode_allgather_end_to_end"] = {"skipped": "needs RCCL (backend nccl on every rank)"}
+        except Exception as e:  # noqa: BLE001 -- a failed collective is reported AND fails the run (rc 4): never a silent success
+            extra.setdefault("allgather_packed", {})["error"] = repr(e)[:300]
+            extra["collective_error"] = True
+            state["rc"] = 4
+        wd.disarm()
 
-            def one_shot():
-                ctx.encode_dev(seqs[0], n, words[0])
-                return allgather_packed(words[0])
-            e2e = {}
-            for name, fn in (("one_shot", one_shot), ("overlap8", lambda: encode_allgather_overlapped(enc_chunk, nw, 8, words[0]))):
-                ref_full = fn()
-                fence()
-                t = time.perf_counter()
-                for _ in range(reps):
-                    full = fn()
-                fence()
-                e2e[name + "_ms"] = round((time.perf_counter() - t) / reps * 1e3, 3)
-                e2e[name + "_ok"] = bool(torch.equal(full, ref_full))
-                del full, ref_full
-            e2e["note"] = "encode of this rank's 10^9-base shard + all-gather of the packed words; fabric-bound, so it cannot scale like the step"
-            extra["encode_allgather_end_to_end"] = e2e
-        except Exception as e:  # noqa: BLE001 -- a side measurement must never cost the headline line
-            extra["allgather_packed"] = {"error": repr(e)[:300]}
-    if world == 1 and not args.no_extras:
+    if not rehearse and world == 1 and not args.no_extras:
         try:
-            # BASELINE configs[2] and [4], measured beside the headline (never inside the timed step)
-            del backs[1:], seqs[1:], words[1:]
-            torch.cuda.empty_cache()
-
-            def timed(fn, reps=10):
-                ms = []
-                for _ in range(reps + 2):
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record(stream)
-                    fn()
-                    b.record(stream)
-                    torch.cuda.synchronize()
-                    ms.append(a.elapsed_time(b))
-                return statistics.median(ms[2:])
-            count, k = 10**8, 31
-            kseq = torch.empty(count * k, dtype=torch.uint8, device=dev)
-            ctx.nucgen_dev(kseq, count * k, SEED + 100)
-            kout = torch.empty(count, dtype=torch.int64, device=dev)
-            ms = timed(lambda: ctx.as_2bit_batch_dev(kseq, k, k, count, kout))
-            gbs = count * (k + 8) / (ms * 1e-3) / 1e9
-            extra["kmer_batch"] = {"workload": "BASELINE configs[2]: 10^8 dense 31-mers as_2bit -> u64", "gkmers_s": round(count / (ms * 1e-3) / 1e9, 2),
-                                   "ms": round(ms, 4), "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                                    "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": count * (k + 8)}}
-            del kseq, kout
-            # every window of a sequence (`seq.windows(k)` + as_2bit, src/lib.rs:170-173): stride 1, 1 B read + 8 B written per window
-            nwin = n - k + 1
-            wout = torch.empty(nwin, dtype=torch.int64, device=dev)
-            ms = timed(lambda: ctx.as_2bit_batch_dev(seqs[0], k, 1, nwin, wout), reps=6)
-            gbs = 9 * nwin / (ms * 1e-3) / 1e9
-            extra["kmer_windows"] = {"workload": "as_2bit of every 31-base window of 10^9 bases (stride 1) -> u64 per window", "ms": round(ms, 4),
-                                     "gwindows_s": round(nwin / (ms * 1e-3) / 1e9, 2),
-                                     "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 9 * nwin}}
-            del wout
-            dist_out = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
-            q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
-            ms = timed(lambda: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, dist_out))
-            gbs = 2 * (n - k + 1) / (ms * 1e-3) / 1e9
-            extra["kmer_hdist_scan"] = {"workload": "BASELINE configs[4]: sliding 31-mer pack + Hamming distance to one query over 10^9 bases",
-                                        "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4),
-                                        "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 2 * (n - k + 1)}}
-            # bulk packed-vs-packed Hamming distance (hdist, hamming/multi.rs:121-160): 16 B per 32-base word pair
-            wa, wb = words[0], torch.empty(nw, dtype=torch.int64, device=dev)
-            ctx.nucgen_dev(backs[0], n, SEED + 200)
-            ctx.encode_dev(backs[0], n, wb)
-            res = torch.zeros(1, dtype=torch.int32, device=dev)
-            ms = timed(lambda: ctx.hdist_dev(wa, nw, wb, nw, n, res))
-            gbs = 16 * nw / (ms * 1e-3) / 1e9
-            extra["hdist_bulk"] = {"workload": "hdist of two 10^9-base packed buffers (SURVEY 8f rank 1)", "ms": round(ms, 4),
-                                   "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "distance": int(res.item()) & 0xFFFFFFFF,
-                                   "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 16 * nw}}
-            # SURVEY 8f ranks 1-2: analysis directly on packed words
-            cnt = torch.zeros(4, dtype=torch.int64, device=dev)
-            # these two read only 250 MB per launch, which would fit the 256 MiB Infinity Cache:
-            # alternate between two packed buffers so that every launch streams from HBM
-            flip = [0]
-
-            def alt():
-                flip[0] ^= 1
-                return wb if flip[0] else wa
-            ms = timed(lambda: ctx.base_counts_dev(alt(), nw, n, cnt))
-            gbs = 8 * nw / (ms * 1e-3) / 1e9
-            extra["base_counts"] = {"workload": "A/C/G/T counts of 10^9 packed bases (analysis.rs:23-39 without the decode)", "ms": round(ms, 4),
-                                    "gbases_s": round(n / (ms * 1e-3) / 1e9, 1),
-                                    "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 8 * nw}}
-            qd = torch.empty(nw, dtype=torch.uint8, device=dev)
-            ms = timed(lambda: ctx.hdist_query_dev(0x1B1B1B1B1B1B1B1B, alt(), nw, 32, qd))
-            gbs = 9 * nw / (ms * 1e-3) / 1e9
-            extra["hdist_query"] = {"workload": "one packed 32-mer against 3.1e7 packed 32-mers -> u8 distances", "ms": round(ms, 4),
-                                    "gwords_s": round(nw / (ms * 1e-3) / 1e9, 2),
-                                    "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 9 * nw}}
-            del qd
-            # SURVEY 8f rank 4: split_packed at an odd base in the middle (16 B per word: read once, write once)
-            sidx = n // 2 + 5
-            snl, snr = ctx.split_packed_sizes(nw, n, sidx, canonical=True)
-            sl, sr = torch.empty(snl, dtype=torch.int64, device=dev), torch.empty(snr, dtype=torch.int64, device=dev)
-            ms = timed(lambda: ctx.split_packed_dev(alt(), nw, n, sidx, sl, sr, canonical=True))
-            gbs = 8 * (nw + snl + snr) / (ms * 1e-3) / 1e9
-            extra["split_packed"] = {"workload": "split 10^9 packed bases at base n/2+5 (functions/split.rs:15-99, funnel-shift form)", "ms": round(ms, 4),
-                                     "gbases_s": round(n / (ms * 1e-3) / 1e9, 1),
-                                     "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 8 * (nw + snl + snr)}}
-            del sl, sr
-            # ragged batch of independent sequences: 150-base reads (each read pads its own last word)
-            L, rcount = 150, n // 150
-            roff = torch.arange(0, rcount + 1, dtype=torch.int64, device=dev) * L
-            rwo = torch.empty(rcount + 1, dtype=torch.int64, device=dev)
-            torch.cuda.synchronize()
-            rtotal = ctx.batch_word_offsets_dev(roff, rcount, rwo)
-            rwords = torch.empty(rtotal, dtype=torch.int64, device=dev)
-            ms_e = timed(lambda: ctx.encode_batch_dev(seqs[0], roff, rwo, rcount, rtotal, rwords))
-            ms_d = timed(lambda: ctx.decode_batch_dev(rwords, rwo, roff, rcount, rtotal, backs[0]))
-            rb = L * rcount
-            alg = rb + 8 * rtotal  # bases + packed words (offset tables: +16 B per read, not counted)
-            extra["reads_batch"] = {"workload": f"{rcount} independent 150-base reads, encode_batch / decode_batch (each read pads its own last word)",
-                                    "encode_ms": round(ms_e, 4), "decode_ms": round(ms_d, 4),
-                                    "encode_gbases_s": round(rb / (ms_e * 1e-3) / 1e9, 1), "decode_gbases_s": round(rb / (ms_d * 1e-3) / 1e9, 1),
-                                    "encode_gb_s": round(alg / (ms_e * 1e-3) / 1e9, 1), "decode_gb_s": round(alg / (ms_d * 1e-3) / 1e9, 1),
-                                    "algorithmic_bytes_per_launch": alg}
-            ms_fe = timed(lambda: ctx.encode_fixed_dev(seqs[0], L, L, rcount, rwords))
-            ms_fd = timed(lambda: ctx.decode_fixed_dev(rwords, L, L, rcount, backs[0]))
-            extra["reads_fixed"] = {"workload": f"{rcount} fixed-length 150-base reads, encode_fixed / decode_fixed (no offsets tables)",
-                                    "encode_ms": round(ms_fe, 4), "decode_ms": round(ms_fd, 4),
-                                    "encode_gbases_s": round(rb / (ms_fe * 1e-3) / 1e9, 1), "decode_gbases_s": round(rb / (ms_fd * 1e-3) / 1e9, 1),
-                                    "encode_gb_s": round(alg / (ms_fe * 1e-3) / 1e9, 1), "decode_gb_s": round(alg / (ms_fd * 1e-3) / 1e9, 1),
-                                    "encode_frac": round(alg / (ms_fe * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "decode_frac": round(alg / (ms_fd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "algorithmic_bytes_per_launch": alg}
-            del rwords, roff, rwo
-            ctx.sync()
-            backs.append(dist_out)  # reused by the probe below
+            side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, extra)
         except Exception as e:  # noqa: BLE001 -- side measurements must never cost the headline line
             extra["extras_error"] = repr(e)[:300]
-    if args.probe or (world == 1 and not args.no_extras):
-        # the box's own streaming ceiling, same harness: best of a few cache-policy variants per shape
+    if not rehearse and (args.probe or (world == 1 and not args.no_extras)):
         try:
-            def probe_rate(mode, moved):
-                ms = []
-                for i in range(8):
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record(stream)
-                    ctx.stream_probe_dev(mode, seqs[i % len(seqs)], backs[(i + 1) % len(backs)], min(n, backs[(i + 1) % len(backs)].numel()))
-                    b.record(stream)
-                    torch.cuda.synchronize()
-                    ms.append(a.elapsed_time(b))
-                return round(moved / (statistics.median(ms[2:]) * 1e-3) / 1e9, 1)
-            nb = min(n, min(t.numel() for t in backs))
-            probe = {"read": max(probe_rate(m, nb) for m in (0 | 8, 0 | 8 | 32, 0)),
-                     "copy": max(probe_rate(m, 2 * nb) for m in (1 | 8 | 16, 1 | 8, 1 | 16, 1)),
-                     "fill": max(probe_rate(m, nb) for m in (2 | 16, 2))}
-            extra["stream_probe_gb_s"] = probe
+            extra["stream_probe_gb_s"] = stream_probes(ctx, torch, stream, seqs, backs, n)
         except Exception as e:  # noqa: BLE001
             extra["stream_probe_gb_s"] = {"error": repr(e)[:300]}
-    emit(extra)
-    ctx.close()
+    emit(make_line(extra))
+    if ctx:
+        ctx.close()
+    rc = state.get("rc", 0)
     if use_dist:
+        if probe_thread is not None and probe_thread.is_alive():
+            os._exit(rc)  # an RCCL probe that never returned still holds the communicator: do not wait for it again
+        wd.arm(120.0, "destroy_process_group")
         dist.destroy_process_group()
-    if watchdog is not None:
-        watchdog.cancel()
+        wd.disarm()
+    return rc
+
+
+def timed_median(torch, stream, fn, reps=10):
+    ms = []
+    for _ in range(reps + 2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        fn()
+        b.record(stream)
+        torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    return statistics.median(ms[2:])
+
+
+def hbm(alg, ms):
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": alg}
+
+
+def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, extra):
+    """BASELINE configs[2] and [4] and the SURVEY 8f rows, measured beside the headline (never inside the timed step)."""
+    del backs[1:], seqs[1:], words[1:]
+    torch.cuda.empty_cache()
+
+    def timed(fn, reps=10):
+        return timed_median(torch, stream, fn, reps)
+    count, k = 10**8, 31
+    kseq = torch.empty(count * k, dtype=torch.uint8, device=dev)
+    ctx.nucgen_dev(kseq, count * k, SEED + 100)
+    kout = torch.empty(count, dtype=torch.int64, device=dev)
+    ms = timed(lambda: ctx.as_2bit_batch_dev(kseq, k, k, count, kout))
+    extra["kmer_batch"] = {"workload": "BASELINE configs[2]: 10^8 dense 31-mers as_2bit -> u64", "gkmers_s": round(count / (ms * 1e-3) / 1e9, 2),
+                           "ms": round(ms, 4), "roofline": hbm(count * (k + 8), ms)}
+    del kseq, kout
+    # every window of a sequence (`seq.windows(k)` + as_2bit, src/lib.rs:170-173): stride 1, 1 B read + 8 B written per window
+    nwin = n - k + 1
+    wout = torch.empty(nwin, dtype=torch.int64, device=dev)
+    ms = timed(lambda: ctx.as_2bit_batch_dev(seqs[0], k, 1, nwin, wout), reps=6)
+    extra["kmer_windows"] = {"workload": "as_2bit of every 31-base window of 10^9 bases (stride 1) -> u64 per window", "ms": round(ms, 4),
+                             "gwindows_s": round(nwin / (ms * 1e-3) / 1e9, 2), "roofline": hbm(9 * nwin, ms)}
+    del wout
+    dist_out = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
+    q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
+    ms = timed(lambda: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, dist_out))
+    extra["kmer_hdist_scan"] = {"workload": "BASELINE configs[4]: sliding 31-mer pack + Hamming distance to one query over 10^9 bases",
+                                "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "roofline": hbm(2 * (n - k + 1), ms)}
+    if hasattr(ctx, "kmer_hdist_count_dev"):
+        # SURVEY 8d cfg 5's optional fused output: only the COUNT of windows with d <= tau leaves the chip (1 B read per window)
+        cnt1 = torch.zeros(1, dtype=torch.int64, device=dev)
+        tau = 8
+        ms = timed(lambda: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1))
+        extra["kmer_hdist_count"] = {"workload": f"same scan, fused `d <= {tau}` count instead of the distance bytes (1 B read per window)",
+                                     "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "matches": int(cnt1.item()),
+                                     "matches_check": int((dist_out <= tau).sum().item()), "roofline": hbm(n - k + 1, ms)}
+    # bulk packed-vs-packed Hamming distance (hdist, hamming/multi.rs:121-160): 16 B per 32-base word pair
+    wa, wb = words[0], torch.empty(nw, dtype=torch.int64, device=dev)
+    ctx.nucgen_dev(backs[0], n, SEED + 200)
+    ctx.encode_dev(backs[0], n, wb)
+    res = torch.zeros(1, dtype=torch.int32, device=dev)
+    ms = timed(lambda: ctx.hdist_dev(wa, nw, wb, nw, n, res))
+    extra["hdist_bulk"] = {"workload": "hdist of two 10^9-base packed buffers (SURVEY 8f rank 1)", "ms": round(ms, 4),
+                           "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "distance": int(res.item()) & 0xFFFFFFFF, "roofline": hbm(16 * nw, ms)}
+    # SURVEY 8f ranks 1-2: analysis directly on packed words
+    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    # these two read only 250 MB per launch, which would fit the 256 MiB Infinity Cache:
+    # alternate between two packed buffers so that every launch streams from HBM
+    flip = [0]
+
+    def alt():
+        flip[0] ^= 1
+        return wb if flip[0] else wa
+    ms = timed(lambda: ctx.base_counts_dev(alt(), nw, n, cnt))
+    extra["base_counts"] = {"workload": "A/C/G/T counts of 10^9 packed bases (analysis.rs:23-39 without the decode)", "ms": round(ms, 4),
+                            "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "roofline": hbm(8 * nw, ms)}
+    qd = torch.empty(nw, dtype=torch.uint8, device=dev)
+    ms = timed(lambda: ctx.hdist_query_dev(0x1B1B1B1B1B1B1B1B, alt(), nw, 32, qd))
+    extra["hdist_query"] = {"workload": "one packed 32-mer against 3.1e7 packed 32-mers -> u8 distances", "ms": round(ms, 4),
+                            "gwords_s": round(nw / (ms * 1e-3) / 1e9, 2), "roofline": hbm(9 * nw, ms)}
+    del qd
+    # SURVEY 8f rank 4: split_packed at an odd base in the middle (16 B per word: read once, write once)
+    sidx = n // 2 + 5
+    snl, snr = ctx.split_packed_sizes(nw, n, sidx, canonical=True)
+    sl, sr = torch.empty(snl, dtype=torch.int64, device=dev), torch.empty(snr, dtype=torch.int64, device=dev)
+    ms = timed(lambda: ctx.split_packed_dev(alt(), nw, n, sidx, sl, sr, canonical=True))
+    extra["split_packed"] = {"workload": "split 10^9 packed bases at base n/2+5 (functions/split.rs:15-99, funnel-shift form)", "ms": round(ms, 4),
+                             "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "roofline": hbm(8 * (nw + snl + snr), ms)}
+    del sl, sr
+    # ragged batch of independent sequences: 150-base reads (each read pads its own last word)
+    L, rcount = 150, n // 150
+    roff = torch.arange(0, rcount + 1, dtype=torch.int64, device=dev) * L
+    rwo = torch.empty(rcount + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    rtotal = ctx.batch_word_offsets_dev(roff, rcount, rwo)
+    rwords = torch.empty(rtotal, dtype=torch.int64, device=dev)
+    ms_e = timed(lambda: ctx.encode_batch_dev(seqs[0], roff, rwo, rcount, rtotal, rwords))
+    ms_d = timed(lambda: ctx.decode_batch_dev(rwords, rwo, roff, rcount, rtotal, backs[0]))
+    rb = L * rcount
+    alg = rb + 8 * rtotal  # bases + packed words (offset tables: +16 B per read, not counted)
+    extra["reads_batch"] = {"workload": f"{rcount} independent 150-base reads, encode_batch / decode_batch from the two offset tables alone (each read pads its own last word)",
+                            "encode_ms": round(ms_e, 4), "decode_ms": round(ms_d, 4),
+                            "encode_gbases_s": round(rb / (ms_e * 1e-3) / 1e9, 1), "decode_gbases_s": round(rb / (ms_d * 1e-3) / 1e9, 1),
+                            "encode_gb_s": round(alg / (ms_e * 1e-3) / 1e9, 1), "decode_gb_s": round(alg / (ms_d * 1e-3) / 1e9, 1),
+                            "encode_frac": round(alg / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "decode_frac": round(alg / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes_per_launch": alg, "roundtrip_ok": bool(torch.equal(seqs[0][:rb], backs[0][:rb]))}
+    ms_fe = timed(lambda: ctx.encode_fixed_dev(seqs[0], L, L, rcount, rwords))
+    ms_fd = timed(lambda: ctx.decode_fixed_dev(rwords, L, L, rcount, backs[0]))
+    extra["reads_fixed"] = {"workload": f"{rcount} fixed-length 150-base reads, encode_fixed / decode_fixed (no offsets tables)",
+                            "encode_ms": round(ms_fe, 4), "decode_ms": round(ms_fd, 4),
+                            "encode_gbases_s": round(rb / (ms_fe * 1e-3) / 1e9, 1), "decode_gbases_s": round(rb / (ms_fd * 1e-3) / 1e9, 1),
+                            "encode_gb_s": round(alg / (ms_fe * 1e-3) / 1e9, 1), "decode_gb_s": round(alg / (ms_fd * 1e-3) / 1e9, 1),
+                            "encode_frac": round(alg / (ms_fe * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "decode_frac": round(alg / (ms_fd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes_per_launch": alg}
+    del rwords, roff, rwo
+    ctx.sync()
+    backs.append(dist_out)  # reused by the probes
+    # host-pointer entry points: PCIe-inclusive rates (never `value`) and the latency of the reference's own bench shapes
+    try:
+        extra["host_path"] = host_path_block(ctx, torch)
+    except Exception as e:  # noqa: BLE001
+        extra["host_path"] = {"error": repr(e)[:300]}
+    try:
+        extra["small_call_latency"] = small_call_latency()
+    except Exception as e:  # noqa: BLE001
+        extra["small_call_latency"] = {"error": repr(e)[:300]}
+
+
+def stream_probes(ctx, torch, stream, seqs, backs, n):
+    """The box's own streaming rates in the same harness: pure read / copy / fill, and two kernels with
+    exactly the codec's access shapes and no arithmetic (encode: 16 B nt-loads + 4 B stores per lane, 2 in flight,
+    128-thread workgroups; decode: 4 B loads + 16 B nt-stores, 256-thread workgroups).  Rates, not bounds."""
+    def rate(mode, moved):
+        ms = []
+        for i in range(8):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            ctx.stream_probe_dev(mode, seqs[i % len(seqs)], backs[(i + 1) % len(backs)], min(n, backs[(i + 1) % len(backs)].numel()))
+            b.record(stream)
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b))
+        return round(moved / (statistics.median(ms[2:]) * 1e-3) / 1e9, 1)
+    nb = min(n, min(t.numel() for t in backs))
+    return {"read": max(rate(m, nb) for m in (0 | 8, 0 | 8 | 32, 0)),
+            "copy": max(rate(m, 2 * nb) for m in (1 | 8 | 16, 1 | 8, 1 | 16, 1)),
+            "fill": max(rate(m, nb) for m in (2 | 16, 2)),
+            "encode_shape": rate(3, 1.25 * nb), "decode_shape": rate(4, 1.25 * nb),
+            "note": "best of a few cache-policy variants per shape; *_shape = the codec kernels' exact access pattern without arithmetic"}
+
+
+def host_path_block(ctx, torch):
+    """Host-pointer bulk entry points on 10^9 bases of pageable host memory (PCIe inclusive), next to the box's
+    pinned hipMemcpyAsync rate."""
+    import numpy as np
+    n = 10**9
+    out = {}
+    pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    devb = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    for name, (dst, src) in (("pinned_h2d_gb_s", (devb, pin)), ("pinned_d2h_gb_s", (pin, devb))):
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t)
+        out[name] = round((1 << 30) / min(ts[1:]) / 1e9, 1)
+    del pin, devb
+    seq = np.frombuffer(np.random.default_rng(1).bytes(n // 4), dtype=np.uint8)
+    seq = np.repeat(np.frombuffer(b"ACGT", dtype=np.uint8)[seq & 3], 4)[:n].copy()  # pageable, valid bases
+    ctx.set_variant("force_gpu", 0)
+    te, td = [], []
+    words = None
+    for _ in range(3):
+        t = time.perf_counter()
+        words = ctx.encode_array(seq)
+        te.append(time.perf_counter() - t)
+        t = time.perf_counter()
+        back = ctx.decode_array(words, n)
+        td.append(time.perf_counter() - t)
+    ctx.set_variant("force_gpu", 1)
+    out.update({"bases": n, "encode_gbases_s": round(n / min(te) / 1e9, 1), "decode_gbases_s": round(n / min(td) / 1e9, 1),
+                "encode_gb_s_moved": round(1.25 * n / min(te) / 1e9, 1), "decode_gb_s_moved": round(1.25 * n / min(td) / 1e9, 1),
+                "roundtrip_ok": bool(np.array_equal(seq, back)),
+                "encode_frac_of_pinned_h2d": round(n / min(te) / 1e9 / out["pinned_h2d_gb_s"], 3),
+                "decode_frac_of_pinned_d2h": round(n / min(td) / 1e9 / out["pinned_d2h_gb_s"], 3),
+                "note": "bitnuc_encode / bitnuc_decode on pageable host buffers: staged through pinned double buffers, H2D / kernel / D2H overlapped; PCIe-bound, never the reported value"})
+    return out
+
+
+def small_call_latency():
+    """The reference's criterion shapes (benches/simd_comparison.rs:19-89: as_2bit / from_2bit at 4-32 bases,
+    encode / decode at 1-1024 bases, cyclic ACGT input) through the drop-in's host path (size-dispatched SWAR code
+    inside libbitnuc_hip.so), timed in C by the library itself (bitnuc_selftime_small)."""
+    import ctypes as C
+    from bitnuc_amd import _lib as L
+    lib = L.load()
+    out = {}
+    for name, op, sizes in (("as_2bit", 0, (4, 8, 16, 31, 32)), ("from_2bit", 1, (4, 8, 16, 31, 32)),
+                            ("encode", 2, (1, 16, 32, 128, 1000, 1024)), ("decode", 3, (1, 16, 32, 128, 1000, 1024)),
+                            ("hdist_scalar", 4, (32,))):
+        out[name] = {str(s): round(lib.bitnuc_selftime_small(op, s, 200000), 2) for s in sizes}
+    out["unit"] = "ns per call (host path, median-free mean over 2e5 calls, C loop inside the library)"
+    out["gpu_launch_path_us"] = "a forced-GPU single call costs ~35 us (copy in, launch, copy out, one wait): DESIGN section 5"
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.traffic_child:
+        traffic_child(args)
+        return 0
+    in_rank = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_rank:
+        return self_launch(args, sys.argv[1:])
+    # stdout carries exactly ONE line (the JSON): libraries that print banners from C (RCCL does
+    # at communicator init) are sent to stderr by pointing fd 1 there and keeping the real stdout aside
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    traffic = None
+    if not args.rehearse_cpu:
+        if args.gpus == 1 and not in_rank and not args.no_traffic:
+            traffic = measure_traffic_live(args.bases)  # child processes under rocprofv3; this process has not touched the GPU yet
+            if "error" in traffic:
+                print(f"[bench] live PMC pass unavailable: {traffic['error']}", file=sys.stderr)
+                stored = stored_traffic()
+                traffic = stored if "error" not in stored else {"error": traffic["error"] + " | " + stored["error"]}
+        else:
+            traffic = stored_traffic()
+    return run_rank(args, real_stdout, traffic)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,14 +1,17 @@
 """ctypes binding of libbitnuc_hip.so (the C ABI in include/bitnuc_hip.h).
 
 There is no CPU fallback: if the shared library is missing this module raises
-at import of the symbol table, and every compute call on a machine without a HIP
-device returns BITNUC_BACKEND_ERROR, surfaced as `BackendError`.
+at import of the symbol table, and without a HIP device `Context()` raises `BackendError`
+(every device-pointer call and every bulk call needs a context).  The three single-word
+functions and host-pointer calls below the host cutoff are host code inside the same
+library (include/bitnuc_hip.h, "Size dispatch").
 """
 import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbitnuc_hip.so")
+SWEEP_LIB_PATH = os.path.join(HERE, "libbitnuc_hip_sweep.so")  # all 47 codec variants + the ballot formulation (evidence build)
 
 # bitnuc_status (include/bitnuc_hip.h) == NucleotideError (src/error.rs:3-18)
 OK, INVALID_BASE, SEQUENCE_TOO_LONG, INVALID_LENGTH = 0, 1, 2, 3
@@ -77,24 +80,25 @@ SIGNATURES = {
     "bitnuc_encode_sharded_allgather_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, C.POINTER(_P), _ERR]),
     "bitnuc_nucgen_dev": (C.c_int, [_P, _P, _SZ, _U64, _U64, C.c_int, _ERR]),
     "bitnuc_stream_probe_dev": (C.c_int, [_P, C.c_int, _P, _P, _SZ, _ERR]),
+    "bitnuc_selftime_small": (C.c_double, [C.c_int, _SZ, _SZ]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libbitnuc_hip.so and type every exported entry point."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load libbitnuc_hip.so (or the library at `path`) and type every exported entry point."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m bitnuc_amd.build` "
+            f"{path} is missing: build it with `python -m bitnuc_amd.build` "
             "(hipcc, gfx950). bitnuc_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib

@@ -11,7 +11,9 @@ Same names, argument meaning and error behaviour as the reference's
   * `decode(ebuf, n, dbuf)` / `from_2bit(p, n, seq)` APPEND (unpacking/avx.rs:122,140)
 `ebuf` may be a list or array('Q'); `dbuf` a bytearray.
 
-All arithmetic runs on the GPU through libbitnuc_hip.so.
+All bulk arithmetic runs on the GPU through libbitnuc_hip.so; single words and host-pointer calls
+below the library's host cutoff are the library's own host code (include/bitnuc_hip.h, "Size dispatch").
+The module-level single-word functions need no GPU context, like the reference's.
 """
 import ctypes as C
 
@@ -108,8 +110,8 @@ def _dev_ptr(x):
 class Context:
     """One device + stream + scratch (bitnuc_ctx).  Not thread-safe; make one per thread."""
 
-    def __init__(self, device=0, stream=None):
-        self._lib = L.load()
+    def __init__(self, device=0, stream=None, lib_path=None):
+        self._lib = L.load(lib_path)
         self._h = C.c_void_p()
         err = L.BitnucErr()
         if stream is None:
@@ -518,16 +520,30 @@ def default_context():
     return _default
 
 
+_ctxfree = None
+
+
+def context_free():
+    """A handle with a NULL bitnuc_ctx: the single-word functions (and bulk host-pointer calls below the
+    library's host cutoff) are host code and need no device, like the reference's free functions."""
+    global _ctxfree
+    if _ctxfree is None:
+        c = Context.__new__(Context)
+        c._lib, c._h, c.device = L.load(), C.c_void_p(0), None
+        _ctxfree = c
+    return _ctxfree
+
+
 def as_2bit(seq):
-    return default_context().as_2bit(seq)
+    return context_free().as_2bit(seq)
 
 
 def from_2bit(packed, expected_size, sequence):
-    return default_context().from_2bit(packed, expected_size, sequence)
+    return context_free().from_2bit(packed, expected_size, sequence)
 
 
 def from_2bit_alloc(packed, expected_size):
-    return default_context().from_2bit_alloc(packed, expected_size)
+    return context_free().from_2bit_alloc(packed, expected_size)
 
 
 def encode(sequence, ebuf):
@@ -543,7 +559,7 @@ def decode(ebuf, n_bases, dbuf):
 
 
 def hdist_scalar(u, v, length):
-    return default_context().hdist_scalar(u, v, length)
+    return context_free().hdist_scalar(u, v, length)
 
 
 def hdist(ebuf1, ebuf2, n_bases):

@@ -11,6 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbitnuc_hip.so")
+LIB_SWEEP = os.path.join(HERE, "libbitnuc_hip_sweep.so")  # evidence build: all 47 codec variants + the ballot formulation
 SOURCES = [os.path.join(CSRC, "bitnuc_hip.hip")]
 import glob
 
@@ -24,38 +25,43 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: libbitnuc_hip.so cannot be built (there is no CPU fallback)")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def is_stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build_library(force=False, verbose=True, extra_flags=()):
-    if not force and not is_stale():
-        return LIB
-    tmp = f"{LIB}.tmp.{os.getpid()}"  # other processes (bench ranks) only ever see a complete library
+def build_library(force=False, verbose=True, extra_flags=(), sweep=False):
+    """sweep=False: the product (libbitnuc_hip.so, the shipped codec variants).  sweep=True: the evidence build
+    (libbitnuc_hip_sweep.so, -DBITNUC_SWEEP_VARIANTS) that tools/sweep*.py and the all-variants parity test load."""
+    lib = LIB_SWEEP if sweep else LIB
+    if not force and not is_stale(lib):
+        return lib
+    tmp = f"{lib}.tmp.{os.getpid()}"  # other processes (bench ranks) only ever see a complete library
+    flags = list(extra_flags) + (["-DBITNUC_SWEEP_VARIANTS"] if sweep else [])
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-fno-gpu-rdc", *extra_flags, "-o", tmp, *SOURCES, "-ldl"]
+           "-Wall", "-Wno-unused-function", "-fno-gpu-rdc", *flags, "-o", tmp, *SOURCES, "-ldl", "-lpthread"]
     if verbose:
-        print(" ".join(cmd).replace(tmp, LIB), file=sys.stderr)
+        print(" ".join(cmd).replace(tmp, lib), file=sys.stderr)
     try:
         subprocess.run(cmd, check=True, cwd=HERE)
-        os.replace(tmp, LIB)
+        os.replace(tmp, lib)
     finally:
         if os.path.exists(tmp):
             os.unlink(tmp)
-    return LIB
+    return lib
 
 
-def ensure_built():
-    """Build libbitnuc_hip.so only if it is missing (a fresh checkout: the .so is git-ignored).  An existing
+def ensure_built(sweep=False):
+    """Build the library only if it is missing (a fresh checkout: the .so is git-ignored).  An existing
     library is used as is -- file times do not survive every copy, so staleness is `build_library`'s business."""
-    if not os.path.exists(LIB):
-        build_library(force=True)
-    return LIB
+    lib = LIB_SWEEP if sweep else LIB
+    if not os.path.exists(lib):
+        build_library(force=True, sweep=sweep)
+    return lib
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
-    print(LIB)
+    build_library(force="--force" in sys.argv, sweep="--sweep" in sys.argv)
+    print(LIB_SWEEP if "--sweep" in sys.argv else LIB)

@@ -10,18 +10,32 @@
 #include "kmer_device.h"
 #include "batch_device.h"
 #include "analysis_device.h"
+#include "host_word.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 using namespace bitnuc_dev;
 
 namespace {
 
 constexpr int kSlots = 4096;                    // data-error slots between two syncs
-constexpr size_t kHostChunk = (size_t)128 << 20; // bases per staged chunk on the host-pointer path
+constexpr size_t kHostChunk = (size_t)128 << 20; // bases per staged chunk on the simple host-pointer path
+constexpr size_t kPipeChunk = (size_t)32 << 20;  // bases per chunk of the pipelined host-pointer path (encode / decode)
+constexpr size_t kPipeMin = (size_t)8 << 20;     // inputs below this stay on the simple path (latency, not bandwidth, matters there)
+// Bulk host-pointer calls below this many bases run on the host (host_word.h): a launch with its two copies
+// costs ~35 us, the SWAR loop moves ~2-4 GB/s, so the crossover sits near 10^5 bases (tools/latency.py).
+constexpr size_t kDefaultHostCutoff = (size_t)64 << 10;
 
 struct Pending {
     unsigned long long base;   // added to the slot's index (host path chunk offset)
@@ -58,6 +72,10 @@ struct bitnuc_ctx {
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
+    int force_gpu = 0;                     // 1: single-word and below-cutoff calls launch kernels too (GPU parity tests, BITNUC_FORCE_GPU=1)
+    size_t host_cutoff = kDefaultHostCutoff; // bulk host-pointer calls below this many bases run on the host (host_word.h)
+    int host_pipeline = 1;                 // large host-pointer encode / decode: pinned double buffers + overlapped H2D / kernel / D2H
+    struct HostPipe *pipe = nullptr;       // created on the first large host-pointer call
 };
 
 namespace {
@@ -111,6 +129,142 @@ int ensure_scratch(bitnuc_ctx *c, int which, size_t bytes, bitnuc_err *err) {
     c->scratch_cap[which] = cap;
     return BITNUC_OK;
 }
+
+} // namespace
+
+// ---- pipelined host-pointer path --------------------------------------------------------------------
+// A caller's buffers are pageable.  Handing them to hipMemcpyAsync makes the runtime stage them through its own
+// pinned bounce buffers on the calling thread, serialising copy-in, kernel and copy-out.  Here the library owns the
+// staging: a small worker pool copies chunk c+1 from the caller's memory into one of two pinned input buffers while
+// the DMA engines move chunk c (H2D on one stream, D2H on another) and the kernel runs on the context's stream; events
+// order the three streams and guard buffer reuse; the host waits only when a pinned buffer is about to be overwritten.
+struct CopyPool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    uint8_t *dst = nullptr;
+    const uint8_t *src = nullptr;
+    size_t bytes = 0, slice = 0;
+    unsigned generation = 0, pending = 0;
+    bool stop = false;
+    int n = 1; // workers + the calling thread
+
+    explicit CopyPool(int nthreads) : n(nthreads < 1 ? 1 : nthreads) {
+        for (int i = 1; i < n; ++i) threads.emplace_back([this, i] { run(i); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    void copy_slice(int i) const {
+        const size_t a = slice * (size_t)i;
+        if (a >= bytes) return;
+        const size_t m = bytes - a < slice ? bytes - a : slice;
+        memcpy(dst + a, src + a, m);
+    }
+    void run(int i) {
+        unsigned seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv_work.wait(g, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            copy_slice(i);
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    void copy(void *d, const void *s_, size_t nbytes) { // blocking parallel memcpy
+        if (n == 1 || nbytes < ((size_t)1 << 20)) { memcpy(d, s_, nbytes); return; }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            dst = static_cast<uint8_t *>(d);
+            src = static_cast<const uint8_t *>(s_);
+            bytes = nbytes;
+            slice = ((nbytes + n - 1) / n + 4095) & ~(size_t)4095;
+            pending = (unsigned)(n - 1);
+            ++generation;
+        }
+        cv_work.notify_all();
+        copy_slice(0);
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return pending == 0; });
+    }
+};
+
+struct HostPipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    uint8_t *pin_a[2] = {nullptr, nullptr}, *pin_b[2] = {nullptr, nullptr}; // a: ASCII-sized (chunk + 64), b: word-sized (chunk / 4 + 64)
+    uint8_t *dev_a[2] = {nullptr, nullptr}, *dev_b[2] = {nullptr, nullptr};
+    CopyPool *pool = nullptr;
+    bool ok = false;
+};
+
+namespace {
+
+int host_threads() {
+    if (const char *e = getenv("BITNUC_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) return v;
+    }
+    cpu_set_t set;
+    int avail = 1;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) avail = CPU_COUNT(&set);
+    return avail < 8 ? (avail < 1 ? 1 : avail) : 8;
+}
+
+void pipe_destroy(HostPipe *p) {
+    if (!p) return;
+    for (int i = 0; i < 2; ++i) {
+        if (p->pin_a[i]) (void)hipHostFree(p->pin_a[i]);
+        if (p->pin_b[i]) (void)hipHostFree(p->pin_b[i]);
+        if (p->dev_a[i]) (void)hipFree(p->dev_a[i]);
+        if (p->dev_b[i]) (void)hipFree(p->dev_b[i]);
+        if (p->ev_in[i]) (void)hipEventDestroy(p->ev_in[i]);
+        if (p->ev_k[i]) (void)hipEventDestroy(p->ev_k[i]);
+        if (p->ev_out[i]) (void)hipEventDestroy(p->ev_out[i]);
+    }
+    if (p->s_in) (void)hipStreamDestroy(p->s_in);
+    if (p->s_out) (void)hipStreamDestroy(p->s_out);
+    delete p->pool;
+    delete p;
+}
+
+int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err) {
+    if (c->pipe && c->pipe->ok) { *out = c->pipe; return BITNUC_OK; }
+    HostPipe *p = new HostPipe();
+    hipError_t rc = hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking);
+    if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking);
+    const size_t na = kPipeChunk + 64, nb = kPipeChunk / 4 + 64;
+    for (int i = 0; i < 2 && rc == hipSuccess; ++i) {
+        rc = hipEventCreateWithFlags(&p->ev_in[i], hipEventDisableTiming);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&p->ev_k[i], hipEventDisableTiming);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&p->ev_out[i], hipEventDisableTiming);
+        if (rc == hipSuccess) rc = hipHostMalloc(reinterpret_cast<void **>(&p->pin_a[i]), na, hipHostMallocDefault);
+        if (rc == hipSuccess) rc = hipHostMalloc(reinterpret_cast<void **>(&p->pin_b[i]), nb, hipHostMallocDefault);
+        if (rc == hipSuccess) rc = hipMalloc(&p->dev_a[i], na);
+        if (rc == hipSuccess) rc = hipMalloc(&p->dev_b[i], nb);
+    }
+    if (rc != hipSuccess) { pipe_destroy(p); return fail_hip(err, rc); }
+    p->pool = new CopyPool(host_threads());
+    p->ok = true;
+    c->pipe = p;
+    *out = p;
+    return BITNUC_OK;
+}
+
+} // namespace
+
+namespace {
 
 // Drain: wait for the stream, find the first latched data error among the pending
 // launches (launch order), reset the slots.
@@ -178,7 +332,12 @@ inline size_t words_for(size_t n_bases) { return n_bases / 32 + (n_bases % 32 !=
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- kernel-variant tables -------------------------------------------------------
+// The product library ships the variants that are in use: the tuned defaults (encode 14, decode 22), the plain
+// reference shape (0) and the previous default (3).  The other 43 and the lane-per-base ballot formulation are
+// measurement evidence (profiles/): they are compiled only with -DBITNUC_SWEEP_VARIANTS, into
+// libbitnuc_hip_sweep.so, which tools/sweep*.py and the all-variants parity test load.
 //              id  UNROLL BLOCK NTLD   NTST   XPOSE  XCD
+#ifdef BITNUC_SWEEP_VARIANTS
 #define BITNUC_VARIANTS(X)                            \
     X(0, 4, 256, false, false, false, false)          \
     X(1, 4, 256, true, true, false, false)            \
@@ -227,8 +386,15 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
     X(44, 1, 128, true, true, false, true)            \
     X(45, 1, 512, true, true, false, true)            \
     X(46, 1, 1024, true, true, false, true)
-constexpr int kNumVariants = 47;
-constexpr int kBallotVariant = 100; // encode only: lane-per-base + ballot (selectable with set_variant("encode", 100))
+#else
+#define BITNUC_VARIANTS(X)                            \
+    X(0, 4, 256, false, false, false, false)          \
+    X(3, 2, 256, true, false, false, false)           \
+    X(14, 2, 128, true, false, false, false)          \
+    X(22, 2, 256, false, true, false, false)
+#endif
+constexpr int kNumVariants = 47;    // ids 0..46; which of them this build holds: variant_info(id).built
+[[maybe_unused]] constexpr int kBallotVariant = 100; // encode only: lane-per-base + ballot (sweep build; set_variant("encode", 100))
 // defaults from the sustained (back-to-back) pair sweeps in profiles/ (10^9 bases, one tile per
 // workgroup, 15 interleaved rounds in one process, decode reading words written two steps
 // earlier so that none of its input is Infinity-Cache resident -- what bench.py times):
@@ -240,12 +406,15 @@ constexpr int kBallotVariant = 100; // encode only: lane-per-base + ballot (sele
 // plateau of ~0.40 ms per step = 6.3 TB/s of mixed read/write HBM traffic.
 constexpr int kDefaultEnc = 14, kDefaultDec = 22;
 
-struct VariantInfo { int unroll, block; bool ntld, ntst, xpose, xcd; };
-constexpr VariantInfo kVariants[kNumVariants] = {
-#define X(id, U, B, NL, NS, XP, XC) {U, B, NL, NS, XP, XC},
-    BITNUC_VARIANTS(X)
+struct VariantInfo { int unroll, block; bool ntld, ntst, xpose, xcd, built; };
+constexpr VariantInfo variant_info(int id) {
+    switch (id) {
+#define X(vid, U, B, NL, NS, XP, XC) case vid: return VariantInfo{U, B, NL, NS, XP, XC, true};
+        BITNUC_VARIANTS(X)
 #undef X
-};
+    default: return VariantInfo{0, 0, false, false, false, false, false};
+    }
+}
 
 template <int UNROLL, int BLOCK, bool NTLD, bool NTST, bool XPOSE, bool XCD>
 hipError_t launch_encode_t(bitnuc_ctx *c, const uint8_t *seq, uint32_t *out32, unsigned long long len,
@@ -260,14 +429,16 @@ hipError_t launch_encode_t(bitnuc_ctx *c, const uint8_t *seq, uint32_t *out32, u
 hipError_t launch_encode(bitnuc_ctx *c, const uint8_t *seq, uint64_t *out, unsigned long long len, unsigned long long *slot) {
     uint32_t *o = reinterpret_cast<uint32_t *>(out);
     const bool in_al = aligned16(seq), out_al = aligned16(out);
+#ifdef BITNUC_SWEEP_VARIANTS
     if (c->enc_variant == kBallotVariant) { // lane-per-base + ballot formulation (evidence variant)
         const unsigned grid = grid_for(c, ((len + 63) / 64 + (kBlock / 64) * 4 - 1) / ((kBlock / 64) * 4));
         encode_ballot_kernel<4><<<grid, kBlock, 0, c->stream>>>(seq, reinterpret_cast<unsigned long long *>(out), len, slot);
         return hipGetLastError();
     }
+#endif
     int v = c->enc_variant;
     // the LDS-transpose variant needs 16-byte aligned buffers on both sides
-    if (kVariants[v].xpose && !(in_al && out_al)) v = kDefaultEnc;
+    if (variant_info(v).xpose && !(in_al && out_al)) v = kDefaultEnc;
     switch (v) {
 #define X(id, U, B, NL, NS, XP, XC) \
     case id: return launch_encode_t<U, B, NL, NS, XP, XC>(c, seq, o, len, slot, XP ? true : in_al);
@@ -290,7 +461,7 @@ hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsi
     const uint32_t *i = reinterpret_cast<const uint32_t *>(ebuf);
     const bool in_al = aligned16(ebuf), out_al = aligned16(out);
     int v = c->dec_variant;
-    if (kVariants[v].xpose && !in_al) v = kDefaultDec;
+    if (variant_info(v).xpose && !in_al) v = kDefaultDec;
     switch (v) {
 #define X(id, U, B, NL, NS, XP, XC) \
     case id: return launch_decode_t<U, B, NL, NS, XP, XC>(c, i, out, n_bases, out_al);
@@ -444,6 +615,8 @@ int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, 
     if (rc == hipSuccess) rc = hipMalloc(&c->d_sink, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_slots, 0xFF, sizeof(unsigned long long) * kSlots);
     if (rc == hipSuccess) rc = hipMemset(c->d_sink, 0, 64);
+    if (const char *e = getenv("BITNUC_FORCE_GPU")) c->force_gpu = atoi(e) != 0;
+    if (const char *e = getenv("BITNUC_HOST_CUTOFF")) { const long long v = atoll(e); if (v >= 0) c->host_cutoff = (size_t)v; }
     c->reduce_blocks = (unsigned)c->num_cu * 2; // a resident grid of 2 workgroups of 256 threads per CU (profiles/r01_sweep13_reduce_grid.txt: the tail of atomics + ticket grows with the grid)
     if (rc == hipSuccess) rc = hipMalloc(&c->d_acc, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_acc, 0, 64);
@@ -484,6 +657,7 @@ void bitnuc_ctx_destroy(bitnuc_ctx *c) {
     if (c->d_sink) (void)hipFree(c->d_sink);
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->d_tickets) (void)hipFree(c->d_tickets);
+    pipe_destroy(c->pipe);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -509,8 +683,27 @@ int bitnuc_ctx_sync(bitnuc_ctx *c, bitnuc_err *err) {
 int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     if (!c || !key) return -1;
     int prev = -1;
-    if (!strcmp(key, "encode")) { prev = c->enc_variant; if ((value >= 0 && value < kNumVariants) || value == kBallotVariant) c->enc_variant = value; }
-    else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0 && value < kNumVariants) c->dec_variant = value; }
+    if (!strcmp(key, "encode")) {
+        prev = c->enc_variant;
+        if (value >= 0) { // a variant this build does not hold is refused: -2, nothing changes
+#ifdef BITNUC_SWEEP_VARIANTS
+            if (value == kBallotVariant) { c->enc_variant = value; return prev; }
+#endif
+            if (!variant_info(value).built) return -2;
+            c->enc_variant = value;
+        }
+    }
+    else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0) { if (!variant_info(value).built) return -2; c->dec_variant = value; } }
+    else if (!strcmp(key, "force_gpu")) { prev = c->force_gpu; if (value == 0 || value == 1) c->force_gpu = value; }
+    else if (!strcmp(key, "host_cutoff")) { prev = (int)(c->host_cutoff > 0x7FFFFFFF ? 0x7FFFFFFF : c->host_cutoff); if (value >= 0) c->host_cutoff = (size_t)value; }
+    else if (!strcmp(key, "host_pipeline")) { prev = c->host_pipeline; if (value == 0 || value == 1) c->host_pipeline = value; }
+    else if (!strcmp(key, "sweep_build")) {
+#ifdef BITNUC_SWEEP_VARIANTS
+        prev = 1;
+#else
+        prev = 0;
+#endif
+    }
     else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
     else if (!strcmp(key, "batch_slide")) { prev = c->batch_slide; if (value >= 0 && value <= 1) c->batch_slide = value; }
@@ -645,6 +838,18 @@ int bitnuc_stream_probe_dev(bitnuc_ctx *c, int mode, const void *d_src, void *d_
         if (!d_dst || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
         if (nts) PROBE((probe_fill_kernel<4, true>), dst, n16); else PROBE((probe_fill_kernel<4, false>), dst, n16);
         break;
+    case 3: { // encode_kernel's shape (variant 14: 2 rounds, 128 threads, nt loads, plain stores): `bytes` of ASCII-side input
+        if (!d_src || !d_dst || !aligned16(d_src) || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
+        const unsigned g3 = grid_for(c, n16 / (128 * 2) + 1, 128);
+        probe_enc_shape_kernel<2, 128, true, false><<<g3, 128, 0, c->stream>>>(src, static_cast<uint32_t *>(d_dst), n16);
+        break;
+    }
+    case 4: { // decode_kernel's shape (variant 22: 2 rounds, 256 threads, plain loads, nt stores): `bytes` of ASCII-side output
+        if (!d_src || !d_dst || !aligned16(d_src) || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
+        const unsigned g4 = grid_for(c, n16 / (256 * 2) + 1, 256);
+        probe_dec_shape_kernel<2, 256, false, true><<<g4, 256, 0, c->stream>>>(static_cast<const uint32_t *>(d_src), dst, n16);
+        break;
+    }
     default:
         return fail(err, BITNUC_UNSUPPORTED);
     }
@@ -654,14 +859,109 @@ int bitnuc_stream_probe_dev(bitnuc_ctx *c, int mode, const void *d_src, void *d_
 }
 
 // ---- host-pointer entry points (synchronous, staged through device scratch) -------------------
+// true when a bulk host-pointer call of n bases belongs on the host: below the cutoff and not forced to the GPU.
+// A NULL context is accepted for such calls (the reference's functions need no context either).
+static inline bool on_host(const bitnuc_ctx *c, size_t n) {
+    return c ? (!c->force_gpu && n < c->host_cutoff) : n < kDefaultHostCutoff;
+}
+
+// encode / decode of a large pageable buffer: pinned double buffers, three streams (see HostPipe)
+static int encode_pipelined(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, size_t *n_words, bitnuc_err *err) {
+    HostPipe *p;
+    if (int st = pipe_get(c, &p, err)) return st;
+    const size_t nchunks = (len + kPipeChunk - 1) / kPipeChunk;
+    auto chunk_len = [&](size_t ci) { return len - ci * kPipeChunk < kPipeChunk ? len - ci * kPipeChunk : kPipeChunk; };
+    HIPCHK(hipEventRecord(p->ev_k[0], c->stream)); // earlier work on the context's stream finishes before the device buffers are reused
+    HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[0], 0));
+    for (size_t ci = 0; ci <= nchunks; ++ci) {
+        const int b = (int)(ci & 1);
+        if (ci < nchunks) {
+            const size_t n = chunk_len(ci), nw = words_for(n);
+            if (ci >= 2) HIPCHK(hipEventSynchronize(p->ev_in[b])); // pinned input b: its previous H2D has left
+            p->pool->copy(p->pin_a[b], seq + ci * kPipeChunk, n);
+            if (ci >= 2) HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[b], 0)); // device input b: the kernel of chunk ci-2 has read it
+            HIPCHK(hipMemcpyAsync(p->dev_a[b], p->pin_a[b], n, hipMemcpyHostToDevice, p->s_in));
+            HIPCHK(hipEventRecord(p->ev_in[b], p->s_in));
+            HIPCHK(hipStreamWaitEvent(c->stream, p->ev_in[b], 0));
+            if (ci >= 2) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_out[b], 0)); // device output b: its D2H of chunk ci-2 is done
+            unsigned long long *slot;
+            if (int st = take_slot(c, ci * kPipeChunk, &slot, err)) return st;
+            HIPCHK(launch_encode(c, p->dev_a[b], reinterpret_cast<uint64_t *>(p->dev_b[b]), n, slot));
+            HIPCHK(hipEventRecord(p->ev_k[b], c->stream));
+            HIPCHK(hipStreamWaitEvent(p->s_out, p->ev_k[b], 0));
+            HIPCHK(hipMemcpyAsync(p->pin_b[b], p->dev_b[b], nw * 8, hipMemcpyDeviceToHost, p->s_out)); // pinned output b was drained by the host one iteration ago
+            HIPCHK(hipEventRecord(p->ev_out[b], p->s_out));
+        }
+        if (ci >= 1) { // hand chunk ci-1's words to the caller while chunk ci is in flight
+            const int pb = (int)((ci - 1) & 1);
+            HIPCHK(hipEventSynchronize(p->ev_out[pb]));
+            p->pool->copy(out + (ci - 1) * (kPipeChunk / 32), p->pin_b[pb], words_for(chunk_len(ci - 1)) * 8);
+        }
+    }
+    bitnuc_err e;
+    const int st = drain(c, &e); // one drain at the end: slots are examined in launch order = sequence order
+    if (st != BITNUC_OK) {
+        if (err) *err = e;
+        if (st == BITNUC_INVALID_BASE && n_words) *n_words = (size_t)(e.index / 32);
+        return st;
+    }
+    if (n_words) *n_words = words_for(len);
+    return BITNUC_OK;
+}
+
+static int decode_pipelined(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_bases, uint8_t *out, bitnuc_err *err) {
+    HostPipe *p;
+    if (int st = pipe_get(c, &p, err)) return st;
+    const size_t nchunks = (n_bases + kPipeChunk - 1) / kPipeChunk;
+    auto chunk_len = [&](size_t ci) { return n_bases - ci * kPipeChunk < kPipeChunk ? n_bases - ci * kPipeChunk : kPipeChunk; };
+    HIPCHK(hipEventRecord(p->ev_k[0], c->stream));
+    HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[0], 0));
+    for (size_t ci = 0; ci <= nchunks; ++ci) {
+        const int b = (int)(ci & 1);
+        if (ci < nchunks) {
+            const size_t n = chunk_len(ci), nw = words_for(n);
+            if (ci >= 2) HIPCHK(hipEventSynchronize(p->ev_in[b]));
+            p->pool->copy(p->pin_b[b], ebuf + ci * (kPipeChunk / 32), nw * 8);
+            if (ci >= 2) HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[b], 0));
+            HIPCHK(hipMemcpyAsync(p->dev_b[b], p->pin_b[b], nw * 8, hipMemcpyHostToDevice, p->s_in));
+            HIPCHK(hipEventRecord(p->ev_in[b], p->s_in));
+            HIPCHK(hipStreamWaitEvent(c->stream, p->ev_in[b], 0));
+            if (ci >= 2) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_out[b], 0));
+            HIPCHK(launch_decode(c, reinterpret_cast<const uint64_t *>(p->dev_b[b]), p->dev_a[b], n));
+            HIPCHK(hipEventRecord(p->ev_k[b], c->stream));
+            HIPCHK(hipStreamWaitEvent(p->s_out, p->ev_k[b], 0));
+            HIPCHK(hipMemcpyAsync(p->pin_a[b], p->dev_a[b], n, hipMemcpyDeviceToHost, p->s_out));
+            HIPCHK(hipEventRecord(p->ev_out[b], p->s_out));
+        }
+        if (ci >= 1) {
+            const int pb = (int)((ci - 1) & 1);
+            HIPCHK(hipEventSynchronize(p->ev_out[pb]));
+            p->pool->copy(out + (ci - 1) * kPipeChunk, p->pin_a[pb], chunk_len(ci - 1));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BITNUC_OK;
+}
+
 int bitnuc_encode(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, size_t *n_words, bitnuc_err *err) {
     clear_err(err);
     if (n_words) *n_words = 0;
-    if (int st = check_ctx(c, err)) return st;
-    if (len == 0) return BITNUC_OK;
+    if (len == 0) return BITNUC_OK; // 0 words (the reference panics there: packing/avx.rs:138)
     if (!seq || !out) return fail(err, BITNUC_UNSUPPORTED);
+    if (on_host(c, len)) { // host_word.h: same words, same first-invalid-byte rule, no launch
+        const long long bad = bitnuc_host::encode_small(seq, len, out);
+        if (bad >= 0) {
+            if (err) { memset(err, 0, sizeof *err); err->status = BITNUC_INVALID_BASE; err->byte = seq[bad]; err->index = (uint64_t)bad; }
+            if (n_words) *n_words = (size_t)bad / 32;
+            return BITNUC_INVALID_BASE;
+        }
+        if (n_words) *n_words = words_for(len);
+        return BITNUC_OK;
+    }
+    if (int st = check_ctx(c, err)) return st;
     DeviceGuard g(c->device);
     if (int st = flush_pending(c, err)) return st;
+    if (c->host_pipeline && len >= kPipeMin) return encode_pipelined(c, seq, len, out, n_words, err);
     const size_t chunk = len < kHostChunk ? len : kHostChunk;
     if (int st = ensure_scratch(c, 0, chunk + 16, err)) return st;
     if (int st = ensure_scratch(c, 1, words_for(chunk) * 8 + 16, err)) return st;
@@ -688,11 +988,16 @@ int bitnuc_encode(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, 
 
 int bitnuc_decode(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_words, size_t n_bases, uint8_t *out, bitnuc_err *err) {
     clear_err(err);
-    if (int st = check_ctx(c, err)) return st;
     if (n_words < words_for(n_bases)) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
     if (n_bases == 0) return BITNUC_OK;
     if (!ebuf || !out) return fail(err, BITNUC_UNSUPPORTED);
+    if (on_host(c, n_bases)) {
+        bitnuc_host::decode_small(ebuf, n_bases, out);
+        return BITNUC_OK;
+    }
+    if (int st = check_ctx(c, err)) return st;
     DeviceGuard g(c->device);
+    if (c->host_pipeline && n_bases >= kPipeMin) return decode_pipelined(c, ebuf, n_bases, out, err);
     const size_t chunk = n_bases < kHostChunk ? n_bases : kHostChunk;
     if (int st = ensure_scratch(c, 0, chunk + 16, err)) return st;
     if (int st = ensure_scratch(c, 1, words_for(chunk) * 8 + 16, err)) return st;
@@ -767,12 +1072,13 @@ int bitnuc_kmer_hdist_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k
 
 int bitnuc_hdist(bitnuc_ctx *c, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, size_t n_bases, uint32_t *out, bitnuc_err *err) {
     clear_err(err);
-    if (int st = check_ctx(c, err)) return st;
     const size_t need = words_for(n_bases);
     if (na < need || nb < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
     if (!out) return fail(err, BITNUC_UNSUPPORTED);
     if (n_bases == 0) { *out = 0; return BITNUC_OK; }
     if (!a || !b) return fail(err, BITNUC_UNSUPPORTED);
+    if (on_host(c, n_bases)) { *out = bitnuc_host::hdist_small(a, b, n_bases); return BITNUC_OK; }
+    if (int st = check_ctx(c, err)) return st;
     DeviceGuard g(c->device);
     const size_t chunk_words = kHostChunk / 8;
     const size_t cw = need < chunk_words ? need : chunk_words;
@@ -1441,28 +1747,71 @@ int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_co
     return BITNUC_OK;
 }
 
-// ---- single-word API: batches of one on the device ---------------------------------------------
+// ---- single-word API: host code; batches of one on the device when forced ----------------
 int bitnuc_as_2bit(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, bitnuc_err *err) {
     clear_err(err);
-    if (int st = check_ctx(c, err)) return st;
-    if (len > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, len);
-    if (!out) return fail(err, BITNUC_UNSUPPORTED);
-    return bitnuc_as_2bit_batch(c, seq, len, len ? len : 1, 1, out, err);
+    if (len > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, len); // packing/naive.rs:5-7: before any base is looked at
+    if (!out || (len && !seq)) return fail(err, BITNUC_UNSUPPORTED);
+    if (c && c->force_gpu) return bitnuc_as_2bit_batch(c, seq, len, len ? len : 1, 1, out, err);
+    uint64_t w = 0;
+    const int bad = bitnuc_host::pack_word(seq, len, &w);
+    if (bad >= 0) {
+        if (err) { memset(err, 0, sizeof *err); err->status = BITNUC_INVALID_BASE; err->byte = seq[bad]; err->index = (uint64_t)bad; }
+        return BITNUC_INVALID_BASE;
+    }
+    *out = w;
+    return BITNUC_OK;
 }
 
 int bitnuc_from_2bit(bitnuc_ctx *c, uint64_t packed, size_t n, uint8_t *out, bitnuc_err *err) {
     clear_err(err);
-    if (int st = check_ctx(c, err)) return st;
     if (n > 32) return fail(err, BITNUC_INVALID_LENGTH, n); // unpacking/naive.rs:8-10
     if (n == 0) return BITNUC_OK;
-    return bitnuc_decode(c, &packed, 1, n, out, err);
+    if (!out) return fail(err, BITNUC_UNSUPPORTED);
+    if (c && c->force_gpu) return bitnuc_decode(c, &packed, 1, n, out, err);
+    bitnuc_host::unpack_word(packed, n, out);
+    return BITNUC_OK;
 }
 
 int bitnuc_hdist_scalar(bitnuc_ctx *c, uint64_t u, uint64_t v, size_t len, uint32_t *out, bitnuc_err *err) {
     clear_err(err);
-    if (int st = check_ctx(c, err)) return st;
     if (len > 32) return fail(err, BITNUC_INVALID_LENGTH, len); // hamming/scalar.rs:13-15
-    return bitnuc_hdist(c, &u, 1, &v, 1, len, out, err);
+    if (!out) return fail(err, BITNUC_UNSUPPORTED);
+    if (c && c->force_gpu) return bitnuc_hdist(c, &u, 1, &v, 1, len, out, err);
+    *out = bitnuc_host::hdist_word(u, v, len);
+    return BITNUC_OK;
+}
+
+// Diagnostic (bench.py's small_call_latency block): mean ns per call of the HOST path over `iters` calls on the
+// reference's bench input (cyclic "ACGT", benches/simd_comparison.rs:4-7), timed here so that no binding overhead is in it.
+// op: 0 as_2bit, 1 from_2bit, 2 encode, 3 decode, 4 hdist_scalar.  Returns < 0 on a bad argument.
+double bitnuc_selftime_small(int op, size_t n, size_t iters) {
+    if (iters == 0 || n == 0 || n > ((size_t)1 << 20) || ((op == 0 || op == 1 || op == 4) && n > 32)) return -1.0;
+    std::vector<uint8_t> seq(n), back(n);
+    for (size_t i = 0; i < n; ++i) seq[i] = "ACGT"[i & 3];
+    std::vector<uint64_t> words(words_for(n) + 1);
+    size_t nw = 0;
+    bitnuc_err e;
+    if (bitnuc_encode(nullptr, seq.data(), n, words.data(), &nw, &e) != BITNUC_OK && n < kDefaultHostCutoff) return -1.0;
+    volatile uint64_t sink = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t it = 0; it < iters; ++it) {
+        uint64_t w = 0;
+        uint32_t d = 0;
+        seq[0] = "AC"[it & 1]; // the input changes between calls: the compiler cannot hoist the work
+        switch (op) {
+        case 0: (void)bitnuc_as_2bit(nullptr, seq.data(), n, &w, &e); sink += w; break;
+        case 1: (void)bitnuc_from_2bit(nullptr, words[0] ^ it, n, back.data(), &e); sink += back[0]; break;
+        case 2: (void)bitnuc_encode(nullptr, seq.data(), n, words.data(), &nw, &e); sink += words[0]; break;
+        case 3: words[0] ^= it & 3; (void)bitnuc_decode(nullptr, words.data(), nw, n, back.data(), &e); sink += back[0]; break;
+        case 4: (void)bitnuc_hdist_scalar(nullptr, words[0] ^ it, words[0], n, &d, &e); sink += d; break;
+        default: return -1.0;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    (void)sink;
+    return ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / (double)iters;
 }
 
 } // extern "C"

@@ -394,6 +394,25 @@ __device__ __forceinline__ unsigned long long gen_word(unsigned long long seed, 
     return mix64(seed + (widx + 1) * 0x9E3779B97F4A7C15ull);
 }
 
+// flags bit 1: lower-case mix (SURVEY 8d parity variant, p = 0.25): base i is lower case iff the 2-bit field i of a second,
+// independent word stream (seed ^ kCaseSalt) is zero.  Returns 0x20 in the bytes of a 16-base group that are lower case.
+constexpr unsigned long long kCaseSalt = 0xC0FFEE5EEDC0DE55ull;
+__device__ __forceinline__ u32x4 case_bits16(uint32_t bits) { // 32 bits = 16 two-bit fields -> 16 bytes of 0x20 / 0x00
+    // field == 0  <=>  neither of its two bits is set
+    const uint32_t z = ~(bits | (bits >> 1)) & 0x55555555u; // bit 2j set iff field j is zero
+    u32x4 o;
+    const uint32_t parts[4] = {z & 0xFFu, (z >> 8) & 0xFFu, (z >> 16) & 0xFFu, z >> 24};
+    uint32_t r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t sft = (parts[q] | (parts[q] << 12)) & 0x000F000Fu; // the dec4 spread: field j of the byte -> byte j
+        sft = (sft | (sft << 6)) & 0x03030303u;
+        r[q] = (sft & 0x01010101u) << 5;
+    }
+    o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+    return o;
+}
+
 __global__ void __launch_bounds__(kBlock)
 nucgen_kernel(uint8_t *__restrict__ out, unsigned long long len, unsigned long long seed,
               unsigned long long first, int flags) {
@@ -406,7 +425,13 @@ nucgen_kernel(uint8_t *__restrict__ out, unsigned long long len, unsigned long l
         const unsigned long long w0 = gen_word(seed, widx, flags);
         unsigned long long bits = w0 >> s;
         if (s > 32) bits |= gen_word(seed, widx + 1, flags) << (64 - s);
-        const u32x4 v = dec16((uint32_t)bits);
+        u32x4 v = dec16((uint32_t)bits);
+        if (flags & 2) {
+            const unsigned long long c0 = gen_word(seed ^ kCaseSalt, widx, 0);
+            unsigned long long cb = c0 >> s;
+            if (s > 32) cb |= gen_word(seed ^ kCaseSalt, widx + 1, 0) << (64 - s);
+            v |= case_bits16((uint32_t)cb);
+        }
         const unsigned long long o = g << 4;
         if (o + 16 <= len) {
             store_group<false, false>(out + o, v);
@@ -471,6 +496,45 @@ probe_fill_kernel(u32x4 *__restrict__ dst, unsigned long long n16) {
         for (int u = 0; u < UNROLL; ++u) {
             u32x4 *q = dst + tile * TILE + u * kBlock + threadIdx.x;
             if constexpr (NT) __builtin_nontemporal_store(v, q); else *q = v;
+        }
+    }
+}
+
+
+// The codec kernels' exact access shapes with no arithmetic between load and store (bench.py's *_shape probes):
+// ENC: 16 B load + 4 B store per lane and round (1 : 0.25), DEC: 4 B load + 16 B store.  Same tile walk, block size,
+// rounds in flight and cache policy as encode_kernel / decode_kernel.
+template <int UNROLL, int BLOCK, bool NTLD, bool NTST>
+__global__ void __launch_bounds__(BLOCK)
+probe_enc_shape_kernel(const u32x4 *__restrict__ src, uint32_t *__restrict__ dst, unsigned long long n16) {
+    constexpr unsigned long long TILE = (unsigned long long)BLOCK * UNROLL;
+    const unsigned long long full_tiles = n16 / TILE;
+    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u32x4 *p = src + tile * TILE + u * BLOCK + threadIdx.x;
+            if constexpr (NTLD) v[u] = __builtin_nontemporal_load(p); else v[u] = *p;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) store_u32<NTST>(dst + tile * TILE + u * BLOCK + threadIdx.x, v[u].x ^ v[u].y ^ v[u].z ^ v[u].w);
+    }
+}
+
+template <int UNROLL, int BLOCK, bool NTLD, bool NTST>
+__global__ void __launch_bounds__(BLOCK)
+probe_dec_shape_kernel(const uint32_t *__restrict__ src, u32x4 *__restrict__ dst, unsigned long long n16) {
+    constexpr unsigned long long TILE = (unsigned long long)BLOCK * UNROLL;
+    const unsigned long long full_tiles = n16 / TILE;
+    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+        uint32_t h[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) h[u] = load_u32<NTLD>(src + tile * TILE + u * BLOCK + threadIdx.x);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u32x4 v = {h[u], h[u] + 1u, h[u] + 2u, h[u] + 3u};
+            u32x4 *q = dst + tile * TILE + u * BLOCK + threadIdx.x;
+            if constexpr (NTST) __builtin_nontemporal_store(v, q); else *q = v;
         }
     }
 }

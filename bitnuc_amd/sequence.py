@@ -1,9 +1,10 @@
 """PackedSequence -- the reference's owned high-level type (src/sequence.rs:5-262) over
 device-encoded data, plus its GCContent / BaseCount traits (src/utils/analysis.rs:3-39).
 
-`data` (u64 words) and `length` have the reference's meaning; `new` encodes on the GPU,
-`slice` / `to_vec` / `get` decode on the GPU (only the words the range touches), the trait
-methods count on the packed words on the GPU.  Range / index checks are the reference's.
+`data` (u64 words) and `length` have the reference's meaning; `new` encodes and `slice` /
+`to_vec` decode through the library (only the words the range touches; on the GPU above the
+library's host cutoff), `get` is the reference's shift and mask, the trait methods count on the
+packed words on the GPU.  Range / index checks are the reference's.
 """
 import numpy as np
 
@@ -36,8 +37,8 @@ class PackedSequence:
     def get(self, index):  # sequence.rs:116-135
         if index < 0 or index >= self.length:
             raise NucleotideError("IndexOutOfBounds", index=index, length=self.length)
-        word = int(self.data[index // 32]) >> (2 * (index % 32))  # bring the base's 2-bit field to bit 0
-        return self._ctx.from_2bit_alloc(word & 0xFFFFFFFFFFFFFFFF, 1)[0]
+        # the reference's shift + mask + match (sequence.rs:121-134): no call into the library at all
+        return b"ACGT"[(int(self.data[index // 32]) >> (2 * (index % 32))) & 3]
 
     def slice(self, start, end):  # sequence.rs:198-212
         if start < 0 or start > end or end > self.length:

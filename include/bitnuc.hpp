@@ -307,9 +307,8 @@ class PackedSequence {
             NucleotideError e; e.kind = NucleotideError::IndexOutOfBounds; e.oob_index = index; e.length = length_;
             return e;
         }
-        auto r = default_context().from_2bit_alloc(data_[index / 32] >> (2 * (index % 32)), 1);
-        if (r.is_err()) return r.unwrap_err();
-        return r.unwrap()[0];
+        // the reference's shift + mask + match (sequence.rs:121-134): no call into the library
+        return static_cast<uint8_t>("ACGT"[(data_[index / 32] >> (2 * (index % 32))) & 3]);
     }
     Result<std::vector<uint8_t>> slice(size_t start, size_t end) const { // sequence.rs:198-212
         if (start > end || end > length_) {

@@ -8,15 +8,27 @@
  * for every symbol is shown in INTEGRATION.md / rust/src/ffi.rs; include/bitnuc.hpp
  * is the compiled C++ host layer with the reference's names and Vec semantics.
  *
- * All compute happens in hand-written HIP kernels (bitnuc_amd/csrc/).  There is
- * no CPU fallback: without a usable HIP device every compute entry point returns
- * BITNUC_BACKEND_ERROR.
+ * All bulk compute happens in hand-written HIP kernels (bitnuc_amd/csrc/).  There is
+ * no CPU fallback: without a usable HIP device context creation fails and every
+ * device-pointer call and every bulk call at or above the host cutoff returns
+ * BITNUC_BACKEND_ERROR / BITNUC_UNSUPPORTED.
+ *
+ * Size dispatch: the reference's as_2bit / from_2bit / hdist_scalar are
+ * #[inline(always)] nanosecond functions, and a kernel launch with its copies costs
+ * ~35 us, so the three single-word entry points and bulk HOST-POINTER calls below
+ * `host_cutoff` bases (default 65 536; bitnuc_ctx_set_variant(ctx, "host_cutoff", n) or
+ * BITNUC_HOST_CUTOFF) run as the library's own SWAR host code (csrc/host_word.h) and
+ * accept ctx == NULL.  bitnuc_ctx_set_variant(ctx, "force_gpu", 1) or BITNUC_FORCE_GPU=1
+ * sends every call to the kernels (batches of one) -- the GPU parity tests run that way.
  *
  * Conventions
  *   - plain pointers + sizes, no torch / C++ types in signatures;
  *   - return value == err->status (err may be NULL);
- *   - "host" entry points take host pointers, stage through device scratch owned
- *     by the context (hipMemcpyAsync in 128 Mbase chunks) and are synchronous;
+ *   - "host" entry points take host pointers and are synchronous; large encode / decode
+ *     calls (>= 8 Mi bases) are pipelined: a worker pool copies the caller's pageable memory
+ *     into pinned double buffers while H2D, kernel and D2H of the neighbouring 32 Mi-base
+ *     chunks overlap on three streams (BITNUC_HOST_THREADS sets the pool size, default 8);
+ *     the other host entry points stage through device scratch in 128 Mbase chunks;
  *     "_dev" entry points take device pointers, are enqueued
  *     on the context's stream and return immediately -- data-dependent errors
  *     (InvalidBase) are latched on the device and reported by bitnuc_ctx_sync();
@@ -72,11 +84,10 @@ void *bitnuc_ctx_stream(bitnuc_ctx *ctx);
 /* Library / build identification ("bitnuc_hip <ver> gfx950"). */
 const char *bitnuc_version(void);
 
-/* ---- single-word API (host) ------------------------------------------------- */
+/* ---- single-word API (host code, ctx may be NULL; see "Size dispatch" above) ------------------ */
 /* as_2bit(seq:&[u8]) -> Result<u64>          src/utils/packing/mod.rs:80-110
  * len > 32 -> SEQUENCE_TOO_LONG(len) before any base is looked at; first bad byte
- * -> INVALID_BASE(byte); len == 0 -> OK, 0.  Runs as a batch of one on the GPU:
- * for many k-mers use bitnuc_as_2bit_batch. */
+ * -> INVALID_BASE(byte, index); len == 0 -> OK, 0.  For many k-mers use bitnuc_as_2bit_batch. */
 int bitnuc_as_2bit(bitnuc_ctx *ctx, const uint8_t *seq, size_t len, uint64_t *out, bitnuc_err *err);
 /* from_2bit(packed, expected_size, &mut Vec<u8>)  src/utils/unpacking/mod.rs:119-147
  * n > 32 -> INVALID_LENGTH(n).  Writes exactly n bytes at out (the Vec append
@@ -228,18 +239,29 @@ int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_co
  * src/utils/mod.rs:116-121; its stream is unpinned, so the build ships its own) ---- */
 /* Fill d_out[0..len) with bases first..first+len of the seeded stream
  * base(i) = "ACGT"[(splitmix64(seed + (i/32+1)*0x9E3779B97F4A7C15) >> 2*(i%32)) & 3];
- * flags bit0: the benches' cyclic "ACGT"[i%4] pattern (benches/simd_comparison.rs:4-7). */
+ * flags bit0: the benches' cyclic "ACGT"[i%4] pattern (benches/simd_comparison.rs:4-7);
+ * bit1: lower-case mix, p = 0.25 (SURVEY 8d parity variant): base i is lower case iff 2-bit field i%32 of
+ * splitmix64((seed ^ 0xC0FFEE5EEDC0DE55) + (i/32+1)*0x9E3779B97F4A7C15) is zero. */
 int bitnuc_nucgen_dev(bitnuc_ctx *ctx, uint8_t *d_out, size_t len, uint64_t seed, uint64_t first, int flags, bitnuc_err *err);
 
 /* ---- tuning / diagnostics (not part of the drop-in surface) ---------------------- */
-/* Select kernel variants for experiments: key in {"encode","decode"}; returns the
- * previous value or -1 for an unknown key. */
+/* Knobs: key in {"force_gpu", "host_cutoff", "host_pipeline"} (see "Size dispatch"), kernel-variant
+ * selectors {"encode", "decode", "grid_mult", ...} for experiments.  A negative value only queries.
+ * Returns the previous value, -1 for an unknown key, -2 for a variant this build does not hold (the
+ * product library ships 4 of the 47 encode/decode variants; libbitnuc_hip_sweep.so, built with
+ * -DBITNUC_SWEEP_VARIANTS, holds all of them plus the ballot formulation). */
 int bitnuc_ctx_set_variant(bitnuc_ctx *ctx, const char *key, int value);
 /* Pure streaming kernels used to measure the box's HBM ceiling next to the codec:
  * mode bits 0-2: 0 = read-only sum of `bytes` from d_src; 1 = copy d_src -> d_dst;
- * 2 = write-only fill of d_dst.  bit 3: nt loads, bit 4: nt stores, bit 5: 2 (not 4)
- * 16-byte groups in flight per lane. */
+ * 2 = write-only fill of d_dst; 3 = encode_kernel's access shape (16 B nt load + 4 B store per lane, 2 in
+ * flight, 128-thread workgroups) and 4 = decode_kernel's (4 B load + 16 B nt store, 256-thread workgroups),
+ * both without arithmetic, `bytes` = ASCII-side bytes.  bit 3: nt loads, bit 4: nt stores, bit 5: 2 (not 4)
+ * 16-byte groups in flight per lane (modes 0-2). */
 int bitnuc_stream_probe_dev(bitnuc_ctx *ctx, int mode, const void *d_src, void *d_dst, size_t bytes, bitnuc_err *err);
+
+/* Mean ns per call of the HOST path (op 0 as_2bit, 1 from_2bit, 2 encode, 3 decode, 4 hdist_scalar) on n bases of the
+ * reference's bench input (benches/simd_comparison.rs:4-7), timed inside the library over `iters` calls; < 0 = bad argument. */
+double bitnuc_selftime_small(int op, size_t n, size_t iters);
 
 #ifdef __cplusplus
 }

@@ -295,5 +295,9 @@ void orc_nucgen(uint8_t *out, size_t len, uint64_t seed, uint64_t first,
             uint64_t w = mix64(seed + (i / 32 + 1) * 0x9E3779B97F4A7C15ull);
             out[j] = lut[(w >> (2 * (i % 32))) & 3];
         }
+        if (flags & 2) { /* lower-case mix, p = 0.25 (SURVEY 8d parity variant): a second word stream decides the case */
+            uint64_t c = mix64((seed ^ 0xC0FFEE5EEDC0DE55ull) + (i / 32 + 1) * 0x9E3779B97F4A7C15ull);
+            if (((c >> (2 * (i % 32))) & 3) == 0) out[j] |= 0x20;
+        }
     }
 }

@@ -274,7 +274,8 @@ impl PackedSequence {
         if index >= self.length {
             return Err(NucleotideError::IndexOutOfBounds { index, length: self.length });
         }
-        Ok(from_2bit_alloc(self.data[index / 32] >> ((index % 32) * 2), 1)?[0])
+        // the reference's shift + mask + match (sequence.rs:121-134): no call into the library
+        Ok(b"ACGT"[((self.data[index / 32] >> ((index % 32) * 2)) & 3) as usize])
     }
     pub fn slice(&self, range: std::ops::Range<usize>) -> Result<Vec<u8>, NucleotideError> {
         if range.start > range.end || range.end > self.length {

@@ -34,5 +34,20 @@ def ctx():
     from bitnuc_amd import build
     build.ensure_built()  # a fresh checkout has no .so (git-ignored): compile the product, never substitute it
     c = bitnuc_amd.Context(0)
+    # every GPU parity test exercises the KERNELS: single words and tiny inputs run as batches of one on the device
+    # (the library's size dispatch would otherwise keep them on the host: tests/test_host_path.py covers that side)
+    c.set_variant("force_gpu", 1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def sweep_ctx():
+    """Context on the evidence build (all 47 codec variants + the ballot formulation)."""
+    import bitnuc_amd
+    from bitnuc_amd import build
+    build.ensure_built(sweep=True)
+    c = bitnuc_amd.Context(0, lib_path=build.LIB_SWEEP)
+    c.set_variant("force_gpu", 1)
     yield c
     c.close()

@@ -112,8 +112,9 @@ SIZES = [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, 4095, 4096, 4097, 16384 * 
 
 
 @pytest.mark.parametrize("variant", range(47))
-def test_encode_decode_variants_vs_oracle(ctx, oracle, variant):
-    assert ctx.get("num_variants") == 47
+def test_encode_decode_variants_vs_oracle(sweep_ctx, oracle, variant):
+    ctx = sweep_ctx  # the evidence build holds all 47; the product ships 4 of them (next test)
+    assert ctx.get("num_variants") == 47 and ctx.get("sweep_build") == 1
     enc0 = ctx.set_variant("encode", variant)
     dec0 = ctx.set_variant("decode", variant)
     try:
@@ -128,6 +129,25 @@ def test_encode_decode_variants_vs_oracle(ctx, oracle, variant):
     finally:
         ctx.set_variant("encode", enc0)
         ctx.set_variant("decode", dec0)
+
+
+def test_product_ships_only_the_variants_in_use(ctx, oracle):
+    assert ctx.get("sweep_build") == 0
+    built = [v for v in range(47) if ctx.set_variant("encode", v) != -2]
+    ctx.set_variant("encode", 14)
+    assert built == [0, 3, 14, 22]
+    assert ctx.set_variant("encode", 100) == -2 and ctx.get("encode") == 14  # the ballot formulation is evidence, not product
+    for v in built:
+        enc0, dec0 = ctx.set_variant("encode", v), ctx.set_variant("decode", v)
+        try:
+            for n in SIZES:
+                s = rand_seq(n)
+                w = ctx.encode_array(s)
+                assert np.array_equal(w, oracle.encode(s)), (v, n)
+                assert np.array_equal(ctx.decode_array(w, n), oracle.decode(w, n)), (v, n)
+        finally:
+            ctx.set_variant("encode", enc0)
+            ctx.set_variant("decode", dec0)
 
 
 @pytest.mark.parametrize("grid_mult", [0, 1, 8])
@@ -1288,9 +1308,10 @@ def test_encode_many_and_fuzz(ctx, oracle):
         assert bytes(ctx.decode_batch(bw, bwo, off)) == bytes(s).upper()
 
 
-def test_ballot_formulation_variant(ctx, oracle):
+def test_ballot_formulation_variant(sweep_ctx, oracle):
     """north_star's lane-per-base + wavefront-ballot encode (variant 100): same bits, same errors."""
     import bitnuc_amd as bn
+    ctx = sweep_ctx
     prev = ctx.set_variant("encode", 100)
     try:
         for n in [1, 31, 32, 33, 63, 64, 65, 127, 128, 1000, 4097, 1000003]:

@@ -21,7 +21,8 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream()
-    ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+    from bitnuc_amd import build as _b
+    ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=_b.ensure_built(sweep=True))  # the evidence build holds all 47 variants
     n = args.bases
     nw = (n + 31) // 32
     R = 3
