@@ -56,6 +56,14 @@ SIGNATURES = {
     "bitnuc_decode_batch_dev": (C.c_int, [_P, _P, _P, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_encode_batch": (C.c_int, [_P, _P, _P, _SZ, _P, _SZ, _P, C.POINTER(_SZ), _ERR]),
     "bitnuc_decode_batch": (C.c_int, [_P, _P, _P, _P, _SZ, _P, _ERR]),
+    "bitnuc_batch_plan_create": (C.c_int, [_P, C.POINTER(_P), _ERR]),
+    "bitnuc_batch_plan_build_dev": (C.c_int, [_P, _P, _P, _SZ, C.POINTER(_SZ), _ERR]),
+    "bitnuc_batch_plan_destroy": (None, [_P]),
+    "bitnuc_batch_plan_total_words": (_SZ, [_P]),
+    "bitnuc_batch_plan_count": (_SZ, [_P]),
+    "bitnuc_batch_plan_word_offsets_dev": (_P, [_P]),
+    "bitnuc_encode_batch_plan_dev": (C.c_int, [_P, _P, _P, _P, _ERR]),
+    "bitnuc_decode_batch_plan_dev": (C.c_int, [_P, _P, _P, _P, _ERR]),
     "bitnuc_encode_fixed_dev": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
     "bitnuc_decode_fixed_dev": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
     "bitnuc_encode_fixed": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
@@ -86,6 +94,28 @@ SIGNATURES = {
 _libs = {}
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as /opt/rocm's, requested under another name).
+    If libbitnuc_hip.so pulls in the system runtime first, a later `import torch` loads a SECOND HIP runtime into the
+    process and fails with "No HIP GPUs are available".  Loading torch's copy first makes both sides share one runtime
+    (our DT_NEEDED libamdhip64.so.7 then resolves to it by soname) -- the order `import torch; import bitnuc_amd` gives."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("BITNUC_NO_TORCH_HIP_PRELOAD"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load(path=None):
     """Load libbitnuc_hip.so (or the library at `path`) and type every exported entry point."""
     path = path or LIB_PATH
@@ -95,6 +125,7 @@ def load(path=None):
         raise RuntimeError(
             f"{path} is missing: build it with `python -m bitnuc_amd.build` "
             "(hipcc, gfx950). bitnuc_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

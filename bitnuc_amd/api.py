@@ -459,6 +459,52 @@ class Context:
         self._call_dev(self._lib.bitnuc_stream_probe_dev, int(mode), _dev_ptr(d_src), _dev_ptr(d_dst), int(nbytes))
 
 
+class BatchPlan:
+    """Layout plan of a ragged batch (bitnuc_batch_plan): built once from the device offsets table, used by every
+    encode / decode of that layout.  `build` may be called again for the next batch (memory is reused)."""
+
+    def __init__(self, ctx, d_offsets=None, count=0):
+        self._ctx, self._lib = ctx, ctx._lib
+        self._h = C.c_void_p()
+        err = L.BitnucErr()
+        if self._lib.bitnuc_batch_plan_create(ctx._h, C.byref(self._h), C.byref(err)) != L.OK:
+            self._h = C.c_void_p()
+            _raise(err)
+        self.total_words = 0
+        if d_offsets is not None:
+            self.build(d_offsets, count)
+
+    def build(self, d_offsets, count):
+        total = C.c_size_t(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_batch_plan_build_dev(self._ctx._h, self._h, _dev_ptr(d_offsets), int(count), C.byref(total), C.byref(err)) != L.OK:
+            _raise(err)
+        self.total_words = total.value
+        return total.value
+
+    @property
+    def word_offsets_ptr(self):
+        """Device address of the plan's word-offsets table (count + 1 u64 entries)."""
+        return self._lib.bitnuc_batch_plan_word_offsets_dev(self._h)
+
+    def encode_dev(self, d_seq, d_out):
+        err = L.BitnucErr()
+        if self._lib.bitnuc_encode_batch_plan_dev(self._ctx._h, self._h, _dev_ptr(d_seq), _dev_ptr(d_out), C.byref(err)) != L.OK:
+            _raise(err)
+
+    def decode_dev(self, d_words, d_out):
+        err = L.BitnucErr()
+        if self._lib.bitnuc_decode_batch_plan_dev(self._ctx._h, self._h, _dev_ptr(d_words), _dev_ptr(d_out), C.byref(err)) != L.OK:
+            _raise(err)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.bitnuc_batch_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
 class Comm:
     """One rank of an RCCL communicator bound to a Context (config 4's concatenation).
     One process per GPU: rank 0 makes `Comm.unique_id()`, shares the 128 bytes, every rank

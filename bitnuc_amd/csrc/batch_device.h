@@ -22,7 +22,6 @@ namespace bitnuc_dev {
 
 constexpr int kBatchTile = 64;                      // words per WAVE: every wave works alone on its own tile, so the
                                                     // kernels have no workgroup barrier at all
-constexpr int kBatchWin = 128;                      // offsets window per wave (>= kBatchTile + 1, + slack for empty sequences)
 constexpr int kBatchStage = kBatchTile * 32 + 128;  // 2 KiB span + alignment / read-ahead slack, per wave
 constexpr int kBatchWaves = kBlock / 64;            // waves (= tiles in flight) per workgroup
 
@@ -90,11 +89,6 @@ __device__ __forceinline__ ReadPos fixed_read_pos(unsigned long long wb, unsigne
     return ReadPos{r0 + q, t - q * wpr};
 }
 
-struct WordLoc {
-    unsigned long long base; // byte offset of the word's first base in the sequence buffer
-    unsigned nb;             // bases in this word (1..32)
-};
-
 // rec[b] = {sequence that owns word 64*b, byte offset of that word's first base}: one thread
 // per wave tile, so the ~log2(count) dependent loads of the search are paid once, in
 // parallel, instead of by every wave -- and the main kernels can start fetching a tile's
@@ -141,83 +135,6 @@ block_owner_kernel(const unsigned long long *__restrict__ offsets, const unsigne
     }
     const unsigned long long base0 = offsets[lo] + ((wb - word_offsets[lo]) << 5);
     recs[b] = TileRec{lo, base0, offsets[lo + 1] - base0};
-}
-
-// Resolve this lane's word from the wave's LDS window (already holding `filled` = 64 entries
-// starting at sequence sb).  If the tile's last word is not covered yet the window grows 64
-// sequences at a time (150-base reads need 14 entries; 1-word sequences need 65).
-// Wave-private: only wave-level fences, no workgroup barrier.
-__device__ __forceinline__ WordLoc locate_word(const unsigned long long *__restrict__ offsets,
-                                               const unsigned long long *__restrict__ word_offsets,
-                                               unsigned long long count, unsigned long long sb, unsigned long long wb,
-                                               unsigned long long w, bool active, unsigned long long *win_wo,
-                                               unsigned long long *win_so, unsigned hi0) {
-    const unsigned lane = threadIdx.x & 63;
-    unsigned filled = 64;
-    while (filled <= (unsigned)kBatchWin && win_wo[filled - 1] <= wb + kBatchTile - 1) { // wave-uniform, rare
-        const unsigned i = filled + lane;
-        if (i <= (unsigned)kBatchWin) {
-            const unsigned long long s = sb + i < count ? sb + i : count;
-            win_wo[i] = word_offsets[s];
-            win_so[i] = offsets[s];
-        }
-        filled = filled + 64 <= (unsigned)kBatchWin + 1 ? filled + 64 : kBatchWin + 1;
-        wave_lds_fence();
-    }
-    WordLoc loc{0, 0};
-    if (!active) return loc;
-    // upper_bound in the window.  Entry 0 (the tile's owner) starts at or before every word of the
-    // tile, and the caller knows the first entry that starts past the tile (hi0, from one ballot over
-    // the entries while they were still in registers): the search runs over the handful of
-    // sequences that really start inside the tile, not over all 64 entries.
-    unsigned lo = 1, hi = filled == 64 ? hi0 : filled;
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (win_wo[mid] <= w) lo = mid + 1; else hi = mid;
-    }
-    unsigned long long w0, s0, s1;
-    if (lo < filled) {
-        w0 = win_wo[lo - 1]; s0 = win_so[lo - 1]; s1 = win_so[lo];
-    } else { // more sequences start inside this tile than the window holds
-        const unsigned long long s = owner_of_word(word_offsets, count, w);
-        w0 = word_offsets[s]; s0 = offsets[s]; s1 = offsets[s + 1];
-    }
-    loc.base = s0 + ((w - w0) << 5);
-    const unsigned long long left = s1 - loc.base;
-    loc.nb = left < 32 ? (unsigned)left : 32u;
-    return loc;
-}
-
-// index of the first of the wave's 64 window entries that starts past the tile's last word (64 if none)
-__device__ __forceinline__ unsigned first_entry_past(unsigned long long entry, unsigned long long last_word) {
-    const unsigned long long m = __ballot(entry > last_word);
-    return m ? (unsigned)__builtin_ctzll(m) : 64u;
-}
-
-// Tile-relative lookup for the common case that the wave's 64 window entries reach past the tile (hi0 < 64).
-// Entry i is kept as two 32-bit numbers relative to the tile: its first word minus the tile's first word, and its
-// first byte minus base0 (the byte of the tile's first base); the owner (entry 0) starts at or before the tile and
-// is entered as (0, 0).  The search, the byte offset and the length are then 32-bit arithmetic on 32-bit LDS
-// entries.  Returns the word's first byte relative to base0 and its base count.
-struct RelLoc { unsigned base, nb; };
-__device__ __forceinline__ RelLoc locate_word_rel(unsigned long long wo_r, unsigned long long so_r, unsigned long long wb,
-                                                  unsigned long long base0, unsigned hi0, uint32_t *win /* 128 entries */) {
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned long long dw = wo_r - wb, ds = so_r - base0; // entries >= 1 start after the tile's first word / base
-    win[lane] = lane == 0 ? 0u : (dw < 0xFFFFull ? (unsigned)dw : 0xFFFFu);
-    win[64 + lane] = lane == 0 ? 0u : (ds < 0x7FFFFFFFull ? (unsigned)ds : 0x7FFFFFFFu);
-    wave_lds_fence();
-    unsigned lo = 1, hi = hi0; // upper_bound over the entries that start inside the tile
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (win[mid] <= lane) lo = mid + 1; else hi = mid;
-    }
-    const unsigned w0 = win[lo - 1], s0 = win[64 + lo - 1], s1 = win[64 + lo];
-    RelLoc loc;
-    loc.base = s0 + ((lane - w0) << 5);
-    const unsigned left = s1 - loc.base;
-    loc.nb = left < 32 ? left : 32u;
-    return loc;
 }
 
 // ---------------------------------------------------------------------------------
@@ -405,176 +322,9 @@ encode_word_from_stream(const uint8_t *__restrict__ seq, unsigned long long seq_
     return stream_cut(strip, (unsigned)(reinterpret_cast<uintptr_t>(seq) + base - lo16), nb);
 }
 
-struct BatchLds { // one per wave and tile in flight
-    unsigned long long win_wo[kBatchWin + 1], win_so[kBatchWin + 1];
+struct BatchLds { // one per wave: the staged byte span of a tile (fixed-length kernels)
     __attribute__((aligned(16))) uint8_t stage[kBatchStage];
 };
-constexpr int kBatchInFlight = 1; // tiles whose loads a wave issues before it computes on the first
-
-// A wave handles kBatchInFlight consecutive tiles per trip in three phases, so that the
-// dependent global loads of a tile (record -> offsets window / bytes) overlap with the other
-// tile's instead of adding up: (A) tile records, (B) window entries + the tile's bytes
-// (always the 2 KiB after its first base, clipped at the buffer end: known from the record
-// alone), (C) LDS lookup, funnel, encode, store.
-template <bool STREAM>
-__global__ void __launch_bounds__(kBlock)
-encode_batch_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets,
-                    unsigned long long count, unsigned long long total_words, const TileRec *__restrict__ recs,
-                    unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
-    constexpr int U = kBatchInFlight;
-    __shared__ BatchLds lds[kBatchWaves][U];
-    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
-    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
-    const unsigned long long seq_end = offsets[count]; // end of the sequence buffer: bounds the 2 KiB tile fetch
-    const unsigned long long seq_begin = offsets[0];   // bytes before the batch are never examined
-    for (unsigned long long t0 = ((unsigned long long)blockIdx.x * kBatchWaves + wave) * U; t0 < ntiles;
-         t0 += (unsigned long long)gridDim.x * kBatchWaves * U) {
-        // (A) records
-        TileRec rec[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) rec[u] = recs[t0 + u < ntiles ? t0 + u : ntiles - 1];
-        // (B) window entries and bytes, all in flight together
-        unsigned long long wo_r[U], so_r[U];
-        u32x4 st[U][3];
-        uintptr_t lo16[U];
-        unsigned nchunk[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned long long s = rec[u].owner + lane < count ? rec[u].owner + lane : count;
-            wo_r[u] = word_offsets[s];
-            so_r[u] = offsets[s];
-            const unsigned long long hi_off = rec[u].base0 + kBatchTile * 32 + 32 < seq_end ? rec[u].base0 + kBatchTile * 32 + 32 : seq_end;
-            const uintptr_t lo = reinterpret_cast<uintptr_t>(seq) + rec[u].base0, hi = reinterpret_cast<uintptr_t>(seq) + hi_off;
-            lo16[u] = lo & ~(uintptr_t)15;
-            nchunk[u] = hi > lo16[u] ? (unsigned)((hi - lo16[u] + 15) >> 4) : 0; // <= 129
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const unsigned c = lane + 64 * j;
-                st[u][j] = c < nchunk[u] ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16[u] + 16 * (uintptr_t)c)) : u32x4{0, 0, 0, 0};
-            }
-        }
-        // (C) per tile
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (t0 + u >= ntiles) break; // wave-uniform
-            BatchLds &my = lds[wave][u];
-            const unsigned long long wb = (t0 + u) * kBatchTile, w = wb + lane;
-            const bool active = w < total_words;
-            if (rec[u].avail >= kBatchTile * 32) {
-                // fast tile (wave-uniform): all 64 words are full and inside one sequence, so the
-                // tile is a plain 2 KiB bulk encode: the bytes already sit in st[u][0..1] as 128
-                // coalesced 16-base groups (group g = chunk g when base0 is 16-byte aligned)
-                if (((reinterpret_cast<uintptr_t>(seq) + rec[u].base0) & 15) == 0) {
-                    uint32_t bad = 0;
-                    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + wb);
-                    const uint32_t c0 = enc16(st[u][0], bad), c1 = enc16(st[u][1], bad);
-                    __builtin_nontemporal_store(c0, o32 + lane);
-                    __builtin_nontemporal_store(c1, o32 + 64 + lane);
-                    if (__builtin_expect(residue_is_bad(bad), 0)) {
-                        rescan_bytes(seq, rec[u].base0 + 16 * lane, 16, slot);
-                        rescan_bytes(seq, rec[u].base0 + 16 * (lane + 64), 16, slot);
-                    }
-                    continue;
-                }
-            }
-            if constexpr (STREAM) {
-                // The sequences are back to back, so the tile is a bulk encode whose 2-bit stream is cut at the word
-                // starts (stream_fill / stream_cut).  The lookup runs first: it gives the exact end of the tile's last
-                // word, so only the chunks that hold the tile's bases are encoded (two rounds of enc16, not three).
-                uint32_t *strip = reinterpret_cast<uint32_t *>(my.stage);
-                const unsigned hi0 = first_entry_past(wo_r[u], wb + kBatchTile - 1);
-                wave_lds_fence(); // previous trip's LDS readers are done
-                // the first 2 KiB of chunks are needed by (almost) every tile: encode them while the lookup is in flight
-                const unsigned n01 = nchunk[u] < 128 ? nchunk[u] : 128u;
-                stream_fill(st[u], n01, lo16[u], seq, seq_end, strip, slot, seq_begin);
-                unsigned off, nb;
-                unsigned long long base;
-                const unsigned lastl = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
-                if (hi0 < 64) {
-                    const RelLoc rl = locate_word_rel(wo_r[u], so_r[u], wb, rec[u].base0, hi0, reinterpret_cast<uint32_t *>(my.win_wo));
-                    nb = rl.nb;
-                    base = rec[u].base0 + rl.base;
-                } else {
-                    my.win_wo[lane] = wo_r[u];
-                    my.win_so[lane] = so_r[u];
-                    wave_lds_fence();
-                    const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, wb + (lane < lastl ? lane : lastl), true,
-                                                    my.win_wo, my.win_so, hi0);
-                    nb = loc.nb;
-                    base = loc.base;
-                }
-                off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + base - lo16[u]);
-                const unsigned long long span_hi = read_lane_u64(base + nb, lastl);
-                const unsigned need = (unsigned)((reinterpret_cast<uintptr_t>(seq) + span_hi - lo16[u] + 15) >> 4);
-                if (need > 128) { // wave-uniform and rare: the tile's last bases sit in the third round of chunks (<= 2 of them)
-                    const unsigned c = 128 + lane;
-                    if (c < need && c < nchunk[u]) {
-                        uint32_t bad = 0;
-                        strip[c] = enc16(st[u][2], bad);
-                        if (__builtin_expect(residue_is_bad(bad), 0)) {
-                            const uintptr_t g = lo16[u] + 16 * (uintptr_t)c, s0 = reinterpret_cast<uintptr_t>(seq), e0 = s0 + seq_end;
-                            const uintptr_t b = g + 16 < e0 ? g + 16 : e0;
-                            if (b > g) rescan_bytes(seq, (unsigned long long)(g - s0), (unsigned)(b - g), slot);
-                        }
-                    }
-                    if (lane < 4) strip[(need < nchunk[u] ? need : nchunk[u]) + lane] = 0; // the funnel may read 2 dwords past the last chunk
-                }
-                wave_lds_fence();
-                if (!active) continue;
-                const unsigned long long word = stream_cut(strip, off, nb);
-                __builtin_nontemporal_store(word, out + w);
-            } else {
-                wave_lds_fence(); // previous trip's LDS readers are done
-    #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const unsigned c = lane + 64 * j;
-                    if (c < nchunk[u]) *reinterpret_cast<u32x4 *>(my.stage + 16 * c) = st[u][j];
-                }
-                const unsigned hi0 = first_entry_past(wo_r[u], wb + kBatchTile - 1);
-                unsigned off, nb;
-                unsigned long long base; // absolute byte offset of the word's first base (error reporting only)
-                if (hi0 < 64) { // the window reaches past the tile (always, unless > 63 sequences start inside it)
-                    const RelLoc rl = locate_word_rel(wo_r[u], so_r[u], wb, rec[u].base0, hi0, reinterpret_cast<uint32_t *>(my.win_wo));
-                    off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + rec[u].base0 - lo16[u]) + rl.base;
-                    nb = rl.nb;
-                    base = rec[u].base0 + rl.base;
-                } else {
-                    my.win_wo[lane] = wo_r[u];
-                    my.win_so[lane] = so_r[u];
-                    wave_lds_fence();
-                    const WordLoc loc = locate_word(offsets, word_offsets, count, rec[u].owner, wb, w, active, my.win_wo, my.win_so, hi0);
-                    off = (unsigned)(reinterpret_cast<uintptr_t>(seq) + loc.base - lo16[u]);
-                    nb = loc.nb;
-                    base = loc.base;
-                }
-                if (!active) continue;
-                // The word's bytes start at any byte offset: read the 9 ALIGNED LDS dwords that cover 32
-                // bytes from there and funnel-shift (misaligned ds_read_b32 works on gfx950 but runs ~2x
-                // slower).  These kernels are VALU-issue bound (PMC), so there is no per-dword length
-                // logic: all 32 bytes are packed -- past the word's nb bases they are the next sequence's
-                // bytes or stage slack -- and the packed word is masked to 2*nb bits instead.  A residue
-                // from those extra bytes only sends the lane to rescan_bytes, which looks at its own nb.
-                const unsigned sh = off & 3;
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(my.stage + (off & ~3u));
-                uint32_t a[9];
-    #pragma unroll
-                for (int i = 0; i < 9; ++i) a[i] = src[i];
-                uint32_t bad = 0, wlo = 0, whi = 0;
-    #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const uint32_t r = enc4(__builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), bad);
-                    if (i < 4) wlo |= r << (8 * i); else whi |= r << (8 * (i - 4));
-                }
-                const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
-                wlo &= (uint32_t)keep;
-                whi &= (uint32_t)(keep >> 32);
-                __builtin_nontemporal_store(((unsigned long long)whi << 32) | wlo, out + w);
-                if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, base, nb, slot);
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------
 // fixed-length reads: `count` reads of `read_len` bases, read r at byte r*stride
 // ---------------------------------------------------------------------------------
@@ -756,22 +506,42 @@ __device__ __forceinline__ void strip_or_word(uint32_t *strip, unsigned bit, uns
     atomicOr(dst + 1, (uint32_t)(t >> 32));
     atomicOr(dst + 2, sh ? (uint32_t)(v >> 32) >> (32 - sh) : 0u);
 }
-// strip dword c is the 16-byte chunk at lo16 + 16c: decode and store it; the run's first / last chunk (shared with
-// the neighbouring tiles) only as far as [lo, hi) reaches, through a 16-byte LDS slot and store_stage_chunk
+// strip dword c is the 16-byte chunk at lo16 + 16c: decode and store it.  The run's first / last chunk is shared with the
+// neighbouring tiles when lo / hi are not 16-byte aligned.  Those two edges are NOT written byte by byte (that cost ~30
+// memory instructions per tile for two lanes' worth of data): lane 0 stores the run's FIRST 16 bytes [lo, lo+16) and lane 1
+// its LAST 16 bytes [hi-16, hi) as one unaligned dwordx4 each, cut from the bit strip at an arbitrary 2-bit position (two
+// dword reads + v_alignbit).  They overlap this tile's own aligned chunks with identical bytes and never touch a
+// neighbour's.  Runs shorter than 16 bytes (the last tile of a small batch) take the byte-wise path.
 __device__ __forceinline__ void strip_drain(const uint32_t *strip, uint8_t (*edge)[16], uintptr_t lo16, uintptr_t lo, uintptr_t hi, unsigned lane) {
     const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4); // <= 130
+    const bool wide = hi - lo >= 16;                           // wave-uniform
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const unsigned c = lane + 64 * j;
         if (c >= nchunk) break;
-        const u32x4 d = dec16(strip[c]);
         const uintptr_t g = lo16 + 16 * (uintptr_t)c;
         if (g >= lo && g + 16 <= hi) {
-            __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
-        } else {
+            const u32x4 d = dec16(strip[c]);
+            // The run's first and last 128-byte cache lines are shared with the neighbouring tiles: their chunks are stored
+            // with the allocating policy, so that the two parts of a line meet in L2 and leave as one full line; every
+            // other chunk streams past the caches (nt).  In-process A/B, 150-base reads: -2 % (-3.5 % for 1000-base
+            // reads); giving the shared chunk to one wave (look-ahead into the next tile) or an XCD-contiguous tile
+            // order were both slower (profiles/r02_plan_decode_edges.txt).
+            if ((g >> 7) == (lo >> 7) || (g >> 7) == ((hi - 1) >> 7)) *reinterpret_cast<u32x4 *>(g) = d;
+            else __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
+        } else if (!wide) {
             uint8_t *e = edge[c ? 1 : 0];
-            *reinterpret_cast<u32x4 *>(e) = d;
+            *reinterpret_cast<u32x4 *>(e) = dec16(strip[c]);
             store_stage_chunk(e, g, lo, hi);
+        }
+    }
+    if (wide && lane < 2) {
+        const bool head = lane == 0;
+        if (head ? (lo & 15) != 0 : (hi & 15) != 0) {
+            const uintptr_t a = head ? lo : hi - 16;
+            const unsigned bit = 2u * (unsigned)(a - lo16);
+            const uint32_t w0 = strip[bit >> 5], w1 = strip[(bit >> 5) + 1];
+            *reinterpret_cast<u32x4_u *>(a) = dec16(__builtin_amdgcn_alignbit(w1, w0, bit & 31));
         }
     }
 }
@@ -805,71 +575,370 @@ decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned
     }
 }
 
-// ---------------------------------------------------------------------------------
-// batched decode: sequence i's bases go to out[offsets[i] .. offsets[i+1])
-// ---------------------------------------------------------------------------------
-// Wave-private, like encode_batch: the tile is the wave's 64 words (same records, same tile-relative lookup), the
-// output run is rebuilt as a 2-bit stream in the wave's bit strip (see decode_fixed_strip_kernel) and leaves as
-// aligned dwordx4 stores; no workgroup barrier.  (A 128-word workgroup tile with a byte scatter was the faster
-// form until the bit strip: profiles/r01_ab_decode_batch_wave_private.txt.)
+// =================================================================================
+// ragged batches, second formulation (round 2): O(1) word -> sequence lookup, stream-cut encode
+// =================================================================================
+// What the PMC counters said about the first formulation (profiles/r01_batch_pmc_sq*.txt): the waves sit in
+// s_waitcnt (68 %), the LDS array is busy 45 % (encode) / 71 % (decode) of the launch, and the bank-conflict counter
+// (in quad-cycles) equals the nine 8-way conflicting funnel reads of the byte stage (lane stride 32 B = 8 dwords).
+// So this form removes LDS work, not VALU work:
+//   * word -> sequence lookup without a search.  Lane i holds window entry i = sequence (owner + i): its first word
+//     and first byte relative to the tile (dw_i, ds_i).  The padding of the sequence before it,
+//     pad_{i-1} = 32 (dw_i - dw_{i-1}) - (ds_i - ds_{i-1})  (0..31: what the last word of sequence i-1 lacks),
+//     is ADDED into an LDS array at index dw_i (the tile word where sequence i starts; ds_add_u32, so empty
+//     sequences, which start at the same word and have pad 0, need no special case).  Lane l then reads pads[l] and
+//     pads[l+1]; an inclusive DPP prefix sum P(l) of pads[0..l] is the padding that precedes word l, hence
+//         first byte of word l = base0 + 32 l - P(l),      bases in word l = 32 - pads[l+1].
+//     One zeroing store, one add, one read2 and six DPP adds replace the window stores, a 4-7 step binary search
+//     (dependent LDS round trips) and three entry reads.
+//   * encode cuts the tile's 2-bit stream (stream_fill / stream_cut above): the staged data are the enc16 code words
+//     (a quarter of the bytes), and a lane's three funnel dwords sit 2 dwords from its neighbour's (2-way at worst)
+//     instead of nine reads at an 8-dword stride (8-way).
+// The window is 64 entries, a second round of 64 is fetched when more than 63 sequences start inside one tile
+// (sequences shorter than a word), and a per-lane global search covers what is left (runs of empty sequences).
+constexpr int kB2Strip = 136; // dwords of the code / bit strip: chunk 0..128 + funnel slack
+constexpr int kB2Pads = 68;   // pads[0..64] + slack
+
+struct Batch2Lds {
+    uint32_t strip[kB2Strip];
+    uint32_t pads[kB2Pads];
+    __attribute__((aligned(16))) uint8_t edge[2][16];
+};
+
+// lane i <- lane i-1 across the wave (gfx9 DPP wave_shr:1); lane 0 gets 0
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+}
+
+// inclusive prefix sum over the 64 lanes: row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast:15 into rows 1 and 3
+// and row_bcast:31 into rows 2 and 3 (six DPP adds, no LDS)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+    return v;
+}
+
+// Resolve word (wb + lane) of the tile: *base_rel = its first byte relative to rec.base0, *nb = its bases.
+// wo / so = this lane's window entry (first word / first byte of sequence owner + lane, clamped to `count`).
+// last_abs = the tile's last real word.  Wave-private; `pads` needs kB2Pads dwords.
+__device__ __forceinline__ void tile_lookup(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets,
+                                            unsigned long long count, const TileRec &rec, unsigned long long wo, unsigned long long so,
+                                            unsigned long long wb, unsigned long long last_abs, uint32_t *pads, unsigned &base_rel, unsigned &nb) {
+    const unsigned lane = threadIdx.x & 63;
+    uint32_t dw = (uint32_t)(wo - wb), ds = (uint32_t)(so - rec.base0); // exact mod 2^32; used only where the true values are small
+    bool reaches = __ballot(wo > last_abs) != 0ull;                     // some entry starts past the tile: the window covers it
+    wave_lds_fence(); // the previous trip's readers of pads are done
+    pads[lane] = 0u;
+    if (lane < (unsigned)(kB2Pads - 64)) pads[64 + lane] = 0u;
+    wave_lds_fence();
+    {
+        const uint32_t pad = 32u * (dw - lane_shr1(dw)) - (ds - lane_shr1(ds));
+        if (lane >= 1 && wo <= wb + 64) atomicAdd(&pads[dw], pad); // sequence `lane` starts at tile word dw (1..64)
+    }
+    if (!reaches) { // more than 63 sequences start inside the tile: entries 64..127 (wave-uniform, rare)
+        const uint32_t dw63 = (uint32_t)__builtin_amdgcn_readlane((int)dw, 63), ds63 = (uint32_t)__builtin_amdgcn_readlane((int)ds, 63);
+        const unsigned long long s2 = rec.owner + 64 + lane < count ? rec.owner + 64 + lane : count;
+        const unsigned long long wo2 = word_offsets[s2], so2 = offsets[s2];
+        const uint32_t dw2 = (uint32_t)(wo2 - wb), ds2 = (uint32_t)(so2 - rec.base0);
+        uint32_t pdw = lane_shr1(dw2), pds = lane_shr1(ds2);
+        if (lane == 0) { pdw = dw63; pds = ds63; }
+        const uint32_t pad = 32u * (dw2 - pdw) - (ds2 - pds);
+        if (wo2 <= wb + 64) atomicAdd(&pads[dw2], pad);
+        reaches = __ballot(wo2 > last_abs) != 0ull;
+    }
+    wave_lds_fence();
+    if (__builtin_expect(reaches, 1)) {
+        const uint32_t p0 = pads[lane], p1 = pads[lane + 1];
+        base_rel = 32u * lane - wave_inclusive_sum(p0);
+        nb = 32u - p1;
+        return;
+    }
+    // more sequence starts than two windows hold (runs of empty sequences): per-lane search in global memory
+    const unsigned long long w = wb + lane < last_abs ? wb + lane : last_abs;
+    const unsigned long long sidx = owner_of_word(word_offsets, count, w);
+    const unsigned long long b = offsets[sidx] + ((w - word_offsets[sidx]) << 5), left = offsets[sidx + 1] - b;
+    base_rel = (unsigned)(b - rec.base0);
+    nb = left < 32 ? (unsigned)left : 32u;
+}
+
+// residue of chunk c (16 bytes at lo16 + 16 c) flagged: latch the first invalid byte among those of the chunk that
+// lie inside the batch [seq_begin, seq_end)
+__device__ __forceinline__ void rescan_chunk(const uint8_t *__restrict__ seq, uintptr_t lo16, unsigned c, unsigned long long seq_begin,
+                                             unsigned long long seq_end, unsigned long long *__restrict__ slot) {
+    const uintptr_t s0 = reinterpret_cast<uintptr_t>(seq), g = lo16 + 16 * (uintptr_t)c;
+    const uintptr_t a = g > s0 + seq_begin ? g : s0 + seq_begin, b = g + 16 < s0 + seq_end ? g + 16 : s0 + seq_end;
+    if (b > a) rescan_bytes(seq, (unsigned long long)(a - s0), (unsigned)(b - a), slot);
+}
+
+// ABL != 0: timing-only ablations for tools/ab_batch_ablate.py (the output is WRONG): bit 0 = no window loads, bit 1 = no
+// pad scatter / scan (fixed fake positions), bit 2 = decode: no partial edge chunks, bit 3 = no tile-record load.
+template <int ABL>
 __global__ void __launch_bounds__(kBlock)
-decode_batch_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ word_offsets,
-                         const unsigned long long *__restrict__ offsets, unsigned long long count,
-                         unsigned long long total_words, const TileRec *__restrict__ recs, uint8_t *__restrict__ out) {
-    __shared__ uint32_t strips[kBatchWaves][kStripDwords];
-    __shared__ unsigned long long wins[kBatchWaves][2 * (kBatchWin + 1)];
-    __shared__ __attribute__((aligned(16))) uint8_t edge[kBatchWaves][2][16];
-    const unsigned wv = wave_in_block(), lane = threadIdx.x & 63;
-    uint32_t *strip = strips[wv];
-    unsigned long long *win_wo = wins[wv], *win_so = wins[wv] + kBatchWin + 1;
+encode_batch2_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets,
+                     unsigned long long count, unsigned long long total_words, const TileRec *__restrict__ recs,
+                     unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
+    __shared__ Batch2Lds lds[kBatchWaves];
+    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
+    Batch2Lds &my = lds[wave];
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
-    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wv; tile < ntiles;
+    const unsigned long long seq_end = offsets[count], seq_begin = offsets[0];
+    const uintptr_t sp = reinterpret_cast<uintptr_t>(seq);
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave; tile < ntiles;
+         tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        TileRec rec;
+        if constexpr (ABL & 8) { rec.owner = tile * 12; rec.base0 = tile * 1900 + offsets[0]; rec.avail = 150; }
+        else rec = recs[tile];
+        const unsigned long long wb = tile * kBatchTile;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        // the tile's bytes are the <= 2 KiB after its first base: 128 aligned chunks from lo16, plus chunk 128 when the
+        // first base is not 16-byte aligned; clipped at the end of the buffer.  Known from the record alone.
+        const uintptr_t lo = sp + rec.base0, lo16 = lo & ~(uintptr_t)15;
+        const uintptr_t hi = rec.base0 + kBatchTile * 32 < seq_end ? lo + kBatchTile * 32 : sp + seq_end;
+        const unsigned nchunk = hi > lo16 ? (unsigned)((hi - lo16 + 15) >> 4) : 0u; // <= 129
+        const unsigned long long s = rec.owner + lane < count ? rec.owner + lane : count;
+        // Only the entries the tile can need are fetched: the owner, the sequences that start inside the tile, and the first
+        // one past it -- the next tile's owner is the last sequence that starts at or before word wb + 64, so that is
+        // (next owner - owner) + 2 entries (14 for 150-base reads: 2 cache lines per table instead of 8).  Lanes beyond
+        // that hold an entry "past everything".
+        const unsigned long long span = (tile + 1 < ntiles ? recs[tile + 1].owner : count) - rec.owner + 2;
+        const unsigned need = span < 64 ? (unsigned)span : 64u;
+        unsigned long long wo = ~0ull, so = 0;
+        if constexpr (ABL & 1) { wo = wb + 5ull * lane; so = rec.base0 + 150ull * lane; }
+        else if (lane < need) { wo = word_offsets[s]; so = offsets[s]; }
+        const u32x4 zero4 = {0u, 0u, 0u, 0u};
+        const u32x4 v0 = lane < nchunk ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)lane)) : zero4;
+        const u32x4 v1 = lane + 64 < nchunk ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)(lane + 64))) : zero4;
+        u32x4 v2 = zero4;
+        if (nchunk > 128 && lane == 0) v2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 2048));
+        if (rec.avail >= kBatchTile * 32 && (lo & 15) == 0) {
+            // fast tile (wave-uniform): 64 full words inside one sequence = a plain 2 KiB bulk encode
+            uint32_t bad = 0;
+            uint32_t *o32 = reinterpret_cast<uint32_t *>(out + wb);
+            const uint32_t c0 = enc16(v0, bad), c1 = enc16(v1, bad);
+            __builtin_nontemporal_store(c0, o32 + lane);
+            __builtin_nontemporal_store(c1, o32 + 64 + lane);
+            if (__builtin_expect(residue_is_bad(bad), 0)) {
+                rescan_bytes(seq, rec.base0 + 16 * lane, 16, slot);
+                rescan_bytes(seq, rec.base0 + 16 * (lane + 64), 16, slot);
+            }
+            continue;
+        }
+        // code words of the chunks -> strip (chunks past the buffer end and the funnel's slack are zero)
+        uint32_t b0 = 0, b1 = 0, b2 = 0;
+        const uint32_t c0 = enc16(v0, b0), c1 = enc16(v1, b1), c2 = enc16(v2, b2);
+        wave_lds_fence(); // the previous trip's strip readers are done
+        my.strip[lane] = lane < nchunk ? c0 : 0u;
+        my.strip[64 + lane] = lane + 64 < nchunk ? c1 : 0u;
+        if (lane < (unsigned)(kB2Strip - 128)) my.strip[128 + lane] = (lane == 0 && nchunk > 128) ? c2 : 0u;
+        if (__builtin_expect(residue_is_bad(b0) && lane < nchunk, 0)) rescan_chunk(seq, lo16, lane, seq_begin, seq_end, slot);
+        if (__builtin_expect(residue_is_bad(b1) && lane + 64 < nchunk, 0)) rescan_chunk(seq, lo16, lane + 64, seq_begin, seq_end, slot);
+        if (__builtin_expect(residue_is_bad(b2) && lane == 0 && nchunk > 128, 0)) rescan_chunk(seq, lo16, 128, seq_begin, seq_end, slot);
+        unsigned base_rel, nb;
+        if constexpr (ABL & 2) { base_rel = 30u * lane + (unsigned)(wo & 1); nb = 30u; wave_lds_fence(); }
+        else tile_lookup(offsets, word_offsets, count, rec, wo, so, wb, wb + last, my.pads, base_rel, nb); // its fences order the strip stores too
+        if (lane <= last) {
+            const unsigned long long word = stream_cut(my.strip, (unsigned)(lo - lo16) + base_rel, nb);
+            __builtin_nontemporal_store(word, out + wb + lane);
+        }
+    }
+}
+
+template <int ABL>
+__global__ void __launch_bounds__(kBlock)
+decode_batch2_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ word_offsets,
+                     const unsigned long long *__restrict__ offsets, unsigned long long count,
+                     unsigned long long total_words, const TileRec *__restrict__ recs, uint8_t *__restrict__ out) {
+    __shared__ Batch2Lds lds[kBatchWaves];
+    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
+    Batch2Lds &my = lds[wave];
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    const uintptr_t op = reinterpret_cast<uintptr_t>(out);
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave; tile < ntiles;
          tile += (unsigned long long)gridDim.x * kBatchWaves) {
         const unsigned long long wb = tile * kBatchTile;
         const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
-        const bool active = lane <= last;
         const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last)); // independent of the lookup
-        const TileRec rec = recs[tile];
-        if (rec.avail >= kBatchTile * 32 && ((reinterpret_cast<uintptr_t>(out) + rec.base0) & 15) == 0) {
+        TileRec rec;
+        if constexpr (ABL & 8) { rec.owner = tile * 12; rec.base0 = tile * 1900 + offsets[0]; rec.avail = 150; }
+        else rec = recs[tile];
+        const uintptr_t lo = op + rec.base0, lo16 = lo & ~(uintptr_t)15;
+        if (rec.avail >= kBatchTile * 32 && (lo & 15) == 0) {
             // fast tile (wave-uniform): 64 full words inside one sequence; the words cross the strip once so that
             // lane l owns 16-base groups l and l+64
             wave_lds_fence();
-            reinterpret_cast<unsigned long long *>(strip)[lane] = word;
+            reinterpret_cast<unsigned long long *>(my.strip)[lane] = word;
             wave_lds_fence();
-            const uint32_t h0 = strip[lane], h1 = strip[64 + lane];
+            const uint32_t h0 = my.strip[lane], h1 = my.strip[64 + lane];
             uint8_t *dst = out + rec.base0;
             store_group<true, true>(dst + 16 * lane, dec16(h0));
             store_group<true, true>(dst + 16 * (lane + 64), dec16(h1));
             continue;
         }
-        const unsigned long long si = rec.owner + lane < count ? rec.owner + lane : count;
-        const unsigned long long wo_r = word_offsets[si], so_r = offsets[si];
-        const unsigned hi0 = first_entry_past(wo_r, wb + kBatchTile - 1);
-        wave_lds_fence(); // previous trip's readers are done
-        strip_zero(strip, lane);
-        unsigned long long base; // absolute byte offset of the lane's word
-        unsigned nb;
-        const unsigned long long wq = wb + (lane < last ? lane : last); // inactive lanes mirror the last word
-        if (hi0 < 64) {
-            const RelLoc rl = locate_word_rel(wo_r, so_r, wb, rec.base0, hi0, reinterpret_cast<uint32_t *>(win_wo));
-            // locate_word_rel resolves word wb + lane; an inactive lane's result is never used
-            base = rec.base0 + rl.base;
-            nb = rl.nb;
-        } else {
-            win_wo[lane] = wo_r;
-            win_so[lane] = so_r;
-            wave_lds_fence();
-            const WordLoc loc = locate_word(offsets, word_offsets, count, rec.owner, wb, wq, true, win_wo, win_so, hi0);
-            base = loc.base;
-            nb = loc.nb;
-        }
-        const unsigned long long span_hi = read_lane_u64(base + nb, last);
-        const uintptr_t lo = reinterpret_cast<uintptr_t>(out) + rec.base0, hi = reinterpret_cast<uintptr_t>(out) + span_hi;
-        const uintptr_t lo16 = lo & ~(uintptr_t)15;
-        wave_lds_fence(); // zeroing (and the lookup's LDS traffic) before the ORs
-        if (active) strip_or_word(strip, 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16), word, nb);
+        const unsigned long long s = rec.owner + lane < count ? rec.owner + lane : count;
+        const unsigned long long span = (tile + 1 < ntiles ? recs[tile + 1].owner : count) - rec.owner + 2; // see encode_batch2_kernel
+        const unsigned need = span < 64 ? (unsigned)span : 64u;
+        unsigned long long wo = ~0ull, so = 0;
+        if constexpr (ABL & 1) { wo = wb + 5ull * lane; so = rec.base0 + 150ull * lane; }
+        else if (lane < need) { wo = word_offsets[s]; so = offsets[s]; }
+        wave_lds_fence(); // the previous trip's strip readers are done
+        strip_zero(my.strip, lane);
+        unsigned base_rel, nb;
+        if constexpr (ABL & 2) { base_rel = 30u * lane + (unsigned)(wo & 1); nb = 30u; wave_lds_fence(); }
+        else tile_lookup(offsets, word_offsets, count, rec, wo, so, wb, wb + last, my.pads, base_rel, nb); // fences: zeroing before the ORs
+        const unsigned end_rel = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)last);
+        uintptr_t hi = lo + end_rel;
+        uintptr_t lo_w = lo;
+        if constexpr (ABL & 4) { lo_w = (lo + 15) & ~(uintptr_t)15; hi &= ~(uintptr_t)15; }
+        if (lane <= last) strip_or_word(my.strip, 2u * ((unsigned)(lo - lo16) + base_rel), word, nb);
         wave_lds_fence();
-        strip_drain(strip, edge[wv], lo16, lo, hi, lane);
+        strip_drain(my.strip, my.edge, lo16, lo_w, hi, lane);
+    }
+}
+
+
+// =================================================================================
+// ragged batches with a layout PLAN (bitnuc_batch_plan): the shipped fast path
+// =================================================================================
+// What the ablations of the table-driven kernels showed (tools/ab_batch_ablate.py, profiles/r02_batch_ablation.txt): with
+// the window loads and the tile-record pre-kernel taken out, the ragged kernels run at the speed of the fixed-length
+// ones.  Both are properties of the LAYOUT, not of the data, and a layout is used at least twice (encode, later decode)
+// and often many times.  The plan therefore holds, per layout:
+//   tile_base[t]  byte offset of word 64 t (one u64 per wave tile), and
+//   P[w]          one byte per word: the padding of the sequence that ENDS at word w-1 (0..31; 0 when word w does
+//                 not start a sequence) -- written by one streaming pass over the two offset tables (plan_emit_kernel).
+// A lane's lookup is then ONE byte load, issued together with the tile's data, and a DPP prefix sum:
+//   n  = P[wb + lane + 1]          what word (wb + lane) lacks to 32 bases,
+//   nb = 32 - n,    first byte = tile_base + 32 lane - (sum of n over the lanes before it).
+// No window, no search, no LDS for the lookup, no dependent global load, no per-call pre-kernel.
+__global__ void __launch_bounds__(kBlock)
+plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets, unsigned long long count,
+                 uint8_t *__restrict__ P /* zeroed, total_words + 1 */, unsigned long long *__restrict__ tile_base) {
+    const unsigned lane = threadIdx.x & 63;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < count; base += (unsigned long long)gridDim.x * kBlock) { // block-uniform trip count
+        const unsigned long long i = base + threadIdx.x;
+        const bool valid = i < count;
+        const unsigned long long a = valid ? word_offsets[i] : 0, b = valid ? word_offsets[i + 1] : 0;
+        const unsigned long long o = valid ? offsets[i] : 0, e = valid ? offsets[i + 1] : 0;
+        const bool has_words = b > a;
+        if (has_words) P[b] = (uint8_t)(32ull * (b - a) - (e - o)); // what this sequence's last word lacks; seen by the word after it
+        // tile boundaries 64 t inside [a, b): this sequence owns the first word of tile t
+        const unsigned long long t0 = (a + 63) >> 6, t1 = has_words ? (b + 63) >> 6 : t0;
+        const bool is_long = t1 - t0 > 8;
+        if (!is_long)
+            for (unsigned long long t = t0; t < t1; ++t) tile_base[t] = o + (((t << 6) - a) << 5);
+        unsigned long long m = __ballot(is_long); // long sequences: the whole wave writes their tile records
+        while (m) {
+            const unsigned l = (unsigned)__builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned long long A = read_lane_u64(a, l), O = read_lane_u64(o, l), T0 = read_lane_u64(t0, l), T1 = read_lane_u64(t1, l);
+            for (unsigned long long t = T0 + lane; t < T1; t += 64) tile_base[t] = O + (((t << 6) - A) << 5);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
+                         unsigned long long total_words, unsigned long long seq_begin, unsigned long long seq_end,
+                         unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
+    __shared__ uint32_t strips[kBatchWaves][kB2Strip];
+    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
+    uint32_t *strip = strips[wave];
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    const uintptr_t sp = reinterpret_cast<uintptr_t>(seq);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave; tile < ntiles;
+         tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        const unsigned long long base0 = tile_base[tile];
+        const unsigned long long wb = tile * kBatchTile;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        const uintptr_t lo = sp + base0, lo16 = lo & ~(uintptr_t)15;
+        const uintptr_t hi = base0 + kBatchTile * 32 < seq_end ? lo + kBatchTile * 32 : sp + seq_end;
+        const unsigned nchunk = hi > lo16 ? (unsigned)((hi - lo16 + 15) >> 4) : 0u; // <= 129
+        const uint32_t n = lane <= last ? (uint32_t)P[wb + lane + 1] : 0u;          // the whole lookup: one byte
+        const u32x4 v0 = lane < nchunk ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)lane)) : zero4;
+        const u32x4 v1 = lane + 64 < nchunk ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)(lane + 64))) : zero4;
+        u32x4 v2 = zero4;
+        if (nchunk > 128 && lane == 0) v2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 2048));
+        if (__ballot(n != 0u) == 0ull && last == 63u && (lo & 15) == 0) {
+            // fast tile (wave-uniform): 64 full words, first base 16-byte aligned = a plain 2 KiB bulk encode
+            uint32_t bad = 0;
+            uint32_t *o32 = reinterpret_cast<uint32_t *>(out + wb);
+            const uint32_t c0 = enc16(v0, bad), c1 = enc16(v1, bad);
+            __builtin_nontemporal_store(c0, o32 + lane);
+            __builtin_nontemporal_store(c1, o32 + 64 + lane);
+            if (__builtin_expect(residue_is_bad(bad), 0)) {
+                rescan_bytes(seq, base0 + 16 * lane, 16, slot);
+                rescan_bytes(seq, base0 + 16 * (lane + 64), 16, slot);
+            }
+            continue;
+        }
+        uint32_t b0 = 0, b1 = 0, b2 = 0;
+        const uint32_t c0 = enc16(v0, b0), c1 = enc16(v1, b1), c2 = enc16(v2, b2);
+        wave_lds_fence(); // the previous trip's strip readers are done
+        strip[lane] = lane < nchunk ? c0 : 0u;
+        strip[64 + lane] = lane + 64 < nchunk ? c1 : 0u;
+        if (lane < (unsigned)(kB2Strip - 128)) strip[128 + lane] = (lane == 0 && nchunk > 128) ? c2 : 0u;
+        if (__builtin_expect(residue_is_bad(b0) && lane < nchunk, 0)) rescan_chunk(seq, lo16, lane, seq_begin, seq_end, slot);
+        if (__builtin_expect(residue_is_bad(b1) && lane + 64 < nchunk, 0)) rescan_chunk(seq, lo16, lane + 64, seq_begin, seq_end, slot);
+        if (__builtin_expect(residue_is_bad(b2) && lane == 0 && nchunk > 128, 0)) rescan_chunk(seq, lo16, 128, seq_begin, seq_end, slot);
+        const unsigned base_rel = 32u * lane - (wave_inclusive_sum(n) - n), nb = 32u - n;
+        wave_lds_fence();
+        if (lane <= last) {
+            const unsigned long long word = stream_cut(strip, (unsigned)(lo - lo16) + base_rel, nb);
+            __builtin_nontemporal_store(word, out + wb + lane);
+        }
+    }
+}
+
+// ABL: timing-only ablations (wrong output): 1 = plain stores instead of the three ds_or, 2 = no strip zeroing, 4 = no edge stores
+template <int ABL>
+__global__ void __launch_bounds__(kBlock)
+decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
+                         unsigned long long total_words, uint8_t *__restrict__ out) {
+    __shared__ uint32_t strips[kBatchWaves][kB2Strip];
+    __shared__ __attribute__((aligned(16))) uint8_t edge[kBatchWaves][2][16];
+    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
+    uint32_t *strip = strips[wave];
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    const uintptr_t op = reinterpret_cast<uintptr_t>(out);
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave; tile < ntiles;
+         tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        const unsigned long long wb = tile * kBatchTile;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last));
+        const uint32_t n = lane <= last ? (uint32_t)P[wb + lane + 1] : 0u;
+        const unsigned long long base0 = tile_base[tile];
+        const uintptr_t lo = op + base0, lo16 = lo & ~(uintptr_t)15;
+        if (__ballot(n != 0u) == 0ull && last == 63u && (lo & 15) == 0) {
+            // fast tile (wave-uniform): the words cross the strip once so that lane l owns 16-base groups l and l+64
+            wave_lds_fence();
+            reinterpret_cast<unsigned long long *>(strip)[lane] = word;
+            wave_lds_fence();
+            const uint32_t h0 = strip[lane], h1 = strip[64 + lane];
+            uint8_t *dst = out + base0;
+            store_group<true, true>(dst + 16 * lane, dec16(h0));
+            store_group<true, true>(dst + 16 * (lane + 64), dec16(h1));
+            continue;
+        }
+        wave_lds_fence(); // the previous trip's strip readers are done
+        if constexpr (!(ABL & 2)) strip_zero(strip, lane);
+        const uint32_t incl = wave_inclusive_sum(n);
+        const unsigned base_rel = 32u * lane - (incl - n), nb = 32u - n;
+        const unsigned end_rel = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)last);
+        uintptr_t hi = lo + end_rel, lo_w = lo;
+        if constexpr (ABL & 4) { lo_w = (lo + 15) & ~(uintptr_t)15; hi &= ~(uintptr_t)15; }
+        wave_lds_fence();
+        if constexpr (ABL & 1) {
+            if (lane <= last) { uint32_t *dst = strip + ((2u * ((unsigned)(lo - lo16) + base_rel)) >> 5); dst[0] = (uint32_t)word; dst[1] = (uint32_t)(word >> 32); dst[2] = nb; }
+        } else {
+            if (lane <= last) strip_or_word(strip, 2u * ((unsigned)(lo - lo16) + base_rel), word, nb);
+        }
+        wave_lds_fence();
+        if (hi > lo_w) strip_drain(strip, edge[wave], lo16, lo_w, hi, lane);
     }
 }
 

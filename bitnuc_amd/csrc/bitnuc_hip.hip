@@ -68,7 +68,9 @@ struct bitnuc_ctx {
     int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
     int fixed_dec_strip = 1;               // decode_fixed (back-to-back reads): 1 = rebuild the tile's 2-bit stream in LDS, decode aligned chunks
     int owner_est = 3;                     // block_owner_kernel's first guess: 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, 3 = 2 or 0 by average sequence length
-    int batch_stream = 0;                  // encode_batch: 1 = cut the tile's 2-bit stream, 0 = funnel raw bytes per word
+    int batch_host_plan = 1;               // host-pointer ragged-batch calls build a layout plan (bitnuc_batch_plan) and use the plan kernels
+    bitnuc_batch_plan *host_plan = nullptr; // ... kept by the context
+    int batch_abl = 0;                     // timing-only ablation mask of the second formulation (tools/ab_batch_ablate.py); 0 in normal use
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
@@ -658,6 +660,7 @@ void bitnuc_ctx_destroy(bitnuc_ctx *c) {
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->d_tickets) (void)hipFree(c->d_tickets);
     pipe_destroy(c->pipe);
+    bitnuc_batch_plan_destroy(c->host_plan);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -712,7 +715,8 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "fixed_stream")) { prev = c->fixed_stream; if (value == 0 || value == 1) c->fixed_stream = value; }
     else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value == 0 || value == 1) c->fixed_dec_strip = value; }
     else if (!strcmp(key, "owner_est")) { prev = c->owner_est; if (value >= 0 && value <= 3) c->owner_est = value; }
-    else if (!strcmp(key, "batch_stream")) { prev = c->batch_stream; if (value == 0 || value == 1) c->batch_stream = value; }
+    else if (!strcmp(key, "batch_host_plan")) { prev = c->batch_host_plan; if (value == 0 || value == 1) c->batch_host_plan = value; }
+    else if (!strcmp(key, "batch_abl")) { prev = c->batch_abl; if (value >= 0 && value <= 15) c->batch_abl = value; }
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
     else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
@@ -1170,20 +1174,20 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t 
     if (count == 0 || total_words == 0) return BITNUC_OK;
     if (!d_seq || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
+    const unsigned long long *po = reinterpret_cast<const unsigned long long *>(d_offsets), *pw = reinterpret_cast<const unsigned long long *>(d_word_offsets);
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
     const TileRec *recs;
     if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
     unsigned long long *slot;
     if (int st = take_slot(c, 0, &slot, err)) return st;
-    const size_t per_block = (size_t)kBatchTile * kBatchWaves * kBatchInFlight;
+    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
     const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
-    if (c->batch_stream)
-        encode_batch_kernel<true><<<grid, kBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
-                                                              reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, recs,
-                                                              reinterpret_cast<unsigned long long *>(d_out), slot);
-    else
-        encode_batch_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, reinterpret_cast<const unsigned long long *>(d_offsets),
-                                                               reinterpret_cast<const unsigned long long *>(d_word_offsets), count, total_words, recs,
-                                                               reinterpret_cast<unsigned long long *>(d_out), slot);
+    switch (c->batch_abl) { // timing-only ablations (tools/ab_batch_ablate.py): anything but 0 produces wrong words
+#define ABL_CASE(A) case A: encode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot); break;
+    ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11)
+#undef ABL_CASE
+    default: encode_batch2_kernel<0><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot);
+    }
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
@@ -1194,13 +1198,18 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64
     if (count == 0 || total_words == 0) return BITNUC_OK;
     if (!d_words || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
+    const unsigned long long *po = reinterpret_cast<const unsigned long long *>(d_offsets), *pw = reinterpret_cast<const unsigned long long *>(d_word_offsets);
+    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
     const TileRec *recs;
     if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
     const size_t per_block = (size_t)kBatchTile * kBatchWaves;
     const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
-    decode_batch_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_words),
-                                                        reinterpret_cast<const unsigned long long *>(d_word_offsets),
-                                                        reinterpret_cast<const unsigned long long *>(d_offsets), count, total_words, recs, d_out);
+    switch (c->batch_abl) {
+#define ABL_CASE(A) case A: decode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out); break;
+    ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11) ABL_CASE(15)
+#undef ABL_CASE
+    default: decode_batch2_kernel<0><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out);
+    }
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
@@ -1217,20 +1226,29 @@ int bitnuc_encode_batch(bitnuc_ctx *c, const uint8_t *seq, const uint64_t *offse
     const uint64_t b0 = offsets[0], nbytes = offsets[count] - b0;
     if (int st = ensure_scratch(c, 0, nbytes + 16, err)) return st;
     if (int st = ensure_scratch(c, 4, (count + 1) * 8, err)) return st;
-    if (int st = ensure_scratch(c, 5, (count + 1) * 8, err)) return st;
-    uint64_t *d_off = reinterpret_cast<uint64_t *>(c->scratch[4]), *d_wo = reinterpret_cast<uint64_t *>(c->scratch[5]);
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(c->scratch[4]);
     if (nbytes && !seq) return fail(err, BITNUC_UNSUPPORTED);
     if (nbytes) HIPCHK(hipMemcpyAsync(c->scratch[0], seq + b0, nbytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_off, offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
     size_t total = 0;
-    if (int st = bitnuc_batch_word_offsets_dev(c, d_off, count, d_wo, &total, err)) return st;
+    const uint64_t *d_wo;
+    if (c->batch_host_plan) { // the layout plan: word offsets + tile bases + pad bytes in one go (the context keeps one for its host calls)
+        if (!c->host_plan) if (int st = bitnuc_batch_plan_create(c, &c->host_plan, err)) return st;
+        if (int st = bitnuc_batch_plan_build_dev(c, c->host_plan, d_off, count, &total, err)) return st;
+        d_wo = bitnuc_batch_plan_word_offsets_dev(c->host_plan);
+    } else {
+        if (int st = ensure_scratch(c, 5, (count + 1) * 8, err)) return st;
+        if (int st = bitnuc_batch_word_offsets_dev(c, d_off, count, reinterpret_cast<uint64_t *>(c->scratch[5]), &total, err)) return st;
+        d_wo = reinterpret_cast<const uint64_t *>(c->scratch[5]);
+    }
     HIPCHK(hipMemcpyAsync(word_offsets, d_wo, (count + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     if (total > out_cap_words || (total && !out)) { HIPCHK(hipStreamSynchronize(c->stream)); return fail(err, BITNUC_INVALID_LENGTH, total); }
     if (int st = ensure_scratch(c, 1, total * 8 + 16, err)) return st;
-    // the kernel indexes the sequence buffer with the caller's offsets: rebase the device pointer
+    // the kernels index the sequence buffer with the caller's offsets: rebase the device pointer
     const uint8_t *d_seq = c->scratch[0] - b0;
     if (total) {
-        if (int st = bitnuc_encode_batch_dev(c, d_seq, d_off, d_wo, count, total, reinterpret_cast<uint64_t *>(c->scratch[1]), err)) return st;
+        if (c->batch_host_plan) { if (int st = bitnuc_encode_batch_plan_dev(c, c->host_plan, d_seq, reinterpret_cast<uint64_t *>(c->scratch[1]), err)) return st; }
+        else if (int st = bitnuc_encode_batch_dev(c, d_seq, d_off, d_wo, count, total, reinterpret_cast<uint64_t *>(c->scratch[1]), err)) return st;
         HIPCHK(hipMemcpyAsync(out, c->scratch[1], total * 8, hipMemcpyDeviceToHost, c->stream));
     }
     bitnuc_err e;
@@ -1265,9 +1283,143 @@ int bitnuc_decode_batch(bitnuc_ctx *c, const uint64_t *words, const uint64_t *wo
     HIPCHK(hipMemcpyAsync(c->scratch[1], words, total * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_off, offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_wo, word_offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    if (int st = bitnuc_decode_batch_dev(c, reinterpret_cast<const uint64_t *>(c->scratch[1]), d_wo, d_off, count, total, c->scratch[0] - b0, err)) return st;
+    if (c->batch_host_plan) { // the caller's word_offsets were checked against the offsets above; the plan rebuilds them on the device
+        size_t ptotal = 0;
+        if (!c->host_plan) if (int st = bitnuc_batch_plan_create(c, &c->host_plan, err)) return st;
+        if (int st = bitnuc_batch_plan_build_dev(c, c->host_plan, d_off, count, &ptotal, err)) return st;
+        if (ptotal != total) return fail(err, BITNUC_INVALID_RANGE, count);
+        if (int st = bitnuc_decode_batch_plan_dev(c, c->host_plan, reinterpret_cast<const uint64_t *>(c->scratch[1]), c->scratch[0] - b0, err)) return st;
+    } else if (int st = bitnuc_decode_batch_dev(c, reinterpret_cast<const uint64_t *>(c->scratch[1]), d_wo, d_off, count, total, c->scratch[0] - b0, err)) return st;
     HIPCHK(hipMemcpyAsync(out + b0, c->scratch[0], nbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return BITNUC_OK;
+}
+
+// ---- ragged batches with a layout plan --------------------------------------------------------------
+struct bitnuc_batch_plan {
+    int device = 0;
+    size_t count = 0, total_words = 0;
+    unsigned long long seq_begin = 0, seq_end = 0;
+    unsigned long long *d_wo = nullptr;   // count + 1 word offsets
+    unsigned long long *d_base = nullptr; // one byte offset per 64-word tile
+    uint8_t *d_P = nullptr;               // total_words + 1 pad bytes
+    size_t cap_wo = 0, cap_base = 0, cap_P = 0;
+    bool built = false;
+};
+
+int bitnuc_batch_plan_create(bitnuc_ctx *c, bitnuc_batch_plan **out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!out) return fail(err, BITNUC_UNSUPPORTED);
+    bitnuc_batch_plan *p = new bitnuc_batch_plan();
+    p->device = c->device;
+    *out = p;
+    return BITNUC_OK;
+}
+
+void bitnuc_batch_plan_destroy(bitnuc_batch_plan *p) {
+    if (!p) return;
+    DeviceGuard g(p->device);
+    if (p->d_wo) (void)hipFree(p->d_wo);
+    if (p->d_base) (void)hipFree(p->d_base);
+    if (p->d_P) (void)hipFree(p->d_P);
+    delete p;
+}
+
+size_t bitnuc_batch_plan_total_words(const bitnuc_batch_plan *p) { return p && p->built ? p->total_words : 0; }
+size_t bitnuc_batch_plan_count(const bitnuc_batch_plan *p) { return p && p->built ? p->count : 0; }
+const uint64_t *bitnuc_batch_plan_word_offsets_dev(const bitnuc_batch_plan *p) { return p && p->built ? reinterpret_cast<const uint64_t *>(p->d_wo) : nullptr; }
+
+extern "C++" {
+namespace {
+template <class T> int plan_reserve(T **buf, size_t *cap, size_t need_elems, hipStream_t stream, bitnuc_err *err) {
+    if (need_elems <= *cap) return BITNUC_OK;
+    if (*buf) {
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipFree(*buf));
+        *buf = nullptr;
+        *cap = 0;
+    }
+    size_t want = need_elems + need_elems / 4 + 64; // head-room: a stream of batches of similar size reuses the plan's memory
+    if (hipMalloc(reinterpret_cast<void **>(buf), want * sizeof(T)) != hipSuccess) {
+        (void)hipGetLastError();
+        want = need_elems;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(buf), want * sizeof(T)));
+    }
+    *cap = want;
+    return BITNUC_OK;
+}
+} // namespace
+} // extern "C++"
+
+int bitnuc_batch_plan_build_dev(bitnuc_ctx *c, bitnuc_batch_plan *p, const uint64_t *d_offsets, size_t count, size_t *total_words, bitnuc_err *err) {
+    clear_err(err);
+    if (total_words) *total_words = 0;
+    if (int st = check_ctx(c, err)) return st;
+    if (!p || p->device != c->device || (count && !d_offsets)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    p->built = false;
+    if (int st = plan_reserve(&p->d_wo, &p->cap_wo, count + 1, c->stream, err)) return st;
+    size_t total = 0;
+    if (int st = bitnuc_batch_word_offsets_dev(c, d_offsets, count, reinterpret_cast<uint64_t *>(p->d_wo), &total, err)) return st; // synchronous: total is known
+    p->count = count;
+    p->total_words = total;
+    unsigned long long ends[2] = {0, 0};
+    if (count) {
+        HIPCHK(hipMemcpyAsync(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&ends[1], d_offsets + count, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    const size_t ntiles = (total + kBatchTile - 1) / kBatchTile;
+    if (int st = plan_reserve(&p->d_base, &p->cap_base, ntiles + 1, c->stream, err)) return st;
+    if (int st = plan_reserve(&p->d_P, &p->cap_P, total + 2 + kBatchTile, c->stream, err)) return st;
+    HIPCHK(hipMemsetAsync(p->d_P, 0, total + 2 + kBatchTile, c->stream));
+    if (count && total) {
+        const unsigned long long blocks = (count + kBlock - 1) / kBlock, cap = (unsigned long long)c->num_cu * 16;
+        plan_emit_kernel<<<(unsigned)(blocks < cap ? blocks : cap), kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_offsets), p->d_wo, count, p->d_P, p->d_base);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    p->seq_begin = ends[0];
+    p->seq_end = ends[1];
+    p->built = true;
+    if (total_words) *total_words = total;
+    return BITNUC_OK;
+}
+
+int bitnuc_encode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, const uint8_t *d_seq, uint64_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!p || !p->built || p->device != c->device) return fail(err, BITNUC_UNSUPPORTED);
+    if (p->total_words == 0) return BITNUC_OK;
+    if (!d_seq || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    unsigned long long *slot;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
+    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
+    const unsigned grid = grid_for(c, (p->total_words + per_block - 1) / per_block);
+    encode_batch_plan_kernel<<<grid, kBlock, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end,
+                                                            reinterpret_cast<unsigned long long *>(d_out), slot);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_decode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, const uint64_t *d_words, uint8_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!p || !p->built || p->device != c->device) return fail(err, BITNUC_UNSUPPORTED);
+    if (p->total_words == 0) return BITNUC_OK;
+    if (!d_words || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
+    const unsigned grid = grid_for(c, (p->total_words + per_block - 1) / per_block);
+    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
+    switch (c->batch_abl) { // timing-only ablations: anything but 0 produces wrong bases
+#define ABL_CASE(A) case A: decode_batch_plan_kernel<A><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out); break;
+    ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(6) ABL_CASE(7)
+#undef ABL_CASE
+    default: decode_batch_plan_kernel<0><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out);
+    }
+    HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
 

@@ -156,6 +156,24 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *ctx, const uint64_t *d_words, const uint
 int bitnuc_encode_batch(bitnuc_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, size_t count, uint64_t *out, size_t out_cap_words, uint64_t *word_offsets, size_t *n_words, bitnuc_err *err);
 int bitnuc_decode_batch(bitnuc_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets, const uint64_t *offsets, size_t count, uint8_t *out, bitnuc_err *err);
 
+/* Layout plan: everything about a ragged batch that depends only on its offsets table, computed once and used by
+ * every encode / decode of that layout (a layout is used at least twice: encode now, decode later).  The plan holds
+ * the word offsets, one byte offset per 64-word tile and one pad byte per word; with it a lane finds its word's bytes
+ * with one byte load and a prefix sum -- no offsets window, no search, no per-call pre-kernel -- and the ragged
+ * kernels run at the speed of the fixed-length ones.  _build_dev reads d_offsets (count+1 non-decreasing entries,
+ * device memory) once, is synchronous and may be called again on the same plan for the next batch (memory is reused).
+ * encode / decode take the buffers the table-driven entry points take: sequence i's bases at d_seq + offsets[i], its
+ * words at d_out + word_offsets[i].  Same words, same InvalidBase rule (first invalid byte in buffer order). */
+typedef struct bitnuc_batch_plan bitnuc_batch_plan;
+int bitnuc_batch_plan_create(bitnuc_ctx *ctx, bitnuc_batch_plan **out, bitnuc_err *err);
+int bitnuc_batch_plan_build_dev(bitnuc_ctx *ctx, bitnuc_batch_plan *plan, const uint64_t *d_offsets, size_t count, size_t *total_words, bitnuc_err *err);
+void bitnuc_batch_plan_destroy(bitnuc_batch_plan *plan);
+size_t bitnuc_batch_plan_total_words(const bitnuc_batch_plan *plan);
+size_t bitnuc_batch_plan_count(const bitnuc_batch_plan *plan);
+const uint64_t *bitnuc_batch_plan_word_offsets_dev(const bitnuc_batch_plan *plan); /* count+1 entries, device memory owned by the plan */
+int bitnuc_encode_batch_plan_dev(bitnuc_ctx *ctx, const bitnuc_batch_plan *plan, const uint8_t *d_seq, uint64_t *d_out, bitnuc_err *err);
+int bitnuc_decode_batch_plan_dev(bitnuc_ctx *ctx, const bitnuc_batch_plan *plan, const uint64_t *d_words, uint8_t *d_out, bitnuc_err *err);
+
 /* Fixed-length reads (the common sequencing layout): `count` reads of `read_len` bases, read r
  * at byte r*stride (stride >= read_len; stride == read_len: back to back; stride == read_len+1:
  * newline-separated, ...).  Read r's ceil(read_len/32) words are out[r*wpr .. (r+1)*wpr), its

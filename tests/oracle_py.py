@@ -201,6 +201,14 @@ def nucgen(length, seed, first=0, flags=0):
     return out
 
 
+def build_flags():
+    """The compiler flags the oracle was built with (bench.py records them beside cpu_baseline)."""
+    for line in open(os.path.join(ORACLE_DIR, "Makefile")):
+        if line.startswith("CFLAGS"):
+            return (os.environ.get("CC", "gcc") + " " + line.split("=", 1)[1].strip())
+    return None
+
+
 def avx2_time_roundtrip(seq):
     s = _u8(seq)
     e, d = C.c_double(0), C.c_double(0)

@@ -512,15 +512,17 @@ def _oracle_batch(oracle, seq, off):
     return (np.concatenate(words) if words else np.zeros(0, np.uint64)), np.array(wo, dtype=np.uint64)
 
 
-@pytest.fixture(params=[0, 1], ids=["byte-funnel", "stream-cut"])
+@pytest.fixture(params=[1, 0], ids=["plan", "tables"])
 def batch_body(request, ctx):
-    """Both tile bodies of encode_batch (knob batch_stream): the raw-byte funnel and the stream cut."""
-    prev = ctx.set_variant("batch_stream", request.param)
+    """Both formulations of the ragged-batch kernels behind the host-pointer entry points: the layout plan
+    (bitnuc_batch_plan: one pad byte per word; what host calls use) and the table-driven kernels (tile records + O(1)
+    pad-scatter lookup from the two offset tables; what the *_dev table entry points use)."""
+    prev = ctx.set_variant("batch_host_plan", request.param)
     yield request.param
-    ctx.set_variant("batch_stream", prev)
+    ctx.set_variant("batch_host_plan", prev)
 
 
-@pytest.mark.parametrize("shape", ["reads150", "tiny", "mixed", "with_empties", "one_long", "many_empties"])
+@pytest.mark.parametrize("shape", ["reads150", "tiny", "mixed", "with_empties", "one_long", "many_empties", "len32", "ones_and_empties", "unaligned_long"])
 def test_batch_encode_decode_vs_oracle_loop(ctx, oracle, shape, batch_body):
     lengths = {
         "reads150": [150] * 3000,
@@ -529,6 +531,9 @@ def test_batch_encode_decode_vs_oracle_loop(ctx, oracle, shape, batch_body):
         "with_empties": [0, 0, 5, 0, 37, 0, 0, 0, 64, 0] * 200,
         "one_long": [1000003],
         "many_empties": [0] * 1000 + [40] + [0] * 2000 + [7, 0, 0, 33] + [0] * 500,
+        "len32": [32] * 4099,                                   # 64 sequence starts per tile: the second window round
+        "ones_and_empties": [1, 0, 1, 1, 0, 0, 1] * 700 + [31, 1, 33, 0, 1] * 50,  # > 64 starts per tile incl. empties
+        "unaligned_long": [7, 300001, 13, 2049, 2048, 2047, 5],  # dense tiles whose first base is not 16-byte aligned (chunk 128)
     }[shape]
     seq, off = _ragged(lengths)
     ew, ewo = _oracle_batch(oracle, seq, off)
@@ -606,6 +611,18 @@ def test_batch_full_scale_reads(ctx, oracle):
     ctx.decode_batch_dev(words, wo, off, count, total, back)
     ctx.sync()
     assert torch.equal(seq, back)
+    # the same batch through a layout plan: same word offsets, same words, same bases
+    import bitnuc_amd as bn
+    plan = bn.BatchPlan(ctx, off, count)
+    assert plan.total_words == total
+    words_p = torch.zeros(total, dtype=torch.int64, device=dev)
+    back.zero_()
+    torch.cuda.synchronize()
+    plan.encode_dev(seq, words_p)
+    plan.decode_dev(words_p, back)
+    ctx.sync()
+    assert torch.equal(words_p, words) and torch.equal(seq, back)
+    plan.close()
     for r0 in (0, 1_234_567, count - 2000):
         h = seq[r0 * L:(r0 + 2000) * L].cpu().numpy()
         exp = np.concatenate([oracle.encode(h[i * L:(i + 1) * L]) for i in range(2000)])

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Timing-only ablations of decode_batch_plan_kernel on 150-base reads, next to the fixed-length and bulk decode kernels."""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bitnuc_amd
+
+dev = torch.device("cuda:0")
+stream = torch.cuda.current_stream()
+ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+N, L = 10**9, int(sys.argv[1]) if len(sys.argv) > 1 else 150
+count = N // L
+seq = torch.empty(N, dtype=torch.uint8, device=dev)
+back = torch.empty(N + 4096, dtype=torch.uint8, device=dev)
+back2 = torch.empty(N + 4096, dtype=torch.uint8, device=dev)
+ctx.nucgen_dev(seq, N, 0xB17C0DE)
+off = torch.arange(0, count + 1, dtype=torch.int64, device=dev) * L
+torch.cuda.synchronize()
+plan = bitnuc_amd.BatchPlan(ctx, off, count)
+total = plan.total_words
+words = torch.empty(total + 64, dtype=torch.int64, device=dev)
+bw = torch.empty(N // 32 + 64, dtype=torch.int64, device=dev)
+plan.encode_dev(seq, words)
+ctx.encode_dev(seq, N, bw)
+ctx.sync()
+
+
+def once(fn):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    fn()
+    b.record(stream)
+    torch.cuda.synchronize()
+    return a.elapsed_time(b)
+
+
+names = {0: "full", 4: "no edge stores", 7: "no or/zero/edges"}
+edges = {}
+res = {k: [] for k in list(names) + ["fixed", "bulk"] + [("e", e) for e in edges]}
+flip = 0
+for rnd in range(9):
+    for a in names:
+        ctx.set_variant("batch_abl", a)
+        flip ^= 1
+        t = once(lambda: plan.decode_dev(words, back if flip else back2))
+        if rnd >= 2:
+            res[a].append(t)
+    ctx.set_variant("batch_abl", 0)
+    for e in edges:
+        ctx.set_variant("plan_edge", e)
+        flip ^= 1
+        t = once(lambda: plan.decode_dev(words, back if flip else back2))
+        if rnd >= 2:
+            res[("e", e)].append(t)
+    t = once(lambda: ctx.decode_fixed_dev(words, L, L, count, back))
+    u = once(lambda: ctx.decode_dev(bw, N // 32, N, back2))
+    if rnd >= 2:
+        res["fixed"].append(t)
+        res["bulk"].append(u)
+alg = L * count + 8 * total
+print(f"L={L}: decode of {count} reads, {alg/1e9:.4f} GB algorithmic; bulk decode of 10^9 bases: 1.25 GB")
+for a in names:
+    m = statistics.median(res[a])
+    print(f"  plan abl {a} {names[a]:26s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
+for e in edges:
+    m = statistics.median(res[("e", e)])
+    print(f"  plan edge {e} {edges[e]:40s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
+plan.decode_dev(words, back)
+ctx.sync()
+print("  round trip:", "ok" if bool(torch.equal(back[:L * count], seq[:L * count])) else "MISMATCH")
+m = statistics.median(res["fixed"])
+print(f"  decode_fixed                        {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
+m = statistics.median(res["bulk"])
+print(f"  bulk decode_kernel (10^9 bases)     {m:.4f} ms  {1.25e9/m/1e6:6.0f} GB/s")
