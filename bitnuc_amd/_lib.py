@@ -89,6 +89,7 @@ SIGNATURES = {
     "bitnuc_nucgen_dev": (C.c_int, [_P, _P, _SZ, _U64, _U64, C.c_int, _ERR]),
     "bitnuc_stream_probe_dev": (C.c_int, [_P, C.c_int, _P, _P, _SZ, _ERR]),
     "bitnuc_selftime_small": (C.c_double, [C.c_int, _SZ, _SZ]),
+    "bitnuc_selftime_host_copy": (C.c_double, [_SZ, C.c_int, C.c_int]),
 }
 
 _libs = {}

@@ -190,6 +190,27 @@ class Context:
                 raise
         return out
 
+    def encode_into(self, sequence, out):
+        """encode into a caller-owned uint64 array of >= ceil(len/32) words (no allocation: a pipeline reuses its buffers,
+        and a freshly allocated output would be timed by its page faults, not by the codec).  -> number of words."""
+        s = _as_u8(sequence)
+        if not (isinstance(out, np.ndarray) and out.dtype == np.uint64 and out.flags.c_contiguous and out.size >= (s.size + 31) // 32):
+            raise ValueError("out must be a contiguous uint64 array of at least ceil(len/32) words")
+        nw = C.c_size_t(0)
+        err = L.BitnucErr()
+        if self._lib.bitnuc_encode(self._h, _ptr(s), s.size, _ptr(out), C.byref(nw), C.byref(err)) != L.OK:
+            _raise(err)
+        return nw.value
+
+    def decode_into(self, ebuf, n_bases, out):
+        """decode into a caller-owned uint8 array of >= n_bases bytes (see encode_into)."""
+        e = _as_u64(ebuf)
+        if not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags.c_contiguous and out.size >= n_bases):
+            raise ValueError("out must be a contiguous uint8 array of at least n_bases bytes")
+        err = L.BitnucErr()
+        if self._lib.bitnuc_decode(self._h, _ptr(e), e.size, int(n_bases), _ptr(out), C.byref(err)) != L.OK:
+            _raise(err)
+
     def encode(self, sequence, ebuf):
         del ebuf[:]  # ebuf.clear(), packing/avx.rs:132
         try:

@@ -31,7 +31,7 @@ namespace {
 
 constexpr int kSlots = 4096;                    // data-error slots between two syncs
 constexpr size_t kHostChunk = (size_t)128 << 20; // bases per staged chunk on the simple host-pointer path
-constexpr size_t kPipeChunk = (size_t)32 << 20;  // bases per chunk of the pipelined host-pointer path (encode / decode)
+constexpr size_t kPipeChunkDefault = (size_t)32 << 20; // bases per chunk of the pipelined host-pointer path (encode / decode); BITNUC_PIPE_CHUNK_MB overrides
 constexpr size_t kPipeMin = (size_t)8 << 20;     // inputs below this stay on the simple path (latency, not bandwidth, matters there)
 // Bulk host-pointer calls below this many bases run on the host (host_word.h): a launch with its two copies
 // costs ~35 us, the SWAR loop moves ~2-4 GB/s, so the crossover sits near 10^5 bases (tools/latency.py).
@@ -202,12 +202,14 @@ struct CopyPool {
     }
 };
 
+constexpr int kPipeDepth = 3; // buffer sets in flight: the host hands chunk c-2 to the caller while chunk c-1 is on the DMA engines and chunk c is staged
 struct HostPipe {
     hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    uint8_t *pin_a[2] = {nullptr, nullptr}, *pin_b[2] = {nullptr, nullptr}; // a: ASCII-sized (chunk + 64), b: word-sized (chunk / 4 + 64)
-    uint8_t *dev_a[2] = {nullptr, nullptr}, *dev_b[2] = {nullptr, nullptr};
+    hipEvent_t ev_in[kPipeDepth] = {}, ev_k[kPipeDepth] = {}, ev_out[kPipeDepth] = {};
+    uint8_t *pin_a[kPipeDepth] = {}, *pin_b[kPipeDepth] = {}; // a: ASCII-sized (chunk + 64), b: word-sized (chunk / 4 + 64)
+    uint8_t *dev_a[kPipeDepth] = {}, *dev_b[kPipeDepth] = {};
     CopyPool *pool = nullptr;
+    size_t chunk = kPipeChunkDefault; // bases per chunk (a multiple of 32)
     bool ok = false;
 };
 
@@ -226,7 +228,7 @@ int host_threads() {
 
 void pipe_destroy(HostPipe *p) {
     if (!p) return;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kPipeDepth; ++i) {
         if (p->pin_a[i]) (void)hipHostFree(p->pin_a[i]);
         if (p->pin_b[i]) (void)hipHostFree(p->pin_b[i]);
         if (p->dev_a[i]) (void)hipFree(p->dev_a[i]);
@@ -246,8 +248,12 @@ int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err) {
     HostPipe *p = new HostPipe();
     hipError_t rc = hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking);
-    const size_t na = kPipeChunk + 64, nb = kPipeChunk / 4 + 64;
-    for (int i = 0; i < 2 && rc == hipSuccess; ++i) {
+    if (const char *e = getenv("BITNUC_PIPE_CHUNK_MB")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 1024) p->chunk = (size_t)v << 20;
+    }
+    const size_t na = p->chunk + 64, nb = p->chunk / 4 + 64;
+    for (int i = 0; i < kPipeDepth && rc == hipSuccess; ++i) {
         rc = hipEventCreateWithFlags(&p->ev_in[i], hipEventDisableTiming);
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&p->ev_k[i], hipEventDisableTiming);
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&p->ev_out[i], hipEventDisableTiming);
@@ -873,33 +879,34 @@ static inline bool on_host(const bitnuc_ctx *c, size_t n) {
 static int encode_pipelined(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, size_t *n_words, bitnuc_err *err) {
     HostPipe *p;
     if (int st = pipe_get(c, &p, err)) return st;
+    const size_t kPipeChunk = p->chunk;
     const size_t nchunks = (len + kPipeChunk - 1) / kPipeChunk;
     auto chunk_len = [&](size_t ci) { return len - ci * kPipeChunk < kPipeChunk ? len - ci * kPipeChunk : kPipeChunk; };
-    HIPCHK(hipEventRecord(p->ev_k[0], c->stream)); // earlier work on the context's stream finishes before the device buffers are reused
-    HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[0], 0));
-    for (size_t ci = 0; ci <= nchunks; ++ci) {
-        const int b = (int)(ci & 1);
+    constexpr int D = kPipeDepth, LAG = kPipeDepth - 1;
+    for (size_t ci = 0; ci < nchunks + LAG; ++ci) {
+        const int b = (int)(ci % D);
         if (ci < nchunks) {
             const size_t n = chunk_len(ci), nw = words_for(n);
-            if (ci >= 2) HIPCHK(hipEventSynchronize(p->ev_in[b])); // pinned input b: its previous H2D has left
+            if (ci >= (size_t)D) HIPCHK(hipEventSynchronize(p->ev_in[b])); // pinned input b: its previous H2D has left
             p->pool->copy(p->pin_a[b], seq + ci * kPipeChunk, n);
-            if (ci >= 2) HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[b], 0)); // device input b: the kernel of chunk ci-2 has read it
+            if (ci >= (size_t)D) HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[b], 0)); // device input b: the kernel of chunk ci-D has read it
             HIPCHK(hipMemcpyAsync(p->dev_a[b], p->pin_a[b], n, hipMemcpyHostToDevice, p->s_in));
             HIPCHK(hipEventRecord(p->ev_in[b], p->s_in));
             HIPCHK(hipStreamWaitEvent(c->stream, p->ev_in[b], 0));
-            if (ci >= 2) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_out[b], 0)); // device output b: its D2H of chunk ci-2 is done
+            if (ci >= (size_t)D) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_out[b], 0)); // device output b: its D2H of chunk ci-D is done
             unsigned long long *slot;
             if (int st = take_slot(c, ci * kPipeChunk, &slot, err)) return st;
             HIPCHK(launch_encode(c, p->dev_a[b], reinterpret_cast<uint64_t *>(p->dev_b[b]), n, slot));
             HIPCHK(hipEventRecord(p->ev_k[b], c->stream));
             HIPCHK(hipStreamWaitEvent(p->s_out, p->ev_k[b], 0));
-            HIPCHK(hipMemcpyAsync(p->pin_b[b], p->dev_b[b], nw * 8, hipMemcpyDeviceToHost, p->s_out)); // pinned output b was drained by the host one iteration ago
+            HIPCHK(hipMemcpyAsync(p->pin_b[b], p->dev_b[b], nw * 8, hipMemcpyDeviceToHost, p->s_out)); // pinned output b was handed to the caller one iteration ago
             HIPCHK(hipEventRecord(p->ev_out[b], p->s_out));
         }
-        if (ci >= 1) { // hand chunk ci-1's words to the caller while chunk ci is in flight
-            const int pb = (int)((ci - 1) & 1);
+        if (ci >= (size_t)LAG) { // hand chunk ci-LAG's words to the caller: its D2H finished long ago, the DMA queues stay full meanwhile
+            const size_t j = ci - LAG;
+            const int pb = (int)(j % D);
             HIPCHK(hipEventSynchronize(p->ev_out[pb]));
-            p->pool->copy(out + (ci - 1) * (kPipeChunk / 32), p->pin_b[pb], words_for(chunk_len(ci - 1)) * 8);
+            p->pool->copy(out + j * (kPipeChunk / 32), p->pin_b[pb], words_for(chunk_len(j)) * 8);
         }
     }
     bitnuc_err e;
@@ -916,31 +923,32 @@ static int encode_pipelined(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint6
 static int decode_pipelined(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_bases, uint8_t *out, bitnuc_err *err) {
     HostPipe *p;
     if (int st = pipe_get(c, &p, err)) return st;
+    const size_t kPipeChunk = p->chunk;
     const size_t nchunks = (n_bases + kPipeChunk - 1) / kPipeChunk;
     auto chunk_len = [&](size_t ci) { return n_bases - ci * kPipeChunk < kPipeChunk ? n_bases - ci * kPipeChunk : kPipeChunk; };
-    HIPCHK(hipEventRecord(p->ev_k[0], c->stream));
-    HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[0], 0));
-    for (size_t ci = 0; ci <= nchunks; ++ci) {
-        const int b = (int)(ci & 1);
+    constexpr int D = kPipeDepth, LAG = kPipeDepth - 1;
+    for (size_t ci = 0; ci < nchunks + LAG; ++ci) {
+        const int b = (int)(ci % D);
         if (ci < nchunks) {
             const size_t n = chunk_len(ci), nw = words_for(n);
-            if (ci >= 2) HIPCHK(hipEventSynchronize(p->ev_in[b]));
+            if (ci >= (size_t)D) HIPCHK(hipEventSynchronize(p->ev_in[b]));
             p->pool->copy(p->pin_b[b], ebuf + ci * (kPipeChunk / 32), nw * 8);
-            if (ci >= 2) HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[b], 0));
+            if (ci >= (size_t)D) HIPCHK(hipStreamWaitEvent(p->s_in, p->ev_k[b], 0));
             HIPCHK(hipMemcpyAsync(p->dev_b[b], p->pin_b[b], nw * 8, hipMemcpyHostToDevice, p->s_in));
             HIPCHK(hipEventRecord(p->ev_in[b], p->s_in));
             HIPCHK(hipStreamWaitEvent(c->stream, p->ev_in[b], 0));
-            if (ci >= 2) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_out[b], 0));
+            if (ci >= (size_t)D) HIPCHK(hipStreamWaitEvent(c->stream, p->ev_out[b], 0));
             HIPCHK(launch_decode(c, reinterpret_cast<const uint64_t *>(p->dev_b[b]), p->dev_a[b], n));
             HIPCHK(hipEventRecord(p->ev_k[b], c->stream));
             HIPCHK(hipStreamWaitEvent(p->s_out, p->ev_k[b], 0));
             HIPCHK(hipMemcpyAsync(p->pin_a[b], p->dev_a[b], n, hipMemcpyDeviceToHost, p->s_out));
             HIPCHK(hipEventRecord(p->ev_out[b], p->s_out));
         }
-        if (ci >= 1) {
-            const int pb = (int)((ci - 1) & 1);
+        if (ci >= (size_t)LAG) {
+            const size_t j = ci - LAG;
+            const int pb = (int)(j % D);
             HIPCHK(hipEventSynchronize(p->ev_out[pb]));
-            p->pool->copy(out + (ci - 1) * kPipeChunk, p->pin_a[pb], chunk_len(ci - 1));
+            p->pool->copy(out + j * kPipeChunk, p->pin_a[pb], chunk_len(j));
         }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1932,6 +1940,34 @@ int bitnuc_hdist_scalar(bitnuc_ctx *c, uint64_t u, uint64_t v, size_t len, uint3
     if (c && c->force_gpu) return bitnuc_hdist(c, &u, 1, &v, 1, len, out, err);
     *out = bitnuc_host::hdist_word(u, v, len);
     return BITNUC_OK;
+}
+
+// Diagnostic (tools/host_path.py): GB/s of the staging pool's parallel memcpy of `bytes` with `threads` threads;
+// mode 0: pageable -> pageable, 1: pageable -> pinned (hipHostMalloc), 2: pinned -> pageable.  < 0 on failure.
+double bitnuc_selftime_host_copy(size_t bytes, int threads, int mode) {
+    if (bytes < 4096 || threads < 1 || threads > 64 || mode < 0 || mode > 2) return -1.0;
+    uint8_t *page = static_cast<uint8_t *>(malloc(bytes)), *other = nullptr;
+    if (!page) return -1.0;
+    memset(page, 65, bytes);
+    if (mode == 0) { other = static_cast<uint8_t *>(malloc(bytes)); if (other) memset(other, 1, bytes); }
+    else if (hipHostMalloc(reinterpret_cast<void **>(&other), bytes, hipHostMallocDefault) != hipSuccess) other = nullptr;
+    if (!other) { free(page); return -1.0; }
+    if (mode != 0) memset(other, 1, bytes);
+    double best = 0.0;
+    {
+        CopyPool pool(threads);
+        for (int rep = 0; rep < 4; ++rep) {
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            if (mode == 2) pool.copy(page, other, bytes); else pool.copy(other, page, bytes);
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            if (rep > 0 && (double)bytes / sec / 1e9 > best) best = (double)bytes / sec / 1e9;
+        }
+    }
+    if (mode == 0) free(other); else (void)hipHostFree(other);
+    free(page);
+    return best;
 }
 
 // Diagnostic (bench.py's small_call_latency block): mean ns per call of the HOST path over `iters` calls on the

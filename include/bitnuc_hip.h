@@ -280,6 +280,9 @@ int bitnuc_stream_probe_dev(bitnuc_ctx *ctx, int mode, const void *d_src, void *
 /* Mean ns per call of the HOST path (op 0 as_2bit, 1 from_2bit, 2 encode, 3 decode, 4 hdist_scalar) on n bases of the
  * reference's bench input (benches/simd_comparison.rs:4-7), timed inside the library over `iters` calls; < 0 = bad argument. */
 double bitnuc_selftime_small(int op, size_t n, size_t iters);
+/* GB/s of the host-path staging pool's parallel memcpy (tools/host_path.py): mode 0 pageable -> pageable, 1 pageable -> pinned,
+ * 2 pinned -> pageable; < 0 on failure. */
+double bitnuc_selftime_host_copy(size_t bytes, int threads, int mode);
 
 #ifdef __cplusplus
 }
