@@ -512,9 +512,16 @@ __device__ __forceinline__ void strip_or_word(uint32_t *strip, unsigned bit, uns
 // its LAST 16 bytes [hi-16, hi) as one unaligned dwordx4 each, cut from the bit strip at an arbitrary 2-bit position (two
 // dword reads + v_alignbit).  They overlap this tile's own aligned chunks with identical bytes and never touch a
 // neighbour's.  Runs shorter than 16 bytes (the last tile of a small batch) take the byte-wise path.
-__device__ __forceinline__ void strip_drain(const uint32_t *strip, uint8_t (*edge)[16], uintptr_t lo16, uintptr_t lo, uintptr_t hi, unsigned lane) {
+// POLICY: cache policy of the whole-chunk stores.  0 = streaming (nt), 1 = allocating (plain), 2 (shipped) = plain for the chunks
+// of the run's first / last 128-byte cache line (shared with the neighbouring tiles, so that the two parts of a line can meet in
+// L2), nt for everything else (inline asm: written as two C++ stores the compiler merges them into one plain flat store).
+// Sustained bursts, 150-base / 1000-base reads (profiles/r02_plan_decode_store_policy.txt): 2 = 5.86 / 6.19 TB/s,
+// 0 = 5.79 / 6.07, 1 = 5.38 / 5.73.
+template <int POLICY = 2>
+__device__ __forceinline__ void strip_drain(const uint32_t *strip, uint8_t (*edge)[16], uint8_t *__restrict__ out, uintptr_t lo16, uintptr_t lo, uintptr_t hi, unsigned lane) {
     const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4); // <= 130
     const bool wide = hi - lo >= 16;                           // wave-uniform
+    const uintptr_t op = reinterpret_cast<uintptr_t>(out);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const unsigned c = lane + 64 * j;
@@ -522,13 +529,15 @@ __device__ __forceinline__ void strip_drain(const uint32_t *strip, uint8_t (*edg
         const uintptr_t g = lo16 + 16 * (uintptr_t)c;
         if (g >= lo && g + 16 <= hi) {
             const u32x4 d = dec16(strip[c]);
-            // The run's first and last 128-byte cache lines are shared with the neighbouring tiles: their chunks are stored
-            // with the allocating policy, so that the two parts of a line meet in L2 and leave as one full line; every
-            // other chunk streams past the caches (nt).  In-process A/B, 150-base reads: -2 % (-3.5 % for 1000-base
-            // reads); giving the shared chunk to one wave (look-ahead into the next tile) or an XCD-contiguous tile
-            // order were both slower (profiles/r02_plan_decode_edges.txt).
-            if ((g >> 7) == (lo >> 7) || (g >> 7) == ((hi - 1) >> 7)) *reinterpret_cast<u32x4 *>(g) = d;
-            else __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(g));
+            u32x4 *dst = reinterpret_cast<u32x4 *>(out + (g - op)); // derived from `out`: a global (not flat) store
+            if constexpr (POLICY == 0) {
+                __builtin_nontemporal_store(d, dst);
+            } else if constexpr (POLICY == 1) {
+                *dst = d;
+            } else {
+                if ((g >> 7) == (lo >> 7) || (g >> 7) == ((hi - 1) >> 7)) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+            }
         } else if (!wide) {
             uint8_t *e = edge[c ? 1 : 0];
             *reinterpret_cast<u32x4 *>(e) = dec16(strip[c]);
@@ -541,7 +550,7 @@ __device__ __forceinline__ void strip_drain(const uint32_t *strip, uint8_t (*edg
             const uintptr_t a = head ? lo : hi - 16;
             const unsigned bit = 2u * (unsigned)(a - lo16);
             const uint32_t w0 = strip[bit >> 5], w1 = strip[(bit >> 5) + 1];
-            *reinterpret_cast<u32x4_u *>(a) = dec16(__builtin_amdgcn_alignbit(w1, w0, bit & 31));
+            *reinterpret_cast<u32x4_u *>(out + (a - op)) = dec16(__builtin_amdgcn_alignbit(w1, w0, bit & 31));
         }
     }
 }
@@ -571,7 +580,7 @@ decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned
         wave_lds_fence();
         if (active) strip_or_word(strip, 2u * (unsigned)(reinterpret_cast<uintptr_t>(out) + base - lo16), word, nb);
         wave_lds_fence();
-        strip_drain(strip, edge[wave_in_block()], lo16, lo, hi, lane);
+        strip_drain(strip, edge[wave_in_block()], out, lo16, lo, hi, lane);
     }
 }
 
@@ -795,7 +804,7 @@ decode_batch2_kernel(const unsigned long long *__restrict__ words, const unsigne
         if constexpr (ABL & 4) { lo_w = (lo + 15) & ~(uintptr_t)15; hi &= ~(uintptr_t)15; }
         if (lane <= last) strip_or_word(my.strip, 2u * ((unsigned)(lo - lo16) + base_rel), word, nb);
         wave_lds_fence();
-        strip_drain(my.strip, my.edge, lo16, lo_w, hi, lane);
+        strip_drain(my.strip, my.edge, out, lo16, lo_w, hi, lane);
     }
 }
 
@@ -895,7 +904,7 @@ encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long lo
 }
 
 // ABL: timing-only ablations (wrong output): 1 = plain stores instead of the three ds_or, 2 = no strip zeroing, 4 = no edge stores
-template <int ABL>
+template <int ABL, int POLICY = 2>
 __global__ void __launch_bounds__(kBlock)
 decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
                          unsigned long long total_words, uint8_t *__restrict__ out) {
@@ -938,7 +947,7 @@ decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const uns
             if (lane <= last) strip_or_word(strip, 2u * ((unsigned)(lo - lo16) + base_rel), word, nb);
         }
         wave_lds_fence();
-        if (hi > lo_w) strip_drain(strip, edge[wave], lo16, lo_w, hi, lane);
+        if (hi > lo_w) strip_drain<POLICY>(strip, edge[wave], out, lo16, lo_w, hi, lane);
     }
 }
 

@@ -70,6 +70,7 @@ struct bitnuc_ctx {
     int owner_est = 3;                     // block_owner_kernel's first guess: 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, 3 = 2 or 0 by average sequence length
     int batch_host_plan = 1;               // host-pointer ragged-batch calls build a layout plan (bitnuc_batch_plan) and use the plan kernels
     bitnuc_batch_plan *host_plan = nullptr; // ... kept by the context
+    int plan_store = 2;                    // decode_batch_plan_kernel's whole-chunk store policy: 0 nt, 1 plain, 2 plain on the shared edge lines + nt elsewhere
     int batch_abl = 0;                     // timing-only ablation mask of the second formulation (tools/ab_batch_ablate.py); 0 in normal use
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
@@ -722,6 +723,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value == 0 || value == 1) c->fixed_dec_strip = value; }
     else if (!strcmp(key, "owner_est")) { prev = c->owner_est; if (value >= 0 && value <= 3) c->owner_est = value; }
     else if (!strcmp(key, "batch_host_plan")) { prev = c->batch_host_plan; if (value == 0 || value == 1) c->batch_host_plan = value; }
+    else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && value <= 2) c->plan_store = value; }
     else if (!strcmp(key, "batch_abl")) { prev = c->batch_abl; if (value >= 0 && value <= 15) c->batch_abl = value; }
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
@@ -1425,7 +1427,10 @@ int bitnuc_decode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, cons
 #define ABL_CASE(A) case A: decode_batch_plan_kernel<A><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out); break;
     ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(6) ABL_CASE(7)
 #undef ABL_CASE
-    default: decode_batch_plan_kernel<0><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out);
+    default:
+        if (c->plan_store == 0) decode_batch_plan_kernel<0, 0><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out);
+        else if (c->plan_store == 1) decode_batch_plan_kernel<0, 1><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out);
+        else decode_batch_plan_kernel<0, 2><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out);
     }
     HIPCHK(hipGetLastError());
     return BITNUC_OK;

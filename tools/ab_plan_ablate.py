@@ -29,35 +29,47 @@ ctx.encode_dev(seq, N, bw)
 ctx.sync()
 
 
+BURST = 12
+
+
 def once(fn):
+    """ms per launch over a burst of back-to-back launches (sustained rate: no host sync between launches)."""
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(stream)
     fn()
+    a.record(stream)
+    for _ in range(BURST):
+        fn()
     b.record(stream)
     torch.cuda.synchronize()
-    return a.elapsed_time(b)
+    return a.elapsed_time(b) / BURST
 
 
 names = {0: "full", 4: "no edge stores", 7: "no or/zero/edges"}
-edges = {}
+edges = {0: "all chunks nt", 1: "all chunks plain", 2: "edge lines plain, rest nt"}
 res = {k: [] for k in list(names) + ["fixed", "bulk"] + [("e", e) for e in edges]}
-flip = 0
-for rnd in range(9):
+flip = [0]
+
+
+def alt():
+    flip[0] ^= 1
+    return back if flip[0] else back2
+
+
+for rnd in range(7):
     for a in names:
         ctx.set_variant("batch_abl", a)
-        flip ^= 1
-        t = once(lambda: plan.decode_dev(words, back if flip else back2))
+        t = once(lambda: plan.decode_dev(words, alt()))
         if rnd >= 2:
             res[a].append(t)
     ctx.set_variant("batch_abl", 0)
     for e in edges:
-        ctx.set_variant("plan_edge", e)
-        flip ^= 1
-        t = once(lambda: plan.decode_dev(words, back if flip else back2))
+        ctx.set_variant("plan_store", e)
+        t = once(lambda: plan.decode_dev(words, alt()))
         if rnd >= 2:
             res[("e", e)].append(t)
-    t = once(lambda: ctx.decode_fixed_dev(words, L, L, count, back))
-    u = once(lambda: ctx.decode_dev(bw, N // 32, N, back2))
+    ctx.set_variant("plan_store", 2)
+    t = once(lambda: ctx.decode_fixed_dev(words, L, L, count, alt()))
+    u = once(lambda: ctx.decode_dev(bw, N // 32, N, alt()))
     if rnd >= 2:
         res["fixed"].append(t)
         res["bulk"].append(u)
@@ -68,7 +80,7 @@ for a in names:
     print(f"  plan abl {a} {names[a]:26s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
 for e in edges:
     m = statistics.median(res[("e", e)])
-    print(f"  plan edge {e} {edges[e]:40s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
+    print(f"  plan store policy {e} {edges[e]:30s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
 plan.decode_dev(words, back)
 ctx.sync()
 print("  round trip:", "ok" if bool(torch.equal(back[:L * count], seq[:L * count])) else "MISMATCH")
