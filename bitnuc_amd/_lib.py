@@ -50,6 +50,7 @@ SIGNATURES = {
     "bitnuc_decode_dev": (C.c_int, [_P, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_as_2bit_batch_dev": (C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _ERR]),
     "bitnuc_kmer_hdist_scan_dev": (C.c_int, [_P, _P, _SZ, _SZ, _U64, _P, _ERR]),
+    "bitnuc_kmer_hdist_count_dev": (C.c_int, [_P, _P, _SZ, _SZ, _U64, C.c_uint, _P, _ERR]),
     "bitnuc_hdist_dev": (C.c_int, [_P, _P, _SZ, _P, _SZ, _SZ, _P, _ERR]),
     "bitnuc_batch_word_offsets_dev": (C.c_int, [_P, _P, _SZ, _P, C.POINTER(_SZ), _ERR]),
     "bitnuc_encode_batch_dev": (C.c_int, [_P, _P, _P, _P, _SZ, _SZ, _P, _ERR]),

@@ -470,6 +470,10 @@ class Context:
     def kmer_hdist_scan_dev(self, d_ref, n, k, query, d_dist):
         self._call_dev(self._lib.bitnuc_kmer_hdist_scan_dev, _dev_ptr(d_ref), int(n), int(k), C.c_uint64(query), _dev_ptr(d_dist))
 
+    def kmer_hdist_count_dev(self, d_ref, n, k, query, tau, d_count):
+        """Number of windows with Hamming distance <= tau to the query (fused scan, no distance bytes written) -> *d_count (u64)."""
+        self._call_dev(self._lib.bitnuc_kmer_hdist_count_dev, _dev_ptr(d_ref), int(n), int(k), C.c_uint64(query), int(tau), _dev_ptr(d_count))
+
     def hdist_dev(self, d_a, na, d_b, nb, n_bases, d_result):
         self._call_dev(self._lib.bitnuc_hdist_dev, _dev_ptr(d_a), int(na), _dev_ptr(d_b), int(nb), int(n_bases), _dev_ptr(d_result))
 

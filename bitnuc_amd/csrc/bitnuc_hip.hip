@@ -75,6 +75,7 @@ struct bitnuc_ctx {
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
+    int scan_impl = 1;                     // 1 = line-aligned rounds of 1024 windows (kmer_scan2_kernel), 0 = rounds of 992 windows (kmer_scan_kernel)
     int force_gpu = 0;                     // 1: single-word and below-cutoff calls launch kernels too (GPU parity tests, BITNUC_FORCE_GPU=1)
     size_t host_cutoff = kDefaultHostCutoff; // bulk host-pointer calls below this many bases run on the host (host_word.h)
     int host_pipeline = 1;                 // large host-pointer encode / decode: pinned double buffers + overlapped H2D / kernel / D2H
@@ -556,15 +557,38 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
     return hipGetLastError();
 }
 
+// de-interleave a packed query into its two bit-planes (bit i = low / high code bit of base i)
+void query_planes(uint64_t query, size_t k, uint32_t *ql, uint32_t *qh) {
+    *ql = *qh = 0;
+    for (unsigned i = 0; i < k; ++i) {
+        *ql |= (uint32_t)((query >> (2 * i)) & 1) << i;
+        *qh |= (uint32_t)((query >> (2 * i + 1)) & 1) << i;
+    }
+}
+
 hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist,
                        unsigned long long *slot) {
-    const unsigned long long rounds = n >= 1024 ? (n - 1024) / kScanWaveWindows + 1 : 0;
-    uint32_t ql = 0, qh = 0; // de-interleave the packed query into its two bit-planes
-    for (unsigned i = 0; i < k; ++i) {
-        ql |= (uint32_t)((query >> (2 * i)) & 1) << i;
-        qh |= (uint32_t)((query >> (2 * i + 1)) & 1) << i;
-    }
+    uint32_t ql, qh;
+    query_planes(query, k, &ql, &qh);
     const int unroll = c->scan_unroll, kb = c->kmer_block;
+    const bool al = aligned16(ref) && aligned16(dist);
+    if (c->scan_impl == 1 && al) { // line-aligned rounds of 1024 windows
+        const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+        const unsigned grid = grid_for(c, rounds / ((kb / 64) * unroll) + 1, kb);
+#define SCAN2(NL, NS, U) kmer_scan2_kernel<true, NL, NS, U, false><<<grid, kb, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, 0u, dist, nullptr, nullptr, nullptr, slot)
+#define SCAN2_POLICY(U)                                              \
+    switch (c->scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    case 0: SCAN2(false, false, U); break;                           \
+    case 1: SCAN2(true, false, U); break;                            \
+    case 2: SCAN2(false, true, U); break;                            \
+    default: SCAN2(true, true, U); break;                            \
+    }
+        if (unroll == 1) { SCAN2_POLICY(1) } else if (unroll == 2) { SCAN2_POLICY(2) } else { SCAN2_POLICY(4) }
+#undef SCAN2_POLICY
+#undef SCAN2
+        return hipGetLastError();
+    }
+    const unsigned long long rounds = n >= 1024 ? (n - 1024) / kScanWaveWindows + 1 : 0;
     const unsigned grid = grid_for(c, rounds / ((kb / 64) * unroll) + 1, kb);
 #define SCAN_LAUNCH(AL, NL, NS, U) \
     kmer_scan_kernel<AL, NL, NS, U><<<grid, kb, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot)
@@ -575,7 +599,7 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
     case 2: SCAN_LAUNCH(true, false, true, U); break;              \
     default: SCAN_LAUNCH(true, true, true, U); break;              \
     }
-    if (!(aligned16(ref) && aligned16(dist))) {
+    if (!al) {
         SCAN_LAUNCH(false, false, false, 1);
     } else if (unroll == 1) {
         SCAN_POLICY(1)
@@ -727,6 +751,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "batch_abl")) { prev = c->batch_abl; if (value >= 0 && value <= 15) c->batch_abl = value; }
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
+    else if (!strcmp(key, "scan_impl")) { prev = c->scan_impl; if (value == 0 || value == 1) c->scan_impl = value; }
     else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
     else if (!strcmp(key, "reduce_mult")) { prev = (int)(c->reduce_blocks / (unsigned)c->num_cu); if (value >= 1 && value <= 32) c->reduce_blocks = (unsigned)c->num_cu * (unsigned)value; }
     else if (!strcmp(key, "num_variants")) { prev = kNumVariants; }
@@ -787,6 +812,32 @@ int bitnuc_kmer_hdist_scan_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, si
     unsigned long long *slot;
     if (int st = take_slot(c, 0, &slot, err)) return st;
     HIPCHK(launch_scan(c, d_ref, n, k, query, d_dist, slot));
+    return BITNUC_OK;
+}
+
+int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, size_t k, uint64_t query, unsigned tau, uint64_t *d_count, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k);
+    if (!d_count || (reinterpret_cast<uintptr_t>(d_count) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (k == 0 || n < k) { // no windows
+        HIPCHK(hipMemsetAsync(d_count, 0, sizeof(uint64_t), c->stream));
+        return BITNUC_OK;
+    }
+    if (!d_ref) return fail(err, BITNUC_UNSUPPORTED);
+    unsigned long long *slot;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
+    uint32_t ql, qh;
+    query_planes(query, k, &ql, &qh);
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+    // a resident grid (the accumulator's ticket needs every workgroup to arrive; 4 trips of 4 rounds per wave keep the tail short)
+    const unsigned long long want = rounds / ((kBlock / 64) * 4) + 1, cap = (unsigned long long)c->num_cu * 8;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    unsigned long long *res = reinterpret_cast<unsigned long long *>(d_count);
+    if (aligned16(d_ref)) kmer_scan2_kernel<true, true, false, 4, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
+    else kmer_scan2_kernel<false, false, false, 1, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
+    HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
 

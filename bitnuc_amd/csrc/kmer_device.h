@@ -259,6 +259,125 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
 }
 
 // ---------------------------------------------------------------------------------
+// scan, line-aligned rounds (round 2) + the fused `d <= tau` count
+// ---------------------------------------------------------------------------------
+// kmer_scan_kernel's rounds advance by 992 windows, so every wave-store of 992 distance bytes starts and ends in the
+// middle of a 128-byte line that the neighbouring wave also writes (and its 1 KiB load overlaps the next one by 32 B).
+// The decode kernels showed what such shared lines cost (batch_device.h, strip_drain).  Here a round is 1024 windows at a
+// 1024-byte aligned offset: all 64 lanes produce 16 windows, the store is eight whole lines, loads do not overlap.  The
+// 30-base halo of lanes 62/63 is the first two chunks of the NEXT round: inside a trip of UNROLL consecutive rounds they
+// are already in registers (two v_readlane + two v_and_or per round), and the trip's last round gets them from one
+// extra 16-byte load in lanes 0 and 1.
+// COUNT: SURVEY 8(d) cfg 5's optional fused output -- only the number of windows with d <= tau leaves the chip
+// (1 B read per window instead of 2 B moved): per window a compare-and-add instead of the byte pack, one u64 atomic per
+// workgroup, published by the last workgroup (single launch, accumulator zero between launches, as hdist_kernel).
+template <bool ALIGNED, bool NTLD, bool NTST, int UNROLL, bool COUNT>
+__global__ void __launch_bounds__(kBlock)
+kmer_scan2_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query,
+                  uint32_t ql, uint32_t qh, unsigned tau, uint8_t *__restrict__ dist, unsigned long long *__restrict__ result,
+                  unsigned long long *__restrict__ total /* zero between launches */, unsigned *__restrict__ ticket,
+                  unsigned long long *__restrict__ slot) {
+    const unsigned long long nwin = n - k + 1;                              // host guarantees 1 <= k <= 32, n >= k
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;       // round r reads bytes [1024 r, 1024 r + 1056)
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const uint32_t km = k == 32 ? ~0u : ((1u << k) - 1u);
+    const uint32_t m63 = lane == 63 ? ~0u : 0u;
+    uint32_t hits = 0;
+
+    for (unsigned long long r0 = wave * UNROLL; r0 < rounds; r0 += nwaves * UNROLL) {
+        const unsigned m = rounds - r0 < (unsigned long long)UNROLL ? (unsigned)(rounds - r0) : (unsigned)UNROLL; // valid rounds in this trip (wave-uniform)
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const unsigned long long r = r0 + u < rounds ? r0 + u : rounds - 1;
+            v[u] = load_group<NTLD, ALIGNED>(ref + (r << 10) + 16 * lane);
+        }
+        u32x4 hv = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+        if (lane < 2) hv = load_group<false, ALIGNED>(ref + ((r0 + m) << 10) + 16 * lane); // the halo of the trip's last round
+        uint32_t pl[UNROLL + 1];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            uint32_t bad = 0, la, lb, ha, hb;
+            planes8(v[u].x, v[u].y, bad, la, ha);
+            planes8(v[u].z, v[u].w, bad, lb, hb);
+            pl[u] = (la | (lb << 8)) | ((ha | (hb << 8)) << 15);
+            if (__builtin_expect(residue_is_bad(bad) && (unsigned)u < m, 0)) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+        }
+        {
+            uint32_t bad = 0, la, lb, ha, hb; // halo bytes are validated by the round (or tail) that owns them
+            planes8(hv.x, hv.y, bad, la, ha);
+            planes8(hv.z, hv.w, bad, lb, hb);
+            pl[UNROLL] = (la | (lb << 8)) | ((ha | (hb << 8)) << 15);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if ((unsigned)u >= m) break; // wave-uniform
+            const uint32_t nx = (unsigned)(u + 1) < m ? pl[u + 1] : pl[UNROLL]; // planes of the next 1 KiB (wave-uniform choice)
+            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)nx, 0), h1 = (uint32_t)__builtin_amdgcn_readlane((int)nx, 1);
+            // lane 63 of a wave_shl is 0 (bound_ctrl), so the halo goes in with one v_and_or.  NOT `lane == 63 ? h : shl(x)`: hipcc turns
+            // that select into a branch and runs the DPP move with lane 63 masked off, and a DPP read from a disabled lane returns 0.
+            const uint32_t n1 = wave_shl1(pl[u]) | (h0 & m63);
+            const uint32_t n2 = wave_shl1(n1) | (h1 & m63);
+            const uint32_t Llo = __builtin_amdgcn_perm(n1, pl[u], 0x05040100u);
+            const uint32_t Hlo = __builtin_amdgcn_perm(n1, pl[u], 0x07060302u);
+            const uint32_t Lhi = n2 & 0xFFFFu, Hhi = n2 >> 16;
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int j = 4 * q + b;
+                    const uint32_t l = j ? __builtin_amdgcn_alignbit(Lhi, Llo, j) : Llo;
+                    const uint32_t h = j ? __builtin_amdgcn_alignbit(Hhi, Hlo, j) : Hlo;
+                    const uint32_t dcount = __builtin_popcount(((l ^ ql) | (h ^ qh)) & km);
+                    if constexpr (COUNT) hits += dcount <= tau ? 1u : 0u;
+                    else acc |= dcount << (8 * b);
+                }
+                o[q] = acc;
+            }
+            if constexpr (!COUNT) {
+                const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                store_group<NTST, ALIGNED>(dist + ((r0 + u) << 10) + 16 * lane, ov);
+            }
+        }
+    }
+
+    // tail: one window per thread, byte loads
+    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (rounds << 10) + gt; i < nwin; i += nthreads) {
+        unsigned long long w = 0;
+        bool flagged = false;
+        for (unsigned b = 0; b < k; ++b) {
+            const uint32_t byte = ref[i + b];
+            if (!valid_base(byte) && !flagged) { latch_bad(slot, i + b, byte); flagged = true; }
+            w |= (unsigned long long)code_of(byte) << (2 * b);
+        }
+        const unsigned long long x = (w ^ query) & kmask;
+        const uint32_t d = (uint32_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);
+        if constexpr (COUNT) hits += d <= tau ? 1u : 0u;
+        else dist[i] = (uint8_t)d;
+    }
+    if constexpr (COUNT) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) hits += __shfl_xor(hits, off);
+        __shared__ uint32_t part[kBlock / 64];
+        if (lane == 0) part[threadIdx.x >> 6] = hits;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long s = 0;
+            for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
+            if (s) add_performed(total, s);
+            if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // every window of a sequence: as_2bit over seq.windows(k)  (stride == 1, src/lib.rs:170-173)
 // ---------------------------------------------------------------------------------
 // out[i] = as_2bit(seq[i .. i+k]) for consecutive i: 1 B read + 8 B written per window, so the kernel is

@@ -130,6 +130,9 @@ int bitnuc_encode_dev(bitnuc_ctx *ctx, const uint8_t *d_seq, size_t len, uint64_
 int bitnuc_decode_dev(bitnuc_ctx *ctx, const uint64_t *d_ebuf, size_t n_words, size_t n_bases, uint8_t *d_out, bitnuc_err *err);
 int bitnuc_as_2bit_batch_dev(bitnuc_ctx *ctx, const uint8_t *d_kmers, size_t k, size_t stride, size_t count, uint64_t *d_out, bitnuc_err *err);
 int bitnuc_kmer_hdist_scan_dev(bitnuc_ctx *ctx, const uint8_t *d_ref, size_t n, size_t k, uint64_t query, uint8_t *d_dist, bitnuc_err *err);
+/* The same scan with the fused threshold of SURVEY 8(d) cfg 5: *d_count (one uint64 in device memory) = number of windows i with
+ * hdist_scalar(as_2bit(ref[i..i+k]), query, k) <= tau.  No distance bytes are written: 1 byte read per window. */
+int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *ctx, const uint8_t *d_ref, size_t n, size_t k, uint64_t query, unsigned tau, uint64_t *d_count, bitnuc_err *err);
 /* d_result: one uint32 in device memory, overwritten with the distance. */
 int bitnuc_hdist_dev(bitnuc_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, size_t n_bases, uint32_t *d_result, bitnuc_err *err);
 

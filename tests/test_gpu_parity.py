@@ -463,16 +463,64 @@ def test_kmer_batch_errors(ctx, oracle):
     assert np.array_equal(ctx.as_2bit_batch(b"", 0, 1, 5), np.zeros(5, np.uint64))
 
 
+@pytest.mark.parametrize("impl", [1, 0], ids=["rounds1024", "rounds992"])
 @pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 32])
-def test_scan_vs_oracle(ctx, oracle, k, unroll):
+def test_scan_vs_oracle(ctx, oracle, k, unroll, impl):
+    prev_impl = ctx.set_variant("scan_impl", impl)
     ctx.set_variant("scan_unroll", unroll)
-    for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 2015, 2016, 2017, 2047, 2048, 5000, 200003]:
+    for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 1057, 2015, 2016, 2017, 2047, 2048, 2079, 2080, 2081, 4127, 4128, 4129, 5000, 5152, 200003]:
         s = rand_seq(n)
         q = int(RNG.integers(0, 1 << 62)) | (int(RNG.integers(0, 4)) << 62)
         got = ctx.kmer_hdist_scan(s, k, q)
         assert np.array_equal(got, oracle.kmer_hdist_scan(s, k, q)), (k, n)
     ctx.set_variant("scan_unroll", 4)
+    ctx.set_variant("scan_impl", prev_impl)
+
+
+def test_scan_fused_threshold_count(ctx, oracle):
+    """bitnuc_kmer_hdist_count_dev: the number of windows with d <= tau equals the count over the distance bytes of the
+    plain scan (oracle), at sizes around the 1024-window rounds and their 32-byte halo, for several k and tau."""
+    import torch
+    dev = torch.device("cuda:0")
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    for n in (31, 40, 1055, 1056, 1057, 2079, 2080, 2081, 4 * 1024 + 32, 16 * 1024 + 31, 100003, 1 << 20):
+        s = rand_seq(n)
+        t = torch.from_numpy(s).to(dev)
+        for k, tau in ((31, 20), (31, 0), (32, 24), (16, 9), (1, 0), (7, 7)):
+            if n < k:
+                continue
+            q = int(RNG.integers(0, 1 << 62)) & ((1 << (2 * k)) - 1)
+            if tau == 0 and n > 2000:  # plant exact matches so that the tau = 0 count is not trivially zero
+                q = oracle.as_2bit(s[1500:1500 + k])
+            torch.cuda.synchronize()
+            ctx.kmer_hdist_count_dev(t, n, k, q, tau, cnt)
+            ctx.sync()
+            d = oracle.kmer_hdist_scan(s, k, q)
+            assert int(cnt.item()) == int((d <= tau).sum()), (n, k, tau)
+    # back-to-back launches reuse the context's accumulator (it must be zero again after each launch)
+    for _ in range(3):
+        ctx.kmer_hdist_count_dev(t, n, k, q, tau, cnt)
+    ctx.sync()
+    assert int(cnt.item()) == int((d <= tau).sum())
+    # unaligned reference pointer, no windows, invalid base
+    buf = torch.from_numpy(np.concatenate([np.zeros(3, np.uint8), s])).to(dev)
+    torch.cuda.synchronize()
+    ctx.kmer_hdist_count_dev(buf.data_ptr() + 3, n, k, q, tau, cnt)
+    ctx.sync()
+    assert int(cnt.item()) == int((d <= tau).sum())
+    ctx.kmer_hdist_count_dev(t, 5, 31, 0, 3, cnt)
+    ctx.sync()
+    assert int(cnt.item()) == 0
+    import bitnuc_amd as bn
+    bad = s.copy()
+    bad[70000] = ord("N")
+    tb = torch.from_numpy(bad).to(dev)
+    torch.cuda.synchronize()
+    ctx.kmer_hdist_count_dev(tb, n, 31, 0, 3, cnt)
+    with pytest.raises(bn.NucleotideError) as ei:
+        ctx.sync()
+    assert (ei.value.byte, ei.value.index) == (ord("N"), 70000)
 
 
 def test_scan_errors_and_bench_invariant(ctx, oracle):

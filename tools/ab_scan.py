@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""In-process A/B of a context knob on the config-5 scan (default: scan_v2 0 vs 1)."""
+"""In-process A/B of the scan kernels: rounds of 992 windows (kmer_scan_kernel) vs line-aligned rounds of 1024
+(kmer_scan2_kernel), cache policies and rounds in flight, and the fused d <= tau count.  Sustained bursts, 10^9 bases, k = 31."""
 import os
 import statistics
 import sys
@@ -9,30 +10,59 @@ import torch
 
 import bitnuc_amd
 
-key = sys.argv[1] if len(sys.argv) > 1 else "scan_v2"
-values = [int(v) for v in sys.argv[2:]] or [0, 1]
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
 ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
 n, k = 10**9, 31
-ref = torch.empty(n, dtype=torch.uint8, device=dev)
-ctx.nucgen_dev(ref, n, 1)
-dist = {v: torch.empty(n - k + 1, dtype=torch.uint8, device=dev) for v in values}
 q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
-res = {v: [] for v in values}
-for rnd in range(9):
-    for v in values:
-        ctx.set_variant(key, v)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
-        ev[0].record(stream)
-        for i in range(6):
-            ctx.kmer_hdist_scan_dev(ref, n, k, q, dist[v])
-            ev[i + 1].record(stream)
-        torch.cuda.synchronize()
-        res[v].append(statistics.mean(ev[i].elapsed_time(ev[i + 1]) for i in range(2, 6)))
+refs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
+dists = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
+for i, r in enumerate(refs):
+    ctx.nucgen_dev(r, n, 0xB17C0DE + i)
+cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 ctx.sync()
-for v in values[1:]:
-    assert torch.equal(dist[values[0]], dist[v])
-for v in values:
-    ms = statistics.median(res[v])
-    print(f"{key}={v}: {ms:.4f} ms  {2 * (n - k + 1) / ms / 1e6:.0f} GB/s", flush=True)
+BURST = 8
+flip = [0]
+
+
+def burst(fn):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    a.record(stream)
+    for _ in range(BURST):
+        fn()
+    b.record(stream)
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / BURST
+
+
+def scan():
+    flip[0] ^= 1
+    ctx.kmer_hdist_scan_dev(refs[flip[0]], n, k, q, dists[flip[0]])
+
+
+def count():
+    flip[0] ^= 1
+    ctx.kmer_hdist_count_dev(refs[flip[0]], n, k, q, 8, cnt)
+
+
+configs = [(impl, pol, un) for impl in (0, 1) for pol in (3, 1) for un in (2, 4)]
+res = {c: [] for c in configs}
+res["count"] = []
+for rnd in range(6):
+    for c in configs:
+        ctx.set_variant("scan_impl", c[0])
+        ctx.set_variant("scan_policy", c[1])
+        ctx.set_variant("scan_unroll", c[2])
+        t = burst(scan)
+        if rnd:
+            res[c].append(t)
+    t = burst(count)
+    if rnd:
+        res["count"].append(t)
+nwin = n - k + 1
+for c in configs:
+    m = statistics.median(res[c])
+    print(f"impl {c[0]} ({'1024-window aligned rounds' if c[0] else '992-window rounds          '}) policy {c[1]} unroll {c[2]}: {m:.4f} ms  {2*nwin/m/1e6:6.0f} GB/s  {nwin/m/1e6:5.0f} Gwin/s")
+m = statistics.median(res["count"])
+print(f"fused d<=tau count: {m:.4f} ms  {nwin/m/1e6:6.0f} GB/s (1 B/window)  {nwin/m/1e6:5.0f} Gwin/s   count={int(cnt.item())}")
