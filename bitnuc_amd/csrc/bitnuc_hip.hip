@@ -467,10 +467,40 @@ hipError_t launch_decode_t(bitnuc_ctx *c, const uint32_t *in32, uint8_t *out, un
     return hipGetLastError();
 }
 
+// decode variants 47..54: decode_x2_kernel (8-byte loads + LDS transpose) for the whole 2 KiB wave tiles, the default
+// decode_kernel for what is left.  id - 47: bit 0 = nt loads, bit 1 = plain (not nt) stores, bit 2 = 2 words in flight per lane.
+constexpr int kX2First = 47, kX2Last = 54;
+template <int UNROLL>
+hipError_t launch_decode_x2_t(bitnuc_ctx *c, int mode, const unsigned long long *w, uint8_t *out, unsigned long long tiles) {
+    constexpr int B = 256;
+    const unsigned long long per = (unsigned long long)(B / 64) * UNROLL;
+    const unsigned grid = (unsigned)((tiles + per - 1) / per);
+    switch (mode & 3) {
+    case 0: decode_x2_kernel<B, UNROLL, false, true><<<grid, B, 0, c->stream>>>(w, out, tiles); break;
+    case 1: decode_x2_kernel<B, UNROLL, true, true><<<grid, B, 0, c->stream>>>(w, out, tiles); break;
+    case 2: decode_x2_kernel<B, UNROLL, false, false><<<grid, B, 0, c->stream>>>(w, out, tiles); break;
+    default: decode_x2_kernel<B, UNROLL, true, false><<<grid, B, 0, c->stream>>>(w, out, tiles); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsigned long long n_bases) {
-    const uint32_t *i = reinterpret_cast<const uint32_t *>(ebuf);
     const bool in_al = aligned16(ebuf), out_al = aligned16(out);
+    if (c->dec_variant >= kX2First && c->dec_variant <= kX2Last && out_al) {
+        const unsigned long long tiles = n_bases >> 11; // whole 2 KiB (64-word) wave tiles
+        if (tiles) {
+            const int mode = c->dec_variant - kX2First;
+            const unsigned long long *w = reinterpret_cast<const unsigned long long *>(ebuf);
+            const hipError_t rc = (mode & 4) ? launch_decode_x2_t<2>(c, mode, w, out, tiles) : launch_decode_x2_t<1>(c, mode, w, out, tiles);
+            if (rc != hipSuccess) return rc;
+        }
+        const unsigned long long done = tiles << 11;
+        if (done == n_bases) return hipSuccess;
+        return launch_decode_t<2, 256, false, true, false, false>(c, reinterpret_cast<const uint32_t *>(ebuf) + (done >> 4), out + done, n_bases - done, true);
+    }
+    const uint32_t *i = reinterpret_cast<const uint32_t *>(ebuf);
     int v = c->dec_variant;
+    if (v >= kX2First) v = kDefaultDec; // x2 asked for an unaligned output: the default kernel handles any alignment
     if (variant_info(v).xpose && !in_al) v = kDefaultDec;
     switch (v) {
 #define X(id, U, B, NL, NS, XP, XC) \
@@ -727,7 +757,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
             c->enc_variant = value;
         }
     }
-    else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0) { if (!variant_info(value).built) return -2; c->dec_variant = value; } }
+    else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0) { if (!(value >= kX2First && value <= kX2Last) && !variant_info(value).built) return -2; c->dec_variant = value; } }
     else if (!strcmp(key, "force_gpu")) { prev = c->force_gpu; if (value == 0 || value == 1) c->force_gpu = value; }
     else if (!strcmp(key, "host_cutoff")) { prev = (int)(c->host_cutoff > 0x7FFFFFFF ? 0x7FFFFFFF : c->host_cutoff); if (value >= 0) c->host_cutoff = (size_t)value; }
     else if (!strcmp(key, "host_pipeline")) { prev = c->host_pipeline; if (value == 0 || value == 1) c->host_pipeline = value; }

@@ -102,6 +102,12 @@ __device__ __forceinline__ unsigned wave_in_block() { return (unsigned)__builtin
 // before, no finishing launch after.
 // Call draw_last_ticket from ONE thread, after a __syncthreads() that follows the workgroup's
 // add_performed() calls.
+// Ordering argument (why relaxed atomics suffice, no fence): every access to the accumulators and the ticket is a
+// device-scope atomic RMW, performed at the L2 / memory side in arrival order, never a cached load or store.  add_performed
+// uses the RETURNING form and consumes the returned value, so the wave cannot reach the barrier before its add has been
+// performed at the coherence point; the ticket RMW is issued after that barrier, hence after every add of its workgroup.
+// The workgroup that draws the last ticket therefore reads (atomicExch) accumulators that already hold every workgroup's
+// contribution.  Nothing else is communicated between workgroups (no plain data), which is what a fence would be for.
 template <class T> __device__ __forceinline__ void add_performed(T *acc, T v) {
     const T prev = atomicAdd(acc, v); // returning form: the value can only arrive once the add has been performed
     if constexpr (sizeof(T) == 8) asm volatile("" ::"v"((uint32_t)prev), "v"((uint32_t)(prev >> 32)));
@@ -377,6 +383,42 @@ decode_kernel(const uint32_t *__restrict__ in32, uint8_t *__restrict__ out, unsi
                 for (unsigned i = 0; i < rem; ++i) out[(n16 << 4) + i] = "ACGT"[(w >> (2 * i)) & 3];
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// decode, 8-byte loads (round 2)
+// ---------------------------------------------------------------------------------
+// decode_kernel's loads are 4 bytes per lane (256 B per wave-instruction); the read side is only a fifth of the traffic but its
+// requests are small.  Here a lane loads one whole u64 word (512 B per wave-instruction, one load per 2 KiB of output); the
+// wave's 64 words cross a wave-private LDS strip once (ds_write_b64 at [lane], ds_read_b32 at [lane] and [64 + lane]: both
+// conflict-free) so that each of the two stores is still one contiguous 1 KiB span.  WAVES_PER_ROUND independent words per
+// lane are in flight.  Only whole 2 KiB wave tiles; the caller finishes the tail with decode_kernel.
+template <int BLOCK, int UNROLL, bool NTLD, bool NTST>
+__global__ void __launch_bounds__(BLOCK)
+decode_x2_kernel(const unsigned long long *__restrict__ words, uint8_t *__restrict__ out, unsigned long long n_tiles /* of 64 words */) {
+    __shared__ unsigned long long strips[BLOCK / 64][UNROLL][64];
+    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
+    constexpr unsigned long long PER_BLOCK = (unsigned long long)(BLOCK / 64) * UNROLL;
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * PER_BLOCK + (unsigned long long)wave * UNROLL;
+    unsigned long long w[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const unsigned long long t = t0 + u < n_tiles ? t0 + u : n_tiles - 1;
+        const unsigned long long *p = words + t * 64 + lane;
+        if constexpr (NTLD) w[u] = __builtin_nontemporal_load(p); else w[u] = *p;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) strips[wave][u][lane] = w[u];
+    wave_lds_fence();
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        if (t0 + u >= n_tiles) break; // wave-uniform
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(strips[wave][u]);
+        const uint32_t h0 = s32[lane], h1 = s32[64 + lane];
+        uint8_t *dst = out + (t0 + u) * 2048;
+        store_group<NTST, true>(dst + 16 * lane, dec16(h0));
+        store_group<NTST, true>(dst + 16 * (lane + 64), dec16(h1));
     }
 }
 

@@ -136,6 +136,7 @@ kmer_dense_kernel(const uint8_t *__restrict__ kmers, unsigned k, unsigned long l
             uint32_t bad = 0;
             ws[lane] = enc16(v0[u], bad);
             ws[lane + 64] = enc16(v1[u], bad);
+            if (lane < 4) ws[128 + lane] = 0u; // k = 32: lane 63's funnel reads ws[128] (masked off by kmask, but no read of unwritten LDS)
             wave_lds_fence();
             const uint32_t w0 = ws[d], w1 = ws[d + 1], w2 = ws[d + 2];
             wave_lds_fence();

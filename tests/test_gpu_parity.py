@@ -137,6 +137,18 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     ctx.set_variant("encode", 14)
     assert built == [0, 3, 14, 22]
     assert ctx.set_variant("encode", 100) == -2 and ctx.get("encode") == 14  # the ballot formulation is evidence, not product
+    # decode variants 47..54: 8-byte loads + LDS transpose (decode_x2_kernel) for the whole 2 KiB tiles, default kernel for the tail
+    dec0 = ctx.get("decode")
+    try:
+        for v in range(47, 55):
+            assert ctx.set_variant("decode", v) != -2
+            for n in SIZES + [2047, 2048, 2049, 4096 * 5 + 31, (1 << 21) + 2048 + 17]:
+                s = rand_seq(n)
+                w = oracle.encode(s)
+                assert np.array_equal(ctx.decode_array(w, n), oracle.decode(w, n)), (v, n)
+    finally:
+        ctx.set_variant("decode", dec0)
+    assert ctx.set_variant("decode", 55) == -2
     for v in built:
         enc0, dec0 = ctx.set_variant("encode", v), ctx.set_variant("decode", v)
         try:

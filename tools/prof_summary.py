@@ -7,9 +7,23 @@ KiB, collected in separate --pmc passes; on gfx950 FETCH_SIZE reports exactly ha
 bytes of a coalesced streaming read, so it is doubled; WRITE_SIZE is taken as is."""
 import collections
 import csv
+import datetime
+import hashlib
 import json
 import os
+import subprocess
 import sys
+
+
+def csrc_sha16(root):
+    """Same identity bench.py computes: a stored traffic figure is only valid for these kernel sources."""
+    h = hashlib.sha256()
+    d = os.path.join(root, "bitnuc_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kernel_short(name):
@@ -21,9 +35,10 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_md = os.path.join(root, "profiles", f"{tag}_summary.md")
-    lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline`",
+    lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-traffic --no-extras` (the timed step only)",
              "(PMC passes: same command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separately; no trace domains combined with --pmc.)", "",
              "## kernel stats (--kernel-trace --stats)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+    lines[3] = "(PMC passes: same command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separately; no trace domains combined with --pmc.  `kernel_stats_full_run.csv`: the same trace of the default run, side measurements included.)"
     stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
     avg = {}
     for r in stats:
@@ -42,7 +57,7 @@ def main():
               "| kernel | launches | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes/launch = (2*FETCH + WRITE)*1024 |", "|---|---|---|---|---|"]
     traffic = {}
     for k, d in pmc.items():
-        if "encode_kernel" not in k and "decode_kernel" not in k and "kmer" not in k:
+        if not any(t in k for t in ("encode_kernel", "decode_kernel", "kmer", "batch", "fixed")):
             continue
         f = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))
         w = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
@@ -59,7 +74,12 @@ def main():
                       f"decode {1.25e9/dec_us:.1f} GB/s = {1.25e9/dec_us/8000*100:.1f}% of 8 TB/s"]
     os.makedirs(os.path.dirname(out_md), exist_ok=True)
     open(out_md, "w").write("\n".join(lines) + "\n")
-    json.dump({"tag": tag, "encode_bytes_per_launch": enc, "decode_bytes_per_launch": dec,
+    try:
+        commit = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        commit = None
+    json.dump({"tag": tag, "commit": commit, "date": datetime.date.today().isoformat(), "csrc_sha16": csrc_sha16(root),
+               "encode_bytes_per_launch": enc, "decode_bytes_per_launch": dec,
                "encode_avg_ns": enc_us, "decode_avg_ns": dec_us,
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts half of a coalesced stream)"},
               open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1)
