@@ -1,6 +1,6 @@
 //! `extern "C"` declarations for include/bitnuc_hip.h (one per exported symbol).
 #![allow(non_camel_case_types)]
-use std::os::raw::{c_char, c_int, c_void};
+use std::os::raw::{c_char, c_int, c_uint, c_void};
 
 pub const BITNUC_OK: c_int = 0;
 pub const BITNUC_INVALID_BASE: c_int = 1;
@@ -26,6 +26,11 @@ pub struct bitnuc_err {
 
 #[repr(C)]
 pub struct bitnuc_ctx {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct bitnuc_batch_plan {
     _private: [u8; 0],
 }
 
@@ -88,4 +93,18 @@ extern "C" {
     pub fn bitnuc_encode_sharded_allgather_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, d_seq_shards: *const *const u8, shard_len: usize, d_alls: *const *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_nucgen_dev(ctx: *mut bitnuc_ctx, d_out: *mut u8, len: usize, seed: u64, first: u64, flags: c_int, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_stream_probe_dev(ctx: *mut bitnuc_ctx, mode: c_int, d_src: *const c_void, d_dst: *mut c_void, bytes: usize, err: *mut bitnuc_err) -> c_int;
+    // layout plan of a ragged batch (include/bitnuc_hip.h): built once per offsets table, used by every encode / decode of it
+    pub fn bitnuc_batch_plan_create(ctx: *mut bitnuc_ctx, out: *mut *mut bitnuc_batch_plan, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_batch_plan_build_dev(ctx: *mut bitnuc_ctx, plan: *mut bitnuc_batch_plan, d_offsets: *const u64, count: usize, total_words: *mut usize, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_batch_plan_destroy(plan: *mut bitnuc_batch_plan);
+    pub fn bitnuc_batch_plan_total_words(plan: *const bitnuc_batch_plan) -> usize;
+    pub fn bitnuc_batch_plan_count(plan: *const bitnuc_batch_plan) -> usize;
+    pub fn bitnuc_batch_plan_word_offsets_dev(plan: *const bitnuc_batch_plan) -> *const u64;
+    pub fn bitnuc_encode_batch_plan_dev(ctx: *mut bitnuc_ctx, plan: *const bitnuc_batch_plan, d_seq: *const u8, d_out: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_decode_batch_plan_dev(ctx: *mut bitnuc_ctx, plan: *const bitnuc_batch_plan, d_words: *const u64, d_out: *mut u8, err: *mut bitnuc_err) -> c_int;
+    // fused scan threshold (SURVEY 8d cfg 5): number of windows with distance <= tau
+    pub fn bitnuc_kmer_hdist_count_dev(ctx: *mut bitnuc_ctx, d_ref: *const u8, n: usize, k: usize, query: u64, tau: c_uint, d_count: *mut u64, err: *mut bitnuc_err) -> c_int;
+    // diagnostics
+    pub fn bitnuc_selftime_small(op: c_int, n: usize, iters: usize) -> f64;
+    pub fn bitnuc_selftime_host_copy(bytes: usize, threads: c_int, mode: c_int) -> f64;
 }

@@ -90,7 +90,8 @@ fn with_ctx<R>(f: impl FnOnce(*mut ffi::bitnuc_ctx) -> R) -> R {
 pub fn as_2bit(seq: &[u8]) -> Result<u64, NucleotideError> {
     let mut out = 0u64;
     let mut e = ffi::bitnuc_err::default();
-    let st = with_ctx(|c| unsafe { ffi::bitnuc_as_2bit(c, seq.as_ptr(), seq.len(), &mut out, &mut e) });
+    // context-free: single words are host code inside the library (include/bitnuc_hip.h, "Size dispatch"), like the reference's #[inline(always)] function
+    let st = unsafe { ffi::bitnuc_as_2bit(std::ptr::null_mut(), seq.as_ptr(), seq.len(), &mut out, &mut e) };
     if st == ffi::BITNUC_OK { Ok(out) } else { Err(to_err(&e)) }
 }
 
@@ -98,7 +99,7 @@ pub fn as_2bit(seq: &[u8]) -> Result<u64, NucleotideError> {
 pub fn from_2bit(packed: u64, expected_size: usize, sequence: &mut Vec<u8>) -> Result<(), NucleotideError> {
     let mut tmp = [0u8; 32];
     let mut e = ffi::bitnuc_err::default();
-    let st = with_ctx(|c| unsafe { ffi::bitnuc_from_2bit(c, packed, expected_size, tmp.as_mut_ptr(), &mut e) });
+    let st = unsafe { ffi::bitnuc_from_2bit(std::ptr::null_mut(), packed, expected_size, tmp.as_mut_ptr(), &mut e) };
     if st != ffi::BITNUC_OK {
         return Err(to_err(&e));
     }
@@ -156,7 +157,7 @@ pub fn decode(ebuf: &[u64], n_bases: usize, dbuf: &mut Vec<u8>) -> Result<(), Nu
 pub fn hdist_scalar(u: u64, v: u64, len: usize) -> Result<u32, NucleotideError> {
     let mut out = 0u32;
     let mut e = ffi::bitnuc_err::default();
-    let st = with_ctx(|c| unsafe { ffi::bitnuc_hdist_scalar(c, u, v, len, &mut out, &mut e) });
+    let st = unsafe { ffi::bitnuc_hdist_scalar(std::ptr::null_mut(), u, v, len, &mut out, &mut e) };
     if st == ffi::BITNUC_OK { Ok(out) } else { Err(to_err(&e)) }
 }
 
