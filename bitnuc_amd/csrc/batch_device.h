@@ -497,14 +497,14 @@ __device__ __forceinline__ void strip_zero(uint32_t *strip, unsigned lane) {
 }
 // OR the low 2*nb bits of `word` into the strip at bit offset `bit` (even, < 32 * (kStripDwords - 2))
 __device__ __forceinline__ void strip_or_word(uint32_t *strip, unsigned bit, unsigned long long word, unsigned nb) {
-    const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
-    const unsigned long long v = word & keep;
+    const unsigned drop = 64u - 2u * nb;                      // 0 for a full word: both shifts are then the identity
+    const unsigned long long v = (word << drop) >> drop;      // bits above 2*nb are ignored, like the reference's decode
     const unsigned sh = bit & 31;
     const unsigned long long t = v << sh; // bits 0..63 of the 96-bit shifted value; the rest is the third dword
     uint32_t *dst = strip + (bit >> 5);
     atomicOr(dst, (uint32_t)t);
     atomicOr(dst + 1, (uint32_t)(t >> 32));
-    atomicOr(dst + 2, sh ? (uint32_t)(v >> 32) >> (32 - sh) : 0u);
+    atomicOr(dst + 2, ((uint32_t)(v >> 32) >> 1) >> (31u - sh)); // == (v >> 32) >> (32 - sh), and 0 for sh == 0, without a select
 }
 // strip dword c is the 16-byte chunk at lo16 + 16c: decode and store it.  The run's first / last chunk is shared with the
 // neighbouring tiles when lo / hi are not 16-byte aligned.  Those two edges are NOT written byte by byte (that cost ~30
@@ -903,8 +903,9 @@ encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long lo
     }
 }
 
-// ABL: timing-only ablations (wrong output): 1 = plain stores instead of the three ds_or, 2 = no strip zeroing, 4 = no edge stores
-template <int ABL, int POLICY = 2>
+// U = tiles per wave trip: the loads of U consecutive tiles (word, pad byte, tile base) are issued before the first is
+// processed, and the line shared by two of the wave's own tiles is written by one wave.
+template <int POLICY, int U>
 __global__ void __launch_bounds__(kBlock)
 decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
                          unsigned long long total_words, uint8_t *__restrict__ out) {
@@ -914,40 +915,46 @@ decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const uns
     uint32_t *strip = strips[wave];
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
     const uintptr_t op = reinterpret_cast<uintptr_t>(out);
-    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave; tile < ntiles;
-         tile += (unsigned long long)gridDim.x * kBatchWaves) {
-        const unsigned long long wb = tile * kBatchTile;
-        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
-        const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last));
-        const uint32_t n = lane <= last ? (uint32_t)P[wb + lane + 1] : 0u;
-        const unsigned long long base0 = tile_base[tile];
-        const uintptr_t lo = op + base0, lo16 = lo & ~(uintptr_t)15;
-        if (__ballot(n != 0u) == 0ull && last == 63u && (lo & 15) == 0) {
-            // fast tile (wave-uniform): the words cross the strip once so that lane l owns 16-base groups l and l+64
-            wave_lds_fence();
-            reinterpret_cast<unsigned long long *>(strip)[lane] = word;
-            wave_lds_fence();
-            const uint32_t h0 = strip[lane], h1 = strip[64 + lane];
-            uint8_t *dst = out + base0;
-            store_group<true, true>(dst + 16 * lane, dec16(h0));
-            store_group<true, true>(dst + 16 * (lane + 64), dec16(h1));
-            continue;
+    for (unsigned long long t0 = ((unsigned long long)blockIdx.x * kBatchWaves + wave) * U; t0 < ntiles;
+         t0 += (unsigned long long)gridDim.x * kBatchWaves * U) {
+        unsigned long long word[U], base0[U];
+        uint32_t n[U];
+        unsigned last[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long tile = t0 + u < ntiles ? t0 + u : ntiles - 1; // clamp: redundant but in bounds
+            const unsigned long long wb = tile * kBatchTile;
+            last[u] = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+            word[u] = __builtin_nontemporal_load(words + wb + (lane < last[u] ? lane : last[u]));
+            n[u] = lane <= last[u] ? (uint32_t)P[wb + lane + 1] : 0u;
+            base0[u] = tile_base[tile];
         }
-        wave_lds_fence(); // the previous trip's strip readers are done
-        if constexpr (!(ABL & 2)) strip_zero(strip, lane);
-        const uint32_t incl = wave_inclusive_sum(n);
-        const unsigned base_rel = 32u * lane - (incl - n), nb = 32u - n;
-        const unsigned end_rel = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)last);
-        uintptr_t hi = lo + end_rel, lo_w = lo;
-        if constexpr (ABL & 4) { lo_w = (lo + 15) & ~(uintptr_t)15; hi &= ~(uintptr_t)15; }
-        wave_lds_fence();
-        if constexpr (ABL & 1) {
-            if (lane <= last) { uint32_t *dst = strip + ((2u * ((unsigned)(lo - lo16) + base_rel)) >> 5); dst[0] = (uint32_t)word; dst[1] = (uint32_t)(word >> 32); dst[2] = nb; }
-        } else {
-            if (lane <= last) strip_or_word(strip, 2u * ((unsigned)(lo - lo16) + base_rel), word, nb);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t0 + u >= ntiles) break; // wave-uniform
+            const uintptr_t lo = op + base0[u], lo16 = lo & ~(uintptr_t)15;
+            if (__ballot(n[u] != 0u) == 0ull && last[u] == 63u && (lo & 15) == 0) {
+                // fast tile (wave-uniform): the words cross the strip once so that lane l owns 16-base groups l and l+64
+                wave_lds_fence();
+                reinterpret_cast<unsigned long long *>(strip)[lane] = word[u];
+                wave_lds_fence();
+                const uint32_t h0 = strip[lane], h1 = strip[64 + lane];
+                uint8_t *dst = out + base0[u];
+                store_group<true, true>(dst + 16 * lane, dec16(h0));
+                store_group<true, true>(dst + 16 * (lane + 64), dec16(h1));
+                continue;
+            }
+            wave_lds_fence(); // the previous tile's strip readers are done
+            strip_zero(strip, lane);
+            const uint32_t incl = wave_inclusive_sum(n[u]);
+            const unsigned base_rel = 32u * lane - (incl - n[u]), nb = 32u - n[u];
+            const unsigned end_rel = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)last[u]);
+            const uintptr_t hi = lo + end_rel;
+            wave_lds_fence();
+            if (lane <= last[u]) strip_or_word(strip, 2u * ((unsigned)(lo - lo16) + base_rel), word[u], nb);
+            wave_lds_fence();
+            if (hi > lo) strip_drain<POLICY>(strip, edge[wave], out, lo16, lo, hi, lane);
         }
-        wave_lds_fence();
-        if (hi > lo_w) strip_drain<POLICY>(strip, edge[wave], out, lo16, lo_w, hi, lane);
     }
 }
 

@@ -70,6 +70,7 @@ struct bitnuc_ctx {
     int owner_est = 3;                     // block_owner_kernel's first guess: 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, 3 = 2 or 0 by average sequence length
     int batch_host_plan = 1;               // host-pointer ragged-batch calls build a layout plan (bitnuc_batch_plan) and use the plan kernels
     bitnuc_batch_plan *host_plan = nullptr; // ... kept by the context
+    int plan_tiles = 1;                    // decode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
     int plan_store = 2;                    // decode_batch_plan_kernel's whole-chunk store policy: 0 nt, 1 plain, 2 plain on the shared edge lines + nt elsewhere
     int batch_abl = 0;                     // timing-only ablation mask of the second formulation (tools/ab_batch_ablate.py); 0 in normal use
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
@@ -777,8 +778,16 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value == 0 || value == 1) c->fixed_dec_strip = value; }
     else if (!strcmp(key, "owner_est")) { prev = c->owner_est; if (value >= 0 && value <= 3) c->owner_est = value; }
     else if (!strcmp(key, "batch_host_plan")) { prev = c->batch_host_plan; if (value == 0 || value == 1) c->batch_host_plan = value; }
+    else if (!strcmp(key, "plan_tiles")) { prev = c->plan_tiles; if (value == 1 || value == 2 || value == 4) c->plan_tiles = value; }
     else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && value <= 2) c->plan_store = value; }
-    else if (!strcmp(key, "batch_abl")) { prev = c->batch_abl; if (value >= 0 && value <= 15) c->batch_abl = value; }
+    else if (!strcmp(key, "batch_abl")) {
+        prev = c->batch_abl;
+#ifdef BITNUC_SWEEP_VARIANTS
+        if (value >= 0 && value <= 15) c->batch_abl = value;
+#else
+        if (value > 0) return -2; // ablated kernels exist in the evidence build only
+#endif
+    }
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
     else if (!strcmp(key, "scan_impl")) { prev = c->scan_impl; if (value == 0 || value == 1) c->scan_impl = value; }
@@ -1273,10 +1282,12 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t 
     if (int st = take_slot(c, 0, &slot, err)) return st;
     const size_t per_block = (size_t)kBatchTile * kBatchWaves;
     const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
-    switch (c->batch_abl) { // timing-only ablations (tools/ab_batch_ablate.py): anything but 0 produces wrong words
+    switch (c->batch_abl) {
+#ifdef BITNUC_SWEEP_VARIANTS // timing-only ablations (tools/ab_batch_ablate.py, evidence build only): anything but 0 produces wrong words
 #define ABL_CASE(A) case A: encode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot); break;
     ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11)
 #undef ABL_CASE
+#endif
     default: encode_batch2_kernel<0><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot);
     }
     HIPCHK(hipGetLastError());
@@ -1296,9 +1307,11 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64
     const size_t per_block = (size_t)kBatchTile * kBatchWaves;
     const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
     switch (c->batch_abl) {
+#ifdef BITNUC_SWEEP_VARIANTS
 #define ABL_CASE(A) case A: decode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out); break;
     ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11) ABL_CASE(15)
 #undef ABL_CASE
+#endif
     default: decode_batch2_kernel<0><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out);
     }
     HIPCHK(hipGetLastError());
@@ -1501,18 +1514,17 @@ int bitnuc_decode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, cons
     if (p->total_words == 0) return BITNUC_OK;
     if (!d_words || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
-    const unsigned grid = grid_for(c, (p->total_words + per_block - 1) / per_block);
     const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
-    switch (c->batch_abl) { // timing-only ablations: anything but 0 produces wrong bases
-#define ABL_CASE(A) case A: decode_batch_plan_kernel<A><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out); break;
-    ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(6) ABL_CASE(7)
-#undef ABL_CASE
-    default:
-        if (c->plan_store == 0) decode_batch_plan_kernel<0, 0><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out);
-        else if (c->plan_store == 1) decode_batch_plan_kernel<0, 1><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out);
-        else decode_batch_plan_kernel<0, 2><<<grid, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out);
-    }
+    const int tiles_per_wave = c->plan_tiles;
+    const size_t per_block2 = (size_t)kBatchTile * kBatchWaves * (size_t)tiles_per_wave;
+    const unsigned grid2 = grid_for(c, (p->total_words + per_block2 - 1) / per_block2);
+#define PLAN_DEC(POL, U) decode_batch_plan_kernel<POL, U><<<grid2, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out)
+#define PLAN_DEC_U(POL) do { if (tiles_per_wave == 1) PLAN_DEC(POL, 1); else if (tiles_per_wave == 2) PLAN_DEC(POL, 2); else PLAN_DEC(POL, 4); } while (0)
+    if (c->plan_store == 0) PLAN_DEC_U(0);
+    else if (c->plan_store == 1) PLAN_DEC_U(1);
+    else PLAN_DEC_U(2);
+#undef PLAN_DEC_U
+#undef PLAN_DEC
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }

@@ -12,7 +12,8 @@ import bitnuc_amd
 
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
-ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+from bitnuc_amd import build as _b
+ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=_b.ensure_built(sweep=True))  # the ablated kernels live in the evidence build
 N, L = 10**9, 150
 count = N // L
 seq = torch.empty(N, dtype=torch.uint8, device=dev)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing-only ablations of decode_batch_plan_kernel on 150-base reads, next to the fixed-length and bulk decode kernels."""
+"""decode_batch_plan_kernel knobs (tiles per wave trip, whole-chunk store policy) on L-base reads, next to the fixed-length and
+bulk decode kernels.  Sustained bursts, interleaved rounds, one process."""
 import os
 import statistics
 import sys
@@ -44,9 +45,9 @@ def once(fn):
     return a.elapsed_time(b) / BURST
 
 
-names = {0: "full", 4: "no edge stores", 7: "no or/zero/edges"}
-edges = {0: "all chunks nt", 1: "all chunks plain", 2: "edge lines plain, rest nt"}
-res = {k: [] for k in list(names) + ["fixed", "bulk"] + [("e", e) for e in edges]}
+names = {}
+edges = {(u, pol): f"{u} tile(s) per trip, " + {0: "all chunks nt", 1: "all chunks plain", 2: "edge lines plain, rest nt"}[pol] for u in (1, 2, 4) for pol in (2, 0)}
+res = {k: [] for k in ["fixed", "bulk"] + [("e", e) for e in edges]}
 flip = [0]
 
 
@@ -56,18 +57,14 @@ def alt():
 
 
 for rnd in range(7):
-    for a in names:
-        ctx.set_variant("batch_abl", a)
-        t = once(lambda: plan.decode_dev(words, alt()))
-        if rnd >= 2:
-            res[a].append(t)
-    ctx.set_variant("batch_abl", 0)
     for e in edges:
-        ctx.set_variant("plan_store", e)
+        ctx.set_variant("plan_tiles", e[0])
+        ctx.set_variant("plan_store", e[1])
         t = once(lambda: plan.decode_dev(words, alt()))
         if rnd >= 2:
             res[("e", e)].append(t)
     ctx.set_variant("plan_store", 2)
+    ctx.set_variant("plan_tiles", 1)
     t = once(lambda: ctx.decode_fixed_dev(words, L, L, count, alt()))
     u = once(lambda: ctx.decode_dev(bw, N // 32, N, alt()))
     if rnd >= 2:
@@ -75,12 +72,9 @@ for rnd in range(7):
         res["bulk"].append(u)
 alg = L * count + 8 * total
 print(f"L={L}: decode of {count} reads, {alg/1e9:.4f} GB algorithmic; bulk decode of 10^9 bases: 1.25 GB")
-for a in names:
-    m = statistics.median(res[a])
-    print(f"  plan abl {a} {names[a]:26s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
 for e in edges:
     m = statistics.median(res[("e", e)])
-    print(f"  plan store policy {e} {edges[e]:30s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
+    print(f"  plan decode: {edges[e]:48s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
 plan.decode_dev(words, back)
 ctx.sync()
 print("  round trip:", "ok" if bool(torch.equal(back[:L * count], seq[:L * count])) else "MISMATCH")
