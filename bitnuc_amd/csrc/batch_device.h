@@ -293,7 +293,7 @@ __device__ __forceinline__ unsigned long long stream_cut(const uint32_t *strip, 
     const unsigned d = byte_off >> 4, sh = (byte_off & 15) * 2;
     const uint32_t w0 = strip[d], w1 = strip[d + 1], w2 = strip[d + 2];
     const uint32_t wlo = __builtin_amdgcn_alignbit(w1, w0, sh), whi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
+    const unsigned long long keep = ~0ull >> ((64u - 2u * nb) & 63u); // nb = 1..32: one 64-bit shift instead of shift / not / compare / select
     return (((unsigned long long)whi << 32) | wlo) & keep;
 }
 
@@ -849,6 +849,88 @@ plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned 
     }
 }
 
+// One tile of the plan encode.  issue: the tile's 16-byte chunks (2 per lane), one dword of the 129th chunk (an unaligned
+// tile's last <= 15 bytes; lanes 0-3) and the lane's pad byte.  Every load is unconditional with a clamped, in-bounds
+// address (a lane past the tile re-reads its last chunk): four memory instructions per tile on every path.  What a clamped
+// lane loads is never looked at: stream_cut masks everything past a word's bases.
+struct PlanEncTile {
+    u32x4 v0, v1;
+    uint32_t x2, n;
+};
+struct PlanEncGeom { // wave-uniform
+    unsigned long long wb;
+    long long off16; // byte offset (from seq) of the 16-byte aligned chunk that holds the tile's first base; may be -15..-1
+    unsigned lead;   // the first base's offset inside that chunk
+    unsigned nchunk; // 1..129
+    unsigned last;   // index of the tile's last real word
+};
+__device__ __forceinline__ PlanEncGeom plan_enc_geom(const uint8_t *seq, unsigned long long tile, unsigned long long base0, unsigned long long total_words,
+                                                     unsigned long long seq_end) {
+    PlanEncGeom g;
+    g.wb = tile * kBatchTile;
+    g.last = (unsigned)((total_words - g.wb < kBatchTile ? total_words - g.wb : kBatchTile) - 1);
+    g.lead = (unsigned)((reinterpret_cast<uintptr_t>(seq) + base0) & 15);
+    g.off16 = (long long)base0 - (long long)g.lead;
+    const unsigned long long hi = base0 + kBatchTile * 32 < seq_end ? base0 + kBatchTile * 32 : seq_end; // offset past the tile's last byte
+    g.nchunk = (long long)hi > g.off16 ? (unsigned)(((long long)hi - g.off16 + 15) >> 4) : 1u;         // a tile holds >= 1 base
+    return g;
+}
+__device__ __forceinline__ void plan_enc_issue(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ P, const PlanEncGeom &g, unsigned lane, PlanEncTile &t) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(seq + g.off16); // derived from the kernel argument: global_load, not flat_load
+    const unsigned top = g.nchunk - 1;
+    t.n = (uint32_t)P[g.wb + (lane < g.last ? lane : g.last) + 1]; // the whole lookup: one byte
+    t.v0 = __builtin_nontemporal_load(src + (lane < top ? lane : top));
+    t.v1 = __builtin_nontemporal_load(src + (lane + 64 < top ? lane + 64 : top));
+    t.x2 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src + (top < 128u ? top : 128u)) + (lane & 3));
+}
+__device__ __forceinline__ void plan_enc_finish(const uint8_t *__restrict__ seq, const PlanEncGeom &g, const PlanEncTile &t, unsigned long long base0,
+                                                unsigned long long seq_begin, unsigned long long seq_end, uint32_t *strip, unsigned lane,
+                                                unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
+    const uintptr_t lo16 = reinterpret_cast<uintptr_t>(seq) + (uintptr_t)g.off16;
+    const uint32_t n = lane <= g.last ? t.n : 0u;
+    // Only the slow path uses x2, and the compiler otherwise SINKS its load into that path, behind the wait for v0 / v1: a
+    // second, dependent memory round trip per unaligned tile (0.228 ms instead of 0.209 ms on 150-base reads).  Pinning
+    // the value here costs nothing: it is the youngest of four loads that are waited for together.
+    uint32_t x2 = t.x2;
+    asm volatile("" : "+v"(x2));
+    if (__ballot(n != 0u) == 0ull && g.last == 63u && g.lead == 0 && g.nchunk >= 128u) {
+        // fast tile (wave-uniform): 64 full words, first base 16-byte aligned = a plain 2 KiB bulk encode
+        uint32_t bad = 0;
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(out + g.wb);
+        const uint32_t c0 = enc16(t.v0, bad), c1 = enc16(t.v1, bad);
+        __builtin_nontemporal_store(c0, o32 + lane);
+        __builtin_nontemporal_store(c1, o32 + 64 + lane);
+        if (__builtin_expect(residue_is_bad(bad), 0)) {
+            rescan_bytes(seq, base0 + 16 * lane, 16, slot);
+            rescan_bytes(seq, base0 + 16 * (lane + 64), 16, slot);
+        }
+        return;
+    }
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    const uint32_t c0 = enc16(t.v0, b0), c1 = enc16(t.v1, b1), c2 = enc4(x2, b2);
+    wave_lds_fence(); // the previous tile's strip readers are done
+    strip[lane] = c0;
+    strip[64 + lane] = c1;
+    if (lane < 4) reinterpret_cast<uint8_t *>(strip + 128)[lane] = (uint8_t)c2; // chunk 128's codes, a byte per lane
+    if (__builtin_expect(residue_is_bad(b0 | b1 | b2), 0)) {
+        if (residue_is_bad(b0) && lane < g.nchunk) rescan_chunk(seq, lo16, lane, seq_begin, seq_end, slot);
+        if (residue_is_bad(b1) && lane + 64 < g.nchunk) rescan_chunk(seq, lo16, lane + 64, seq_begin, seq_end, slot);
+        if (residue_is_bad(b2) && lane < 4 && g.nchunk > 128) rescan_chunk(seq, lo16, 128, seq_begin, seq_end, slot);
+    }
+    const unsigned base_rel = 32u * lane - (wave_inclusive_sum(n) - n), nb = 32u - n;
+    wave_lds_fence();
+    if (lane <= g.last) {
+        const unsigned long long word = stream_cut(strip, g.lead + base_rel, nb);
+        __builtin_nontemporal_store(word, out + g.wb + lane);
+    }
+}
+
+// One tile per wave trip; the grid normally covers every tile and the hardware dispatcher walks them.  (Resident "walking"
+// waves that keep the next 1..3 tiles' loads and the tile base in flight were built on this issue / finish split and
+// measured 3-12 % SLOWER at every grid size: profiles/r02_plan_encode_walking_waves.txt.)
+// U = consecutive tiles per wave trip: their bases come from one scalar load and all their chunk loads are issued before the
+// first tile is encoded (tile_base[t] -> data address is a dependent pair of round trips; U tiles share it).
+template <int U>
 __global__ void __launch_bounds__(kBlock)
 encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
                          unsigned long long total_words, unsigned long long seq_begin, unsigned long long seq_end,
@@ -857,50 +939,50 @@ encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long lo
     const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
     uint32_t *strip = strips[wave];
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
-    const uintptr_t sp = reinterpret_cast<uintptr_t>(seq);
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave; tile < ntiles;
-         tile += (unsigned long long)gridDim.x * kBatchWaves) {
-        const unsigned long long base0 = tile_base[tile];
-        const unsigned long long wb = tile * kBatchTile;
-        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
-        const uintptr_t lo = sp + base0, lo16 = lo & ~(uintptr_t)15;
-        const uintptr_t hi = base0 + kBatchTile * 32 < seq_end ? lo + kBatchTile * 32 : sp + seq_end;
-        const unsigned nchunk = hi > lo16 ? (unsigned)((hi - lo16 + 15) >> 4) : 0u; // <= 129
-        const uint32_t n = lane <= last ? (uint32_t)P[wb + lane + 1] : 0u;          // the whole lookup: one byte
-        const u32x4 v0 = lane < nchunk ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)lane)) : zero4;
-        const u32x4 v1 = lane + 64 < nchunk ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)(lane + 64))) : zero4;
-        u32x4 v2 = zero4;
-        if (nchunk > 128 && lane == 0) v2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 2048));
-        if (__ballot(n != 0u) == 0ull && last == 63u && (lo & 15) == 0) {
-            // fast tile (wave-uniform): 64 full words, first base 16-byte aligned = a plain 2 KiB bulk encode
-            uint32_t bad = 0;
-            uint32_t *o32 = reinterpret_cast<uint32_t *>(out + wb);
-            const uint32_t c0 = enc16(v0, bad), c1 = enc16(v1, bad);
-            __builtin_nontemporal_store(c0, o32 + lane);
-            __builtin_nontemporal_store(c1, o32 + 64 + lane);
-            if (__builtin_expect(residue_is_bad(bad), 0)) {
-                rescan_bytes(seq, base0 + 16 * lane, 16, slot);
-                rescan_bytes(seq, base0 + 16 * (lane + 64), 16, slot);
-            }
-            continue;
+    for (unsigned long long t0 = ((unsigned long long)blockIdx.x * kBatchWaves + wave) * U; t0 < ntiles; t0 += (unsigned long long)gridDim.x * kBatchWaves * U) {
+        unsigned long long base0[U];
+        PlanEncGeom g[U];
+        PlanEncTile t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) base0[u] = tile_base[t0 + u < ntiles ? t0 + u : ntiles - 1]; // clamp: redundant but in bounds
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            g[u] = plan_enc_geom(seq, t0 + u < ntiles ? t0 + u : ntiles - 1, base0[u], total_words, seq_end);
+            plan_enc_issue(seq, P, g[u], lane, t[u]);
         }
-        uint32_t b0 = 0, b1 = 0, b2 = 0;
-        const uint32_t c0 = enc16(v0, b0), c1 = enc16(v1, b1), c2 = enc16(v2, b2);
-        wave_lds_fence(); // the previous trip's strip readers are done
-        strip[lane] = lane < nchunk ? c0 : 0u;
-        strip[64 + lane] = lane + 64 < nchunk ? c1 : 0u;
-        if (lane < (unsigned)(kB2Strip - 128)) strip[128 + lane] = (lane == 0 && nchunk > 128) ? c2 : 0u;
-        if (__builtin_expect(residue_is_bad(b0) && lane < nchunk, 0)) rescan_chunk(seq, lo16, lane, seq_begin, seq_end, slot);
-        if (__builtin_expect(residue_is_bad(b1) && lane + 64 < nchunk, 0)) rescan_chunk(seq, lo16, lane + 64, seq_begin, seq_end, slot);
-        if (__builtin_expect(residue_is_bad(b2) && lane == 0 && nchunk > 128, 0)) rescan_chunk(seq, lo16, 128, seq_begin, seq_end, slot);
-        const unsigned base_rel = 32u * lane - (wave_inclusive_sum(n) - n), nb = 32u - n;
-        wave_lds_fence();
-        if (lane <= last) {
-            const unsigned long long word = stream_cut(strip, (unsigned)(lo - lo16) + base_rel, nb);
-            __builtin_nontemporal_store(word, out + wb + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t0 + u >= ntiles) break; // wave-uniform
+            plan_enc_finish(seq, g[u], t[u], base0[u], seq_begin, seq_end, strip, lane, out, slot);
         }
     }
+}
+
+// One decode tile through the bit strip, shared by the plan and the fixed-length kernels.  base0 = byte offset (in out) of the
+// tile's first base; base_rel / nb = this lane's word relative to it; dense = no word of the tile is short (wave-uniform).
+template <int POLICY>
+__device__ __forceinline__ void decode_tile_strip(uint32_t *strip, uint8_t (*edge)[16], uint8_t *__restrict__ out, unsigned long long base0, unsigned base_rel,
+                                                  unsigned nb, bool dense, unsigned last, unsigned long long word, unsigned lane) {
+    const uintptr_t op = reinterpret_cast<uintptr_t>(out), lo = op + base0, lo16 = lo & ~(uintptr_t)15;
+    if (dense && last == 63u && (lo & 15) == 0) {
+        // fast tile (wave-uniform): the words cross the strip once so that lane l owns 16-base groups l and l+64
+        wave_lds_fence();
+        reinterpret_cast<unsigned long long *>(strip)[lane] = word;
+        wave_lds_fence();
+        const uint32_t h0 = strip[lane], h1 = strip[64 + lane];
+        uint8_t *dst = out + base0;
+        store_group<true, true>(dst + 16 * lane, dec16(h0));
+        store_group<true, true>(dst + 16 * (lane + 64), dec16(h1));
+        return;
+    }
+    wave_lds_fence(); // the previous tile's strip readers are done
+    strip_zero(strip, lane);
+    const unsigned end_rel = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)last);
+    const uintptr_t hi = lo + end_rel;
+    wave_lds_fence();
+    if (lane <= last) strip_or_word(strip, 2u * ((unsigned)(lo - lo16) + base_rel), word, nb);
+    wave_lds_fence();
+    if (hi > lo) strip_drain<POLICY>(strip, edge, out, lo16, lo, hi, lane);
 }
 
 // U = tiles per wave trip: the loads of U consecutive tiles (word, pad byte, tile base) are issued before the first is
@@ -914,7 +996,6 @@ decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const uns
     const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
     uint32_t *strip = strips[wave];
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
-    const uintptr_t op = reinterpret_cast<uintptr_t>(out);
     for (unsigned long long t0 = ((unsigned long long)blockIdx.x * kBatchWaves + wave) * U; t0 < ntiles;
          t0 += (unsigned long long)gridDim.x * kBatchWaves * U) {
         unsigned long long word[U], base0[U];
@@ -932,29 +1013,41 @@ decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const uns
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (t0 + u >= ntiles) break; // wave-uniform
-            const uintptr_t lo = op + base0[u], lo16 = lo & ~(uintptr_t)15;
-            if (__ballot(n[u] != 0u) == 0ull && last[u] == 63u && (lo & 15) == 0) {
-                // fast tile (wave-uniform): the words cross the strip once so that lane l owns 16-base groups l and l+64
-                wave_lds_fence();
-                reinterpret_cast<unsigned long long *>(strip)[lane] = word[u];
-                wave_lds_fence();
-                const uint32_t h0 = strip[lane], h1 = strip[64 + lane];
-                uint8_t *dst = out + base0[u];
-                store_group<true, true>(dst + 16 * lane, dec16(h0));
-                store_group<true, true>(dst + 16 * (lane + 64), dec16(h1));
-                continue;
-            }
-            wave_lds_fence(); // the previous tile's strip readers are done
-            strip_zero(strip, lane);
-            const uint32_t incl = wave_inclusive_sum(n[u]);
-            const unsigned base_rel = 32u * lane - (incl - n[u]), nb = 32u - n[u];
-            const unsigned end_rel = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)last[u]);
-            const uintptr_t hi = lo + end_rel;
-            wave_lds_fence();
-            if (lane <= last[u]) strip_or_word(strip, 2u * ((unsigned)(lo - lo16) + base_rel), word[u], nb);
-            wave_lds_fence();
-            if (hi > lo) strip_drain<POLICY>(strip, edge[wave], out, lo16, lo, hi, lane);
+            const bool dense = __ballot(n[u] != 0u) == 0ull;
+            const unsigned base_rel = 32u * lane - (wave_inclusive_sum(n[u]) - n[u]), nb = 32u - n[u];
+            decode_tile_strip<POLICY>(strip, edge[wave], out, base0[u], base_rel, nb, dense, last[u], word[u], lane);
         }
+    }
+}
+
+// Back-to-back fixed-length reads through the same tile body: the plan's two lookups are arithmetic here.  Wave-uniform
+// (scalar unit): r0 = floor(wb / wpr) by the host's multiply-high constant, j0 = wb - r0 wpr, base0 = r0 read_len + 32 j0.
+// Per lane, all 32-bit and relative to the tile: t = j0 + lane, q = floor(t / wpr) (t < wpr + 64), j = t - q wpr,
+// first byte = q read_len + 32 (j - j0), bases = min(32, read_len - 32 j).
+template <int POLICY>
+__global__ void __launch_bounds__(kBlock)
+decode_fixed_tile_kernel(const unsigned long long *__restrict__ words, unsigned read_len, unsigned wpr, unsigned magic, unsigned long long magic64,
+                         unsigned long long total_words, uint8_t *__restrict__ out) {
+    __shared__ uint32_t strips[kBatchWaves][kB2Strip];
+    __shared__ __attribute__((aligned(16))) uint8_t edge[kBatchWaves][2][16];
+    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
+    uint32_t *strip = strips[wave];
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    const bool dense = (read_len & 31u) == 0u;
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave; tile < ntiles; tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        const unsigned long long wb = tile * kBatchTile;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        const unsigned l = lane < last ? lane : last; // lanes past the tile mirror its last word
+        const unsigned long long word = __builtin_nontemporal_load(words + wb + l);
+        const unsigned long long r0 = magic64 ? (unsigned long long)(((unsigned __int128)wb * magic64) >> 64) : wb;
+        const unsigned j0 = (unsigned)(wb - r0 * wpr);
+        const unsigned long long base0 = r0 * read_len + 32ull * j0;
+        const unsigned t = j0 + l;
+        const unsigned q = wpr > 64 ? (t >= wpr ? 1u : 0u) : (wpr == 1 ? t : __umulhi(t, magic));
+        const unsigned j = t - q * wpr;
+        const unsigned base_rel = q * read_len + 32u * j - 32u * j0;
+        const unsigned left = read_len - 32u * j, nb = left < 32u ? left : 32u;
+        decode_tile_strip<POLICY>(strip, edge[wave], out, base0, base_rel, nb, dense, last, word, lane);
     }
 }
 

@@ -66,11 +66,12 @@ struct bitnuc_ctx {
     int batch_slide = 1;                 // stride 1 (every window of a sequence), 2, 4, 8, 16 batches use kmer_slide_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
     int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
-    int fixed_dec_strip = 1;               // decode_fixed (back-to-back reads): 1 = rebuild the tile's 2-bit stream in LDS, decode aligned chunks
+    int fixed_dec_strip = 2;               // decode_fixed (back-to-back reads): 0 = byte scatter, 1 = bit strip with per-lane 64-bit positions, 2 = the plan decode's tile body with arithmetic lookups (tools/ab_fixed_dec.py)
     int owner_est = 3;                     // block_owner_kernel's first guess: 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, 3 = 2 or 0 by average sequence length
     int batch_host_plan = 1;               // host-pointer ragged-batch calls build a layout plan (bitnuc_batch_plan) and use the plan kernels
     bitnuc_batch_plan *host_plan = nullptr; // ... kept by the context
     int plan_tiles = 1;                    // decode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
+    int plan_enc_tiles = 1;                // encode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
     int plan_store = 2;                    // decode_batch_plan_kernel's whole-chunk store policy: 0 nt, 1 plain, 2 plain on the shared edge lines + nt elsewhere
     int batch_abl = 0;                     // timing-only ablation mask of the second formulation (tools/ab_batch_ablate.py); 0 in normal use
     int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
@@ -775,10 +776,11 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
     else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
     else if (!strcmp(key, "fixed_stream")) { prev = c->fixed_stream; if (value == 0 || value == 1) c->fixed_stream = value; }
-    else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value == 0 || value == 1) c->fixed_dec_strip = value; }
+    else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value >= 0 && value <= 2) c->fixed_dec_strip = value; }
     else if (!strcmp(key, "owner_est")) { prev = c->owner_est; if (value >= 0 && value <= 3) c->owner_est = value; }
     else if (!strcmp(key, "batch_host_plan")) { prev = c->batch_host_plan; if (value == 0 || value == 1) c->batch_host_plan = value; }
     else if (!strcmp(key, "plan_tiles")) { prev = c->plan_tiles; if (value == 1 || value == 2 || value == 4) c->plan_tiles = value; }
+    else if (!strcmp(key, "plan_enc_tiles")) { prev = c->plan_enc_tiles; if (value == 1 || value == 2 || value == 4) c->plan_enc_tiles = value; }
     else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && value <= 2) c->plan_store = value; }
     else if (!strcmp(key, "batch_abl")) {
         prev = c->batch_abl;
@@ -1500,9 +1502,15 @@ int bitnuc_encode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, cons
     unsigned long long *slot;
     if (int st = take_slot(c, 0, &slot, err)) return st;
     const size_t per_block = (size_t)kBatchTile * kBatchWaves;
-    const unsigned grid = grid_for(c, (p->total_words + per_block - 1) / per_block);
-    encode_batch_plan_kernel<<<grid, kBlock, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end,
-                                                            reinterpret_cast<unsigned long long *>(d_out), slot);
+    const unsigned long long blocks = (p->total_words + per_block - 1) / per_block;
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
+    const unsigned long long U = (unsigned long long)c->plan_enc_tiles;
+    const unsigned grid = grid_for(c, (blocks + U - 1) / U);
+#define PLAN_ENC(UU) encode_batch_plan_kernel<UU><<<grid, kBlock, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end, o, slot)
+    if (U == 2) PLAN_ENC(2);
+    else if (U == 4) PLAN_ENC(4);
+    else PLAN_ENC(1);
+#undef PLAN_ENC
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
@@ -1567,7 +1575,8 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
     const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
     const unsigned magic = (unsigned)((0x100000000ull + wpr - 1) / wpr);
     const unsigned long long magic64 = wpr == 1 ? 0ull : ~0ull / wpr + 1;
-    if (stride == read_len && c->fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
+    if (stride == read_len && c->fixed_dec_strip == 2) decode_fixed_tile_kernel<2><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
+    else if (stride == read_len && c->fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
     else if (stride == read_len) decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
     else decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
     HIPCHK(hipGetLastError());

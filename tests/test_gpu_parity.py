@@ -572,14 +572,20 @@ def _oracle_batch(oracle, seq, off):
     return (np.concatenate(words) if words else np.zeros(0, np.uint64)), np.array(wo, dtype=np.uint64)
 
 
-@pytest.fixture(params=[1, 0], ids=["plan", "tables"])
+@pytest.fixture(params=[(1, 1), (1, 2), (1, 4), (0, 1)], ids=["plan", "plan-2tiles", "plan-4tiles", "tables"])
 def batch_body(request, ctx):
     """Both formulations of the ragged-batch kernels behind the host-pointer entry points: the layout plan
-    (bitnuc_batch_plan: one pad byte per word; what host calls use) and the table-driven kernels (tile records + O(1)
-    pad-scatter lookup from the two offset tables; what the *_dev table entry points use)."""
-    prev = ctx.set_variant("batch_host_plan", request.param)
-    yield request.param
+    (bitnuc_batch_plan: one pad byte per word; what host calls use; its kernels with 1, 2 and 4 tiles per wave trip) and
+    the table-driven kernels (tile records + O(1) pad-scatter lookup from the two offset tables; what the *_dev table
+    entry points use)."""
+    use_plan, tiles = request.param
+    prev = ctx.set_variant("batch_host_plan", use_plan)
+    prev_e = ctx.set_variant("plan_enc_tiles", tiles)
+    prev_d = ctx.set_variant("plan_tiles", tiles)
+    yield use_plan
     ctx.set_variant("batch_host_plan", prev)
+    ctx.set_variant("plan_enc_tiles", prev_e)
+    ctx.set_variant("plan_tiles", prev_d)
 
 
 @pytest.mark.parametrize("shape", ["reads150", "tiny", "mixed", "with_empties", "one_long", "many_empties", "len32", "ones_and_empties", "unaligned_long"])
@@ -1435,12 +1441,14 @@ def test_fixed_reads_vs_oracle_loop(ctx, oracle, read_len, stride):
     assert (ei.value.byte, ei.value.index) == (ord("N"), pos)
 
 
-def test_decode_fixed_contiguous_every_alignment(ctx, oracle):
+@pytest.mark.parametrize("body", [2, 1], ids=["shared-tile-body", "strip-64bit-positions"])
+def test_decode_fixed_contiguous_every_alignment(ctx, oracle, body):
     """Back-to-back reads: whole output compared, at several output alignments, with junk in the pad bits of each
     read's last word, and with guard bytes around the run."""
     import torch
     dev = torch.device("cuda:0")
-    if True:
+    prev = ctx.set_variant("fixed_dec_strip", body)
+    try:
         for read_len, count in [(16, 700), (17, 333), (31, 500), (32, 129), (33, 257), (47, 100), (64, 65), (100, 1001), (150, 777),
                                 (250, 300), (2048, 9), (2049, 9), (5000, 7), (100003, 3), (20, 1), (150, 1)]:
             wpr = (read_len + 31) // 32
@@ -1459,6 +1467,8 @@ def test_decode_fixed_contiguous_every_alignment(ctx, oracle):
                 assert bytes(got[:16 + a]) == b"#" * (16 + a), (read_len, count, a)
                 assert bytes(got[16 + a + read_len * count:]) == b"#" * (48 - a), (read_len, count, a)
                 assert np.array_equal(got[16 + a: 16 + a + read_len * count], seq), (read_len, count, a)
+    finally:
+        ctx.set_variant("fixed_dec_strip", prev)
 
 
 def test_fixed_reads_full_scale(ctx, oracle):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""In-process A/B of decode_fixed on back-to-back reads: byte scatter into LDS (fixed_dec_strip=0) vs bit-strip (1).
-Input words alternate between two copies (cache-cold)."""
+"""In-process A/B of decode_fixed on back-to-back reads: byte scatter into LDS (fixed_dec_strip=0), bit strip with per-lane
+64-bit positions (1), the shared tile body of the plan decode with 32-bit tile-relative positions and the dense fast
+path (2).  Input words alternate between two copies (cache-cold)."""
 import os
 import statistics
 import sys
@@ -22,11 +23,11 @@ for L in [int(x) for x in sys.argv[1:]] or [16, 31, 32, 36, 100, 150, 151, 160, 
     words = torch.empty(count * wpr, dtype=torch.int64, device=dev)
     ctx.encode_fixed_dev(seq, L, L, count, words)
     words2 = words.clone()
-    outs = [torch.zeros(count * L, dtype=torch.uint8, device=dev) for _ in range(2)]
+    outs = [torch.zeros(count * L, dtype=torch.uint8, device=dev) for _ in range(3)]
     torch.cuda.synchronize()
-    res = {0: [], 1: []}
+    res = {0: [], 1: [], 2: []}
     for rnd in range(9):
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             ctx.set_variant("fixed_dec_strip", mode)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
             ev[0].record(stream)
@@ -36,7 +37,8 @@ for L in [int(x) for x in sys.argv[1:]] or [16, 31, 32, 36, 100, 150, 151, 160, 
             torch.cuda.synchronize()
             res[mode].append(statistics.mean(ev[i].elapsed_time(ev[i + 1]) for i in range(2, 6)))
     ctx.sync()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], seq[: count * L])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], seq[: count * L])
+    ctx.set_variant("fixed_dec_strip", 2)
     alg = count * L + 8 * count * wpr
-    m0, m1 = statistics.median(res[0]), statistics.median(res[1])
-    print(f"L={L}: byte scatter {m0:.4f} ms ({alg / m0 / 1e6:.0f} GB/s) | bit strip {m1:.4f} ms ({alg / m1 / 1e6:.0f} GB/s)", flush=True)
+    m0, m1, m2 = statistics.median(res[0]), statistics.median(res[1]), statistics.median(res[2])
+    print(f"L={L}: byte scatter {m0:.4f} ms ({alg / m0 / 1e6:.0f} GB/s) | bit strip {m1:.4f} ms ({alg / m1 / 1e6:.0f} GB/s) | shared tile body {m2:.4f} ms ({alg / m2 / 1e6:.0f} GB/s)", flush=True)
