@@ -691,19 +691,26 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
 
     def timed(fn, reps=10):
         return timed_median(torch, stream, fn, reps)
+
+    def both(fn, burst=8, rounds=5, reps=8):
+        """(sustained ms per launch, isolated ms per launch): back-to-back bursts -- how the timed step itself is measured -- and
+        single launches between host syncs (adds the launch ramp and tail, 2-4 us, which matters for the 40-80 us kernels)."""
+        return timed_sustained(torch, stream, lambda i: fn(), burst=burst, rounds=rounds), timed_median(torch, stream, fn, reps)
+    SUST = "sustained bursts of 8 launches (as the timed step is measured); isolated_ms = single launches between host syncs"
     count, k = 10**8, 31
     kseq = torch.empty(count * k, dtype=torch.uint8, device=dev)
     ctx.nucgen_dev(kseq, count * k, SEED + 100)
     kout = torch.empty(count, dtype=torch.int64, device=dev)
-    ms = timed(lambda: ctx.as_2bit_batch_dev(kseq, k, k, count, kout))
+    ms, iso = both(lambda: ctx.as_2bit_batch_dev(kseq, k, k, count, kout), burst=6, rounds=4)
     extra["kmer_batch"] = {"workload": "BASELINE configs[2]: 10^8 dense 31-mers as_2bit -> u64", "gkmers_s": round(count / (ms * 1e-3) / 1e9, 2),
-                           "ms": round(ms, 4), "roofline": hbm(count * (k + 8), ms)}
+                           "ms": round(ms, 4), "isolated_ms": round(iso, 4), "timing": SUST, "roofline": hbm(count * (k + 8), ms)}
     del kseq, kout
     # every window of a sequence (`seq.windows(k)` + as_2bit, src/lib.rs:170-173): stride 1, 1 B read + 8 B written per window
     nwin = n - k + 1
     wout = torch.empty(nwin, dtype=torch.int64, device=dev)
-    ms = timed(lambda: ctx.as_2bit_batch_dev(seqs[0], k, 1, nwin, wout), reps=6)
+    ms, iso = both(lambda: ctx.as_2bit_batch_dev(seqs[0], k, 1, nwin, wout), burst=4, rounds=3, reps=5)
     extra["kmer_windows"] = {"workload": "as_2bit of every 31-base window of 10^9 bases (stride 1) -> u64 per window", "ms": round(ms, 4),
+                             "isolated_ms": round(iso, 4), "timing": SUST.replace("8", "4"),
                              "gwindows_s": round(nwin / (ms * 1e-3) / 1e9, 2), "roofline": hbm(9 * nwin, ms)}
     del wout
     dist_out = torch.empty(n - k + 1, dtype=torch.uint8, device=dev)
@@ -730,8 +737,8 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
     ctx.nucgen_dev(backs[0], n, SEED + 200)
     ctx.encode_dev(backs[0], n, wb)
     res = torch.zeros(1, dtype=torch.int32, device=dev)
-    ms = timed(lambda: ctx.hdist_dev(wa, nw, wb, nw, n, res))
-    extra["hdist_bulk"] = {"workload": "hdist of two 10^9-base packed buffers (SURVEY 8f rank 1)", "ms": round(ms, 4),
+    ms, iso = both(lambda: ctx.hdist_dev(wa, nw, wb, nw, n, res))
+    extra["hdist_bulk"] = {"workload": "hdist of two 10^9-base packed buffers (SURVEY 8f rank 1)", "ms": round(ms, 4), "isolated_ms": round(iso, 4), "timing": SUST,
                            "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "distance": int(res.item()) & 0xFFFFFFFF, "roofline": hbm(16 * nw, ms)}
     # analysis directly on packed words
     cnt = torch.zeros(4, dtype=torch.int64, device=dev)
@@ -742,20 +749,23 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
     def alt():
         flip[0] ^= 1
         return wb if flip[0] else wa
-    ms = timed(lambda: ctx.base_counts_dev(alt(), nw, n, cnt))
+    ms, iso = both(lambda: ctx.base_counts_dev(alt(), nw, n, cnt))
     extra["base_counts"] = {"workload": "A/C/G/T counts of 10^9 packed bases (analysis.rs:23-39 without the decode)", "ms": round(ms, 4),
+                            "isolated_ms": round(iso, 4), "timing": SUST + "; input alternates between two 250 MB buffers (cache-cold)",
                             "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "roofline": hbm(8 * nw, ms)}
     qd = torch.empty(nw, dtype=torch.uint8, device=dev)
-    ms = timed(lambda: ctx.hdist_query_dev(0x1B1B1B1B1B1B1B1B, alt(), nw, 32, qd))
+    ms, iso = both(lambda: ctx.hdist_query_dev(0x1B1B1B1B1B1B1B1B, alt(), nw, 32, qd))
     extra["hdist_query"] = {"workload": "one packed 32-mer against 3.1e7 packed 32-mers -> u8 distances", "ms": round(ms, 4),
+                            "isolated_ms": round(iso, 4), "timing": SUST + "; input alternates between two 250 MB buffers (cache-cold)",
                             "gwords_s": round(nw / (ms * 1e-3) / 1e9, 2), "roofline": hbm(9 * nw, ms)}
     del qd
     # split_packed at an odd base in the middle (16 B per word: read once, write once)
     sidx = n // 2 + 5
     snl, snr = ctx.split_packed_sizes(nw, n, sidx, canonical=True)
     sl, sr = torch.empty(snl, dtype=torch.int64, device=dev), torch.empty(snr, dtype=torch.int64, device=dev)
-    ms = timed(lambda: ctx.split_packed_dev(alt(), nw, n, sidx, sl, sr, canonical=True))
+    ms, iso = both(lambda: ctx.split_packed_dev(alt(), nw, n, sidx, sl, sr, canonical=True))
     extra["split_packed"] = {"workload": "split 10^9 packed bases at base n/2+5 (functions/split.rs:15-99, funnel-shift form)", "ms": round(ms, 4),
+                             "isolated_ms": round(iso, 4), "timing": SUST,
                              "gbases_s": round(n / (ms * 1e-3) / 1e9, 1), "roofline": hbm(8 * (nw + snl + snr), ms)}
     del sl, sr
     # ragged batch of independent sequences: 150-base reads (each read pads its own last word)
@@ -806,7 +816,12 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
     ms_e = timed_sustained(torch, stream, lambda i: ctx.encode_batch_dev(seqs[0], roff, rwo, rcount, rtotal, wsets[i & 1]))
     ms_d = timed_sustained(torch, stream, lambda i: ctx.decode_batch_dev(wsets[i & 1], rwo, roff, rcount, rtotal, bsets[i & 1]))
     extra["reads_batch_tables"] = batch_block(ms_e, ms_d, "the same batch through encode_batch_dev / decode_batch_dev (offset tables only, no plan: every call runs the tile-record pre-kernel)",
-                                              timing="sustained", roundtrip_ok=bool(torch.equal(seqs[0][:rb], backs[0][:rb])))
+                                              timing="sustained", roundtrip_ok=bool(torch.equal(seqs[0][:rb], backs[0][:rb])),
+                                              tables_bytes_per_launch=16 * (rcount + 1),
+                                              encode_gb_s_with_tables=round((alg + 16 * (rcount + 1)) / (ms_e * 1e-3) / 1e9, 1),
+                                              decode_gb_s_with_tables=round((alg + 16 * (rcount + 1)) / (ms_d * 1e-3) / 1e9, 1),
+                                              note="encode_gb_s / decode_gb_s count bases + packed words only; every call of this form must also read the two "
+                                                   "8-byte-per-read tables (+8.4 % for 150-base reads), which the *_with_tables figures include")
     ms_fe = timed_sustained(torch, stream, lambda i: ctx.encode_fixed_dev(seqs[0], L, L, rcount, wsets[i & 1]))
     ms_fd = timed_sustained(torch, stream, lambda i: ctx.decode_fixed_dev(wsets[i & 1], L, L, rcount, bsets[i & 1]))
     extra["reads_fixed"] = batch_block(ms_fe, ms_fd, f"{rcount} fixed-length 150-base reads, encode_fixed / decode_fixed (no offsets tables)", timing="sustained")

@@ -250,6 +250,21 @@ word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned lon
     if (threadIdx.x == kBlock - 1 && i0 + kScanTile >= count) word_offsets[count] = block_sums[blockIdx.x] + total;
 }
 
+// ---- the wave-private LDS strip of 32-bit chunk words (codes of 16 bases), shared by every tile kernel below ----------
+// Chunk c lives at strip_slot(c): EVEN chunks at strip[0..], ODD chunks at strip[kSplitOdd..].  A word is 2 chunks long, so
+// with a linear strip lane l's three funnel dwords (encode) or three OR targets (decode) start 2 dwords after lane l-1's:
+// the 32 lanes of an LDS access group cover 64 dwords = 2 per bank, one extra cycle per group and access (the 6 conflict
+// cycles per tile of profiles/r02_batch_pmc1.txt).  Split by parity, a lane of the encode reads even[e], even[e+1],
+// odd[e], odd[e+1] with e = byte_off >> 5, which advances by 0 or 1 from lane to lane: at most 32 consecutive indices
+// per group, one per bank (equal indices are a broadcast), for every mix of word lengths.  kSplitOdd = 16 mod 32 makes the
+// chunk-ordered accesses (fill in the encode, drain in the decode) conflict-free too: a group's 16 even chunks sit in
+// banks i..i+15, its 16 odd chunks in banks i+16..i+31.  Measured (profiles/r02_lds_split_strip.txt): SQ_LDS_BANK_CONFLICT
+// of the plan encode 3.1 M -> 0 per launch, time unchanged (-0.7 %): the conflicts were real and never the bottleneck.
+constexpr int kSplitOdd = 80;    // dword offset of the odd half: >= 68 even entries (chunks 0..135), = 16 mod 32
+constexpr int kSplitStrip = 152; // dwords per wave
+__device__ __forceinline__ uint32_t *strip_slot(uint32_t *strip, unsigned chunk) { return strip + (chunk >> 1) + (chunk & 1u) * kSplitOdd; }
+__device__ __forceinline__ const uint32_t *strip_slot(const uint32_t *strip, unsigned chunk) { return strip + (chunk >> 1) + (chunk & 1u) * kSplitOdd; }
+
 // ---------------------------------------------------------------------------------
 // batched encode
 // ---------------------------------------------------------------------------------
@@ -276,7 +291,7 @@ __device__ __forceinline__ void stream_fill(const u32x4 (&v)[3], unsigned nchunk
         const unsigned c = lane + 64 * r;
         if (c < nchunk) {
             uint32_t bad = 0;
-            strip[c] = enc16(v[r], bad);
+            strip_slot(strip, lane)[32 * r] = enc16(v[r], bad); // chunk lane + 64 r: same parity as chunk `lane`, 32 dwords further
             if (__builtin_expect(residue_is_bad(bad), 0)) {
                 // a 16-byte aligned chunk may stick out of the buffer at either end: look only at bytes inside it
                 const uintptr_t g = lo16 + 16 * (uintptr_t)c, s0 = reinterpret_cast<uintptr_t>(seq), e0 = s0 + seq_end, b0 = s0 + seq_begin;
@@ -285,22 +300,24 @@ __device__ __forceinline__ void stream_fill(const u32x4 (&v)[3], unsigned nchunk
             }
         }
     }
-    if (lane < 4) strip[nchunk + lane] = 0; // the funnel may read up to 2 dwords past the last chunk
+    // (the funnel may read up to 2 chunks past the last one: whatever it finds there is masked off by stream_cut)
 }
 
-// the word whose first base sits byte_off bytes into the strip's span, nb bases long
+// the word whose first base sits byte_off bytes into the strip's span, nb bases long (nb = 1..32)
 __device__ __forceinline__ unsigned long long stream_cut(const uint32_t *strip, unsigned byte_off, unsigned nb) {
-    const unsigned d = byte_off >> 4, sh = (byte_off & 15) * 2;
-    const uint32_t w0 = strip[d], w1 = strip[d + 1], w2 = strip[d + 2];
+    const unsigned e = byte_off >> 5, sh = (byte_off & 15) * 2;
+    const bool odd = (byte_off & 16u) != 0u;
+    const uint32_t a0 = strip[e], a1 = strip[e + 1], b0 = strip[kSplitOdd + e], b1 = strip[kSplitOdd + e + 1];
+    const uint32_t w0 = odd ? b0 : a0, w1 = odd ? a1 : b0, w2 = odd ? b1 : a1;
     const uint32_t wlo = __builtin_amdgcn_alignbit(w1, w0, sh), whi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    const unsigned long long keep = ~0ull >> ((64u - 2u * nb) & 63u); // nb = 1..32: one 64-bit shift instead of shift / not / compare / select
+    const unsigned long long keep = ~0ull >> ((64u - 2u * nb) & 63u); // one 64-bit shift instead of shift / not / compare / select
     return (((unsigned long long)whi << 32) | wlo) & keep;
 }
 
 // load + fill + cut for a tile whose span [span_lo, span_hi) is known up front
 __device__ __forceinline__ unsigned long long
 encode_word_from_stream(const uint8_t *__restrict__ seq, unsigned long long seq_end, unsigned long long span_lo,
-                        unsigned long long span_hi, unsigned long long base, unsigned nb, uint32_t *strip /* >= 136 dwords */,
+                        unsigned long long span_hi, unsigned long long base, unsigned nb, uint32_t *strip /* >= kSplitStrip dwords */,
                         unsigned long long *__restrict__ slot) {
     const unsigned lane = threadIdx.x & 63;
     // read 32 bytes past the last word (clipped to the buffer) so that the 64-bit funnel of a
@@ -487,7 +504,7 @@ decode_fixed_kernel(const unsigned long long *__restrict__ words, unsigned read_
 // bases and issues one coalesced dwordx4 store -- the store pattern of the bulk decode, no byte staging and no
 // predicated LDS stores.  Only the run's first / last chunk (shared with the neighbouring tiles) is written
 // byte-wise, through the wave's stage buffer and store_stage_chunk.
-constexpr int kStripDwords = kBatchTile * 2 + 8; // 64 words x 64 bits + the <= 15-byte lead + slack
+constexpr int kStripDwords = kBatchTile * 2 + 8; // 64 words x 64 bits + the <= 15-byte lead + slack (the decode strip is LINEAR: see strip_or_word)
 
 // the three steps of a bit-strip tile, shared by decode_fixed_strip_kernel and decode_batch_kernel (wave-private)
 __device__ __forceinline__ void strip_zero(uint32_t *strip, unsigned lane) {
@@ -605,7 +622,7 @@ decode_fixed_strip_kernel(const unsigned long long *__restrict__ words, unsigned
 //     instead of nine reads at an 8-dword stride (8-way).
 // The window is 64 entries, a second round of 64 is fetched when more than 63 sequences start inside one tile
 // (sequences shorter than a word), and a per-lane global search covers what is left (runs of empty sequences).
-constexpr int kB2Strip = 136; // dwords of the code / bit strip: chunk 0..128 + funnel slack
+constexpr int kB2Strip = kSplitStrip; // dwords of the code / bit strip: chunk 0..128 + funnel slack, in the split layout
 constexpr int kB2Pads = 68;   // pads[0..64] + slack
 
 struct Batch2Lds {
@@ -740,9 +757,10 @@ encode_batch2_kernel(const uint8_t *__restrict__ seq, const unsigned long long *
         uint32_t b0 = 0, b1 = 0, b2 = 0;
         const uint32_t c0 = enc16(v0, b0), c1 = enc16(v1, b1), c2 = enc16(v2, b2);
         wave_lds_fence(); // the previous trip's strip readers are done
-        my.strip[lane] = lane < nchunk ? c0 : 0u;
-        my.strip[64 + lane] = lane + 64 < nchunk ? c1 : 0u;
-        if (lane < (unsigned)(kB2Strip - 128)) my.strip[128 + lane] = (lane == 0 && nchunk > 128) ? c2 : 0u;
+        uint32_t *mine = strip_slot(my.strip, lane); // chunk `lane`; chunk lane + 64 has the same parity: 32 dwords further
+        mine[0] = c0;
+        mine[32] = c1;
+        if (lane == 0) *strip_slot(my.strip, 128) = c2; // (chunks past nchunk hold zeros or stale codes: stream_cut masks them off)
         if (__builtin_expect(residue_is_bad(b0) && lane < nchunk, 0)) rescan_chunk(seq, lo16, lane, seq_begin, seq_end, slot);
         if (__builtin_expect(residue_is_bad(b1) && lane + 64 < nchunk, 0)) rescan_chunk(seq, lo16, lane + 64, seq_begin, seq_end, slot);
         if (__builtin_expect(residue_is_bad(b2) && lane == 0 && nchunk > 128, 0)) rescan_chunk(seq, lo16, 128, seq_begin, seq_end, slot);
@@ -909,9 +927,10 @@ __device__ __forceinline__ void plan_enc_finish(const uint8_t *__restrict__ seq,
     uint32_t b0 = 0, b1 = 0, b2 = 0;
     const uint32_t c0 = enc16(t.v0, b0), c1 = enc16(t.v1, b1), c2 = enc4(x2, b2);
     wave_lds_fence(); // the previous tile's strip readers are done
-    strip[lane] = c0;
-    strip[64 + lane] = c1;
-    if (lane < 4) reinterpret_cast<uint8_t *>(strip + 128)[lane] = (uint8_t)c2; // chunk 128's codes, a byte per lane
+    uint32_t *mine = strip_slot(strip, lane); // chunk `lane`; chunk lane + 64 has the same parity: 32 dwords further
+    mine[0] = c0;
+    mine[32] = c1;
+    if (lane < 4) reinterpret_cast<uint8_t *>(strip_slot(strip, 128))[lane] = (uint8_t)c2; // chunk 128's codes, a byte per lane
     if (__builtin_expect(residue_is_bad(b0 | b1 | b2), 0)) {
         if (residue_is_bad(b0) && lane < g.nchunk) rescan_chunk(seq, lo16, lane, seq_begin, seq_end, slot);
         if (residue_is_bad(b1) && lane + 64 < g.nchunk) rescan_chunk(seq, lo16, lane + 64, seq_begin, seq_end, slot);

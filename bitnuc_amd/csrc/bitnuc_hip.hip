@@ -63,6 +63,7 @@ struct bitnuc_ctx {
     int enc_variant = 14, dec_variant = 22; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
+    int slide_rounds = 1;                // kmer_slide_kernel: consecutive 992-base rounds per wave trip (1, 2 or 4)
     int batch_slide = 1;                 // stride 1 (every window of a sequence), 2, 4, 8, 16 batches use kmer_slide_kernel
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
     int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
@@ -548,10 +549,14 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         // windows at a small power-of-two stride (1 = every window of a sequence): whole 1 KiB wave rounds through the
         // sliding kernel, 992 / stride windows each; the round that would read past the batch's last byte is left over
         const unsigned long long rounds = ((count - 1) * stride + k - 1024) / kScanWaveWindows + 1;
-        const unsigned grid = grid_for(c, (rounds + kBlock / 64 - 1) / (kBlock / 64));
+        const unsigned long long per_wave = (unsigned long long)c->slide_rounds;
+        const unsigned grid = grid_for(c, (rounds + per_wave * (kBlock / 64) - 1) / (per_wave * (kBlock / 64)));
         const bool nts = (c->dense_policy & 2) != 0;
-#define SLIDE(S) do { if (nts) kmer_slide_kernel<S, true><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); \
-                      else kmer_slide_kernel<S, false><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); } while (0)
+#define SLIDE_U(S, NT) do { if (per_wave == 2) kmer_slide_kernel<S, NT, 2><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); \
+                            else if (per_wave == 4) kmer_slide_kernel<S, NT, 4><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); \
+                            else if (per_wave == 8) kmer_slide_kernel<S, NT, 8><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); \
+                            else kmer_slide_kernel<S, NT, 1><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); } while (0)
+#define SLIDE(S) do { if (nts) SLIDE_U(S, true); else SLIDE_U(S, false); } while (0)
         switch (stride) {
         case 1: SLIDE(1); break;
         case 2: SLIDE(2); break;
@@ -560,6 +565,7 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         default: SLIDE(16); break;
         }
 #undef SLIDE
+#undef SLIDE_U
         hipError_t rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
         done = (size_t)(rounds * (kScanWaveWindows / stride));
@@ -781,6 +787,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "batch_host_plan")) { prev = c->batch_host_plan; if (value == 0 || value == 1) c->batch_host_plan = value; }
     else if (!strcmp(key, "plan_tiles")) { prev = c->plan_tiles; if (value == 1 || value == 2 || value == 4) c->plan_tiles = value; }
     else if (!strcmp(key, "plan_enc_tiles")) { prev = c->plan_enc_tiles; if (value == 1 || value == 2 || value == 4) c->plan_enc_tiles = value; }
+    else if (!strcmp(key, "slide_rounds")) { prev = c->slide_rounds; if (value == 1 || value == 2 || value == 4 || value == 8) c->slide_rounds = value; }
     else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && value <= 2) c->plan_store = value; }
     else if (!strcmp(key, "batch_abl")) {
         prev = c->batch_abl;

@@ -393,7 +393,9 @@ kmer_scan2_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigne
 // The same tiling serves the power-of-two strides 2, 4, 8, 16 (a lane then owns 16/S windows, every S-th bit
 // position; 992 is a multiple of 16, so rounds stay aligned to the stride): S <= 4 crosses the strip, S >= 8
 // stores its 16 or 8 bytes per lane directly (already contiguous across lanes).
-template <int S, bool NTST>
+// U = consecutive rounds per wave trip: their loads are issued before the first is packed (the strip limits a CU to 16 waves,
+// so a wave with one 1 KiB load in flight leaves the read path idle while it stores its 8 KiB).
+template <int S, bool NTST, int U = 1>
 __global__ void __launch_bounds__(kBlock)
 kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long long rounds, unsigned long long *__restrict__ out,
                   unsigned long long *__restrict__ slot) {
@@ -407,10 +409,17 @@ kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long lon
     const unsigned long long nwaves = (unsigned long long)gridDim.x * (kBlock / 64);
     const uint32_t mlo = k >= 16 ? ~0u : (1u << (2 * k)) - 1u;
     const uint32_t mhi = k <= 16 ? 0u : (k == 32 ? ~0u : (1u << (2 * k - 32)) - 1u);
-    for (unsigned long long r = wave; r < rounds; r += nwaves) {
+    for (unsigned long long r0 = wave * U; r0 < rounds; r0 += nwaves * U) {
+      u32x4 vv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) vv[u] = load_group<true, true>(seq + (r0 + u < rounds ? r0 + u : rounds - 1) * kScanWaveWindows + 16 * lane);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned long long r = r0 + u;
+        if (r >= rounds) break; // wave-uniform
         const unsigned long long wb = r * kScanWaveWindows; // first base of the round
         unsigned long long *dst = out + r * RW;              // its first window
-        const u32x4 v = load_group<true, true>(seq + wb + 16 * lane);
+        const u32x4 v = vv[u];
         uint32_t bad = 0;
         const uint32_t c0 = enc16(v, bad);
         if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, wb + 16 * lane, 16, slot);
@@ -450,6 +459,7 @@ kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long lon
                 }
             }
         }
+      }
     }
 }
 
