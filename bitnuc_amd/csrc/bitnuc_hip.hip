@@ -344,6 +344,15 @@ inline size_t words_for(size_t n_bases) { return n_bases / 32 + (n_bases % 32 !=
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Alternative formulations that lost their A/B (profiles/) stay in the source as evidence, but only the evidence build
+// (-DBITNUC_SWEEP_VARIANTS, libbitnuc_hip_sweep.so: tools/ and the variant tests) instantiates them; in the product a
+// set_variant() to anything but the shipped value returns -2 and changes nothing.
+#ifdef BITNUC_SWEEP_VARIANTS
+constexpr bool kEvidenceBuild = true;
+#else
+constexpr bool kEvidenceBuild = false;
+#endif
+
 // ---- kernel-variant tables -------------------------------------------------------
 // The product library ships the variants that are in use: the tuned defaults (encode 14, decode 22), the plain
 // reference shape (0) and the previous default (3).  The other 43 and the lane-per-base ballot formulation are
@@ -489,7 +498,7 @@ hipError_t launch_decode_x2_t(bitnuc_ctx *c, int mode, const unsigned long long 
 
 hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsigned long long n_bases) {
     const bool in_al = aligned16(ebuf), out_al = aligned16(out);
-    if (c->dec_variant >= kX2First && c->dec_variant <= kX2Last && out_al) {
+    if constexpr (kEvidenceBuild) if (c->dec_variant >= kX2First && c->dec_variant <= kX2Last && out_al) {
         const unsigned long long tiles = n_bases >> 11; // whole 2 KiB (64-word) wave tiles
         if (tiles) {
             const int mode = c->dec_variant - kX2First;
@@ -532,6 +541,7 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
     default: DENSE_LAUNCH(true, true, true, U); break;               \
     }
         if (!aligned16(kmers)) { DENSE_LAUNCH(false, false, false, 1); }
+        else if constexpr (!kEvidenceBuild) { DENSE_LAUNCH(true, true, true, 1); } // the shipped form: dense_policy 3, dense_unroll 1
         else if (un == 1) { DENSE_POLICY(1) }
         else if (un == 2) { DENSE_POLICY(2) }
         else { DENSE_POLICY(4) }
@@ -552,10 +562,11 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         const unsigned long long per_wave = (unsigned long long)c->slide_rounds;
         const unsigned grid = grid_for(c, (rounds + per_wave * (kBlock / 64) - 1) / (per_wave * (kBlock / 64)));
         const bool nts = (c->dense_policy & 2) != 0;
-#define SLIDE_U(S, NT) do { if (per_wave == 2) kmer_slide_kernel<S, NT, 2><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); \
-                            else if (per_wave == 4) kmer_slide_kernel<S, NT, 4><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); \
-                            else if (per_wave == 8) kmer_slide_kernel<S, NT, 8><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); \
-                            else kmer_slide_kernel<S, NT, 1><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); } while (0)
+#define SLIDE_U(S, NT) do { if constexpr (kEvidenceBuild) { \
+                              if (per_wave == 2) { kmer_slide_kernel<S, NT, 2><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); break; } \
+                              if (per_wave == 4) { kmer_slide_kernel<S, NT, 4><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); break; } \
+                              if (per_wave == 8) { kmer_slide_kernel<S, NT, 8><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); break; } } \
+                            kmer_slide_kernel<S, NT, 1><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); } while (0)
 #define SLIDE(S) do { if (nts) SLIDE_U(S, true); else SLIDE_U(S, false); } while (0)
         switch (stride) {
         case 1: SLIDE(1); break;
@@ -621,7 +632,8 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
     case 2: SCAN2(false, true, U); break;                            \
     default: SCAN2(true, true, U); break;                            \
     }
-        if (unroll == 1) { SCAN2_POLICY(1) } else if (unroll == 2) { SCAN2_POLICY(2) } else { SCAN2_POLICY(4) }
+        if constexpr (!kEvidenceBuild) { SCAN2(true, true, 4); } // the shipped form: scan_policy 3, scan_unroll 4
+        else if (unroll == 1) { SCAN2_POLICY(1) } else if (unroll == 2) { SCAN2_POLICY(2) } else { SCAN2_POLICY(4) }
 #undef SCAN2_POLICY
 #undef SCAN2
         return hipGetLastError();
@@ -637,14 +649,10 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
     case 2: SCAN_LAUNCH(true, false, true, U); break;              \
     default: SCAN_LAUNCH(true, true, true, U); break;              \
     }
-    if (!al) {
+    if (!al || !kEvidenceBuild) { // the product reaches this only for unaligned pointers
         SCAN_LAUNCH(false, false, false, 1);
-    } else if (unroll == 1) {
-        SCAN_POLICY(1)
-    } else if (unroll == 2) {
-        SCAN_POLICY(2)
-    } else {
-        SCAN_POLICY(4)
+    } else if constexpr (kEvidenceBuild) {
+        if (unroll == 1) { SCAN_POLICY(1) } else if (unroll == 2) { SCAN_POLICY(2) } else { SCAN_POLICY(4) }
     }
 #undef SCAN_POLICY
 #undef SCAN_LAUNCH
@@ -765,7 +773,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
             c->enc_variant = value;
         }
     }
-    else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0) { if (!(value >= kX2First && value <= kX2Last) && !variant_info(value).built) return -2; c->dec_variant = value; } }
+    else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0) { if (!(kEvidenceBuild && value >= kX2First && value <= kX2Last) && !variant_info(value).built) return -2; c->dec_variant = value; } }
     else if (!strcmp(key, "force_gpu")) { prev = c->force_gpu; if (value == 0 || value == 1) c->force_gpu = value; }
     else if (!strcmp(key, "host_cutoff")) { prev = (int)(c->host_cutoff > 0x7FFFFFFF ? 0x7FFFFFFF : c->host_cutoff); if (value >= 0) c->host_cutoff = (size_t)value; }
     else if (!strcmp(key, "host_pipeline")) { prev = c->host_pipeline; if (value == 0 || value == 1) c->host_pipeline = value; }
@@ -779,16 +787,16 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
     else if (!strcmp(key, "batch_slide")) { prev = c->batch_slide; if (value >= 0 && value <= 1) c->batch_slide = value; }
-    else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && value <= 3) c->dense_policy = value; }
-    else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && value <= 3) c->scan_policy = value; }
+    else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && !kEvidenceBuild && value != 3) return -2; if (value >= 0 && value <= 3) c->dense_policy = value; }
+    else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && !kEvidenceBuild && value != 3) return -2; if (value >= 0 && value <= 3) c->scan_policy = value; }
     else if (!strcmp(key, "fixed_stream")) { prev = c->fixed_stream; if (value == 0 || value == 1) c->fixed_stream = value; }
-    else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value >= 0 && value <= 2) c->fixed_dec_strip = value; }
+    else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value >= 0 && !kEvidenceBuild && value != 2) return -2; if (value >= 0 && value <= 2) c->fixed_dec_strip = value; }
     else if (!strcmp(key, "owner_est")) { prev = c->owner_est; if (value >= 0 && value <= 3) c->owner_est = value; }
     else if (!strcmp(key, "batch_host_plan")) { prev = c->batch_host_plan; if (value == 0 || value == 1) c->batch_host_plan = value; }
-    else if (!strcmp(key, "plan_tiles")) { prev = c->plan_tiles; if (value == 1 || value == 2 || value == 4) c->plan_tiles = value; }
-    else if (!strcmp(key, "plan_enc_tiles")) { prev = c->plan_enc_tiles; if (value == 1 || value == 2 || value == 4) c->plan_enc_tiles = value; }
-    else if (!strcmp(key, "slide_rounds")) { prev = c->slide_rounds; if (value == 1 || value == 2 || value == 4 || value == 8) c->slide_rounds = value; }
-    else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && value <= 2) c->plan_store = value; }
+    else if (!strcmp(key, "plan_tiles")) { prev = c->plan_tiles; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->plan_tiles = value; }
+    else if (!strcmp(key, "plan_enc_tiles")) { prev = c->plan_enc_tiles; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->plan_enc_tiles = value; }
+    else if (!strcmp(key, "slide_rounds")) { prev = c->slide_rounds; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4 || value == 8) c->slide_rounds = value; }
+    else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && !kEvidenceBuild && value != 2) return -2; if (value >= 0 && value <= 2) c->plan_store = value; }
     else if (!strcmp(key, "batch_abl")) {
         prev = c->batch_abl;
 #ifdef BITNUC_SWEEP_VARIANTS
@@ -798,9 +806,9 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
 #endif
     }
     else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
-    else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
-    else if (!strcmp(key, "scan_impl")) { prev = c->scan_impl; if (value == 0 || value == 1) c->scan_impl = value; }
-    else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
+    else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
+    else if (!strcmp(key, "scan_impl")) { prev = c->scan_impl; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 0 || value == 1) c->scan_impl = value; }
+    else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value >= 0 && !kEvidenceBuild && value != 4) return -2; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
     else if (!strcmp(key, "reduce_mult")) { prev = (int)(c->reduce_blocks / (unsigned)c->num_cu); if (value >= 1 && value <= 32) c->reduce_blocks = (unsigned)c->num_cu * (unsigned)value; }
     else if (!strcmp(key, "num_variants")) { prev = kNumVariants; }
     else if (!strcmp(key, "num_cu")) { prev = c->num_cu; }
@@ -1514,9 +1522,13 @@ int bitnuc_encode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, cons
     const unsigned long long U = (unsigned long long)c->plan_enc_tiles;
     const unsigned grid = grid_for(c, (blocks + U - 1) / U);
 #define PLAN_ENC(UU) encode_batch_plan_kernel<UU><<<grid, kBlock, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end, o, slot)
-    if (U == 2) PLAN_ENC(2);
-    else if (U == 4) PLAN_ENC(4);
-    else PLAN_ENC(1);
+    if constexpr (kEvidenceBuild) {
+        if (U == 2) PLAN_ENC(2);
+        else if (U == 4) PLAN_ENC(4);
+        else PLAN_ENC(1);
+    } else {
+        PLAN_ENC(1);
+    }
 #undef PLAN_ENC
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
@@ -1535,9 +1547,13 @@ int bitnuc_decode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, cons
     const unsigned grid2 = grid_for(c, (p->total_words + per_block2 - 1) / per_block2);
 #define PLAN_DEC(POL, U) decode_batch_plan_kernel<POL, U><<<grid2, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out)
 #define PLAN_DEC_U(POL) do { if (tiles_per_wave == 1) PLAN_DEC(POL, 1); else if (tiles_per_wave == 2) PLAN_DEC(POL, 2); else PLAN_DEC(POL, 4); } while (0)
-    if (c->plan_store == 0) PLAN_DEC_U(0);
-    else if (c->plan_store == 1) PLAN_DEC_U(1);
-    else PLAN_DEC_U(2);
+    if constexpr (kEvidenceBuild) {
+        if (c->plan_store == 0) PLAN_DEC_U(0);
+        else if (c->plan_store == 1) PLAN_DEC_U(1);
+        else PLAN_DEC_U(2);
+    } else {
+        PLAN_DEC(2, 1);
+    }
 #undef PLAN_DEC_U
 #undef PLAN_DEC
     HIPCHK(hipGetLastError());
@@ -1582,10 +1598,12 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
     const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
     const unsigned magic = (unsigned)((0x100000000ull + wpr - 1) / wpr);
     const unsigned long long magic64 = wpr == 1 ? 0ull : ~0ull / wpr + 1;
-    if (stride == read_len && c->fixed_dec_strip == 2) decode_fixed_tile_kernel<2><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
-    else if (stride == read_len && c->fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
-    else if (stride == read_len) decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
-    else decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
+    if (stride != read_len) decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
+    else if (c->fixed_dec_strip == 2 || !kEvidenceBuild) decode_fixed_tile_kernel<2><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
+    else if constexpr (kEvidenceBuild) {
+        if (c->fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
+        else decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
+    }
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }

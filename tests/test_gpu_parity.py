@@ -131,13 +131,9 @@ def test_encode_decode_variants_vs_oracle(sweep_ctx, oracle, variant):
         ctx.set_variant("decode", dec0)
 
 
-def test_product_ships_only_the_variants_in_use(ctx, oracle):
-    assert ctx.get("sweep_build") == 0
-    built = [v for v in range(47) if ctx.set_variant("encode", v) != -2]
-    ctx.set_variant("encode", 14)
-    assert built == [0, 3, 14, 22]
-    assert ctx.set_variant("encode", 100) == -2 and ctx.get("encode") == 14  # the ballot formulation is evidence, not product
-    # decode variants 47..54: 8-byte loads + LDS transpose (decode_x2_kernel) for the whole 2 KiB tiles, default kernel for the tail
+def test_decode_x2_variants_vs_oracle(sweep_ctx, oracle):
+    """decode variants 47..54: 8-byte loads + LDS transpose (decode_x2_kernel) for the whole 2 KiB tiles, default kernel for the tail."""
+    ctx = sweep_ctx
     dec0 = ctx.get("decode")
     try:
         for v in range(47, 55):
@@ -149,6 +145,21 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     finally:
         ctx.set_variant("decode", dec0)
     assert ctx.set_variant("decode", 55) == -2
+
+
+def test_product_ships_only_the_variants_in_use(ctx, oracle):
+    assert ctx.get("sweep_build") == 0
+    built = [v for v in range(47) if ctx.set_variant("encode", v) != -2]
+    ctx.set_variant("encode", 14)
+    assert built == [0, 3, 14, 22]
+    assert ctx.set_variant("encode", 100) == -2 and ctx.get("encode") == 14  # the ballot formulation is evidence, not product
+    assert all(ctx.set_variant("decode", v) == -2 for v in range(47, 56)) and ctx.get("decode") == 22  # decode_x2_kernel: evidence build
+    # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
+    for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
+                                 ("slide_rounds", 1, (2, 4, 8)), ("scan_impl", 1, (0,)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
+                                 ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,))):
+        assert ctx.get(key) == shipped, key
+        assert all(ctx.set_variant(key, v) == -2 for v in others) and ctx.get(key) == shipped, key
     for v in built:
         enc0, dec0 = ctx.set_variant("encode", v), ctx.set_variant("decode", v)
         try:
@@ -478,7 +489,9 @@ def test_kmer_batch_errors(ctx, oracle):
 @pytest.mark.parametrize("impl", [1, 0], ids=["rounds1024", "rounds992"])
 @pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 32])
-def test_scan_vs_oracle(ctx, oracle, k, unroll, impl):
+def test_scan_vs_oracle(ctx, sweep_ctx, oracle, k, unroll, impl):
+    if (impl, unroll) != (1, 4):
+        ctx = sweep_ctx  # the product ships only the form in use; the alternatives live in the evidence build
     prev_impl = ctx.set_variant("scan_impl", impl)
     ctx.set_variant("scan_unroll", unroll)
     for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 1057, 2015, 2016, 2017, 2047, 2048, 2079, 2080, 2081, 4127, 4128, 4129, 5000, 5152, 200003]:
@@ -573,23 +586,26 @@ def _oracle_batch(oracle, seq, off):
 
 
 @pytest.fixture(params=[(1, 1), (1, 2), (1, 4), (0, 1)], ids=["plan", "plan-2tiles", "plan-4tiles", "tables"])
-def batch_body(request, ctx):
-    """Both formulations of the ragged-batch kernels behind the host-pointer entry points: the layout plan
-    (bitnuc_batch_plan: one pad byte per word; what host calls use; its kernels with 1, 2 and 4 tiles per wave trip) and
-    the table-driven kernels (tile records + O(1) pad-scatter lookup from the two offset tables; what the *_dev table
-    entry points use)."""
+def batch_ctx(request, ctx, sweep_ctx):
+    """A context set to one formulation of the ragged-batch kernels behind the host-pointer entry points: the layout plan
+    (bitnuc_batch_plan: one pad byte per word; what host calls use) or the table-driven kernels (tile records + O(1)
+    pad-scatter lookup from the two offset tables; what the *_dev table entry points use).  The plan kernels with 2 and 4
+    tiles per wave trip exist in the evidence build only (they lost their A/B)."""
     use_plan, tiles = request.param
-    prev = ctx.set_variant("batch_host_plan", use_plan)
-    prev_e = ctx.set_variant("plan_enc_tiles", tiles)
-    prev_d = ctx.set_variant("plan_tiles", tiles)
-    yield use_plan
-    ctx.set_variant("batch_host_plan", prev)
-    ctx.set_variant("plan_enc_tiles", prev_e)
-    ctx.set_variant("plan_tiles", prev_d)
+    c = ctx if tiles == 1 else sweep_ctx
+    prev = c.set_variant("batch_host_plan", use_plan)
+    prev_e = c.set_variant("plan_enc_tiles", tiles)
+    prev_d = c.set_variant("plan_tiles", tiles)
+    assert c.get("plan_enc_tiles") == tiles and c.get("plan_tiles") == tiles
+    yield c
+    c.set_variant("batch_host_plan", prev)
+    c.set_variant("plan_enc_tiles", prev_e)
+    c.set_variant("plan_tiles", prev_d)
 
 
 @pytest.mark.parametrize("shape", ["reads150", "tiny", "mixed", "with_empties", "one_long", "many_empties", "len32", "ones_and_empties", "unaligned_long"])
-def test_batch_encode_decode_vs_oracle_loop(ctx, oracle, shape, batch_body):
+def test_batch_encode_decode_vs_oracle_loop(batch_ctx, oracle, shape):
+    ctx = batch_ctx
     lengths = {
         "reads150": [150] * 3000,
         "tiny": list(RNG.integers(1, 5, size=5000)),
@@ -610,7 +626,8 @@ def test_batch_encode_decode_vs_oracle_loop(ctx, oracle, shape, batch_body):
     assert bytes(back) == bytes(seq).upper(), shape
 
 
-def test_batch_offsets_base_and_errors(ctx, oracle, batch_body):
+def test_batch_offsets_base_and_errors(batch_ctx, oracle):
+    ctx = batch_ctx
     import bitnuc_amd as bn
     lengths = list(RNG.integers(1, 300, size=1500))
     seq, off = _ragged(lengths)
@@ -1442,11 +1459,13 @@ def test_fixed_reads_vs_oracle_loop(ctx, oracle, read_len, stride):
 
 
 @pytest.mark.parametrize("body", [2, 1], ids=["shared-tile-body", "strip-64bit-positions"])
-def test_decode_fixed_contiguous_every_alignment(ctx, oracle, body):
+def test_decode_fixed_contiguous_every_alignment(ctx, sweep_ctx, oracle, body):
     """Back-to-back reads: whole output compared, at several output alignments, with junk in the pad bits of each
     read's last word, and with guard bytes around the run."""
     import torch
     dev = torch.device("cuda:0")
+    if body != 2:
+        ctx = sweep_ctx  # the earlier kernel exists in the evidence build only
     prev = ctx.set_variant("fixed_dec_strip", body)
     try:
         for read_len, count in [(16, 700), (17, 333), (31, 500), (32, 129), (33, 257), (47, 100), (64, 65), (100, 1001), (150, 777),

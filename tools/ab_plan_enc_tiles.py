@@ -13,7 +13,9 @@ import bitnuc_amd
 
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
-ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+from bitnuc_amd import build as _build
+
+ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=_build.ensure_built(sweep=True))  # the evidence build holds the alternatives
 N = 10**9
 seq = torch.empty(N, dtype=torch.uint8, device=dev)
 ctx.nucgen_dev(seq, N, 0xB17C0DE)

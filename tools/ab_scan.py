@@ -12,7 +12,9 @@ import bitnuc_amd
 
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
-ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+from bitnuc_amd import build as _build
+
+ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=_build.ensure_built(sweep=True))  # the evidence build holds the alternatives
 n, k = 10**9, 31
 q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
 refs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
