@@ -862,6 +862,54 @@ def test_beyond_4gib_batches(ctx, oracle):
     ctx.decode_batch_dev(words, wo, off, count, total, back)
     ctx.sync()
     assert torch.equal(back, seq[: count * L])
+    # the layout plan on the same batch: tile bases past 2^32, same words, same bases
+    import bitnuc_amd as bn
+    plan = bn.BatchPlan(ctx, off, count)
+    assert plan.total_words == total
+    w3 = torch.zeros(total, dtype=torch.int64, device=dev)
+    back.zero_()
+    torch.cuda.synchronize()
+    plan.encode_dev(seq, w3)
+    plan.decode_dev(w3, back)
+    ctx.sync()
+    assert torch.equal(w3, words) and torch.equal(back, seq[: count * L])
+    plan.close()
+
+
+def test_batch_fuzz_vs_oracle_loop(ctx, oracle):
+    """Random ragged batches (length mixes incl. empties and sub-word sequences, a batch that starts anywhere in its buffer,
+    lower case) through the plan and the table-driven kernels, against the oracle's per-sequence loop; then one invalid byte
+    at a random position: (byte, index) of the first one in buffer order."""
+    import bitnuc_amd as bn
+    rng = np.random.default_rng(20260)
+    mixes = [lambda m: rng.integers(0, 4, size=m), lambda m: rng.integers(1, 70, size=m), lambda m: rng.integers(100, 260, size=m),
+             lambda m: np.where(rng.random(m) < 0.3, 0, rng.integers(1, 40, size=m)), lambda m: rng.integers(1, 5000, size=m),
+             lambda m: np.where(rng.random(m) < 0.9, 32, rng.integers(0, 3, size=m)), lambda m: np.full(m, 64) + rng.integers(0, 2, size=m)]
+    for trial in range(28):
+        lengths = [int(x) for x in mixes[trial % len(mixes)](int(rng.integers(1, 1500)))]
+        seq, off = _ragged(lengths)
+        pre = int(rng.integers(0, 40))
+        buf = np.concatenate([np.full(pre, ord("N"), np.uint8), seq, np.full(int(rng.integers(0, 20)), ord("N"), np.uint8)])
+        off2 = off + np.uint64(pre)
+        ew, ewo = _oracle_batch(oracle, seq, off)
+        for use_plan in (1, 0):
+            prev = ctx.set_variant("batch_host_plan", use_plan)
+            try:
+                w, wo = ctx.encode_batch(buf, off2)
+                assert np.array_equal(wo, ewo) and np.array_equal(w, ew), (trial, use_plan)
+                back = ctx.decode_batch(w, wo, off2)
+                assert bytes(back[pre:pre + len(seq)]) == bytes(seq).upper(), (trial, use_plan)
+                if len(seq):
+                    bad = buf.copy()
+                    pos = pre + int(rng.integers(0, len(seq)))
+                    later = pre + int(rng.integers(pos - pre, len(seq)))
+                    bad[later] = ord("X")
+                    bad[pos] = 0xFF if trial & 1 else ord("n")
+                    with pytest.raises(bn.NucleotideError) as ei:
+                        ctx.encode_batch(bad, off2)
+                    assert (ei.value.kind, ei.value.byte, ei.value.index) == ("InvalidBase", int(bad[pos]), pos), (trial, use_plan)
+            finally:
+                ctx.set_variant("batch_host_plan", prev)
 
 
 def test_hbm_scale_round_trip(ctx, oracle):
