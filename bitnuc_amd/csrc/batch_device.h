@@ -138,12 +138,17 @@ block_owner_kernel(const unsigned long long *__restrict__ offsets, const unsigne
 }
 
 // ---------------------------------------------------------------------------------
-// word offsets: exclusive scan of ceil(len_i / 32), three small kernels
+// word offsets: exclusive scan of ceil(len_i / 32) -- and, fused into its last pass, the layout plan
 // ---------------------------------------------------------------------------------
-constexpr int kScanItems = 16; // per thread
-__device__ __forceinline__ unsigned long long words_of(const unsigned long long *__restrict__ offsets, unsigned long long i) {
-    return (offsets[i + 1] - offsets[i] + 31) >> 5;
-}
+// Three launches: per-workgroup sums, a one-workgroup scan of those sums, and the pass that writes the offsets.  A thread
+// owns kScanPer = 8 CONSECUTIVE sequences: their nine offsets are four 16-byte loads plus one 8-byte load (the lanes of a
+// wave read 4 KiB contiguous), the serial part of the scan runs in registers, and the eight results leave as four
+// 16-byte stores.  (Round 1's version staged 16 counts per thread through LDS at a stride of 16 dwords: 10-13 bank-conflict
+// cycles per LDS instruction and 59 us for 6.7 M sequences, profiles/r02_batch_pmc1.txt.)  The last pass also has everything
+// plan_emit_kernel needs -- a sequence's first / one-past-last word and byte -- so the plan's pad bytes and tile bases are
+// written there (EMIT) instead of by a fourth pass that re-reads both tables.
+constexpr int kScanPer = 8;
+constexpr int kScanTile = kBlock * kScanPer; // sequences per workgroup
 
 __device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long long v, unsigned long long *total) {
     // exclusive scan of one value per thread across the workgroup
@@ -167,50 +172,44 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long
     return before + inc - v;
 }
 
-// A workgroup owns kBlock*kScanItems consecutive sequences.  Global accesses are coalesced
-// (sequence t + kBlock*j in round j); the per-thread serial part (16 consecutive sequences
-// per thread, needed for the scan order) runs on an LDS copy of the word counts.
-constexpr int kScanTile = kBlock * kScanItems;
-
-__device__ __forceinline__ void load_counts_to_lds(const unsigned long long *__restrict__ offsets, unsigned long long count,
-                                                   unsigned long long i0, uint32_t *cnt /* [kScanTile] */) {
-    for (int j = 0; j < kScanItems; ++j) {
-        const unsigned long long i = i0 + (unsigned long long)j * kBlock + threadIdx.x;
-        // ceil(len/32) of one sequence fits u32 for sequences < 2^37 bases; longer ones saturate the
-        // u32 and are re-read exactly in the serial part below
-        unsigned long long w = i < count ? words_of(offsets, i) : 0ull;
-        cnt[j * kBlock + threadIdx.x] = w > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)w;
+// o[j] = offsets[min(i + j, count)], j = 0..8: entries past the table repeat its last one (sequences of length 0)
+__device__ __forceinline__ void load_offsets9(const unsigned long long *__restrict__ offsets, unsigned long long count, unsigned long long i,
+                                              unsigned long long (&o)[kScanPer + 1]) {
+    if (i + kScanPer <= count) {
+        const u32x4_u *src = reinterpret_cast<const u32x4_u *>(offsets + i); // any 8-byte aligned table (gfx950 unaligned-access mode)
+#pragma unroll
+        for (int q = 0; q < kScanPer / 2; ++q) {
+            const u32x4 v = src[q];
+            o[2 * q] = ((unsigned long long)v.y << 32) | v.x;
+            o[2 * q + 1] = ((unsigned long long)v.w << 32) | v.z;
+        }
+        o[kScanPer] = offsets[i + kScanPer];
+    } else {
+#pragma unroll
+        for (int j = 0; j <= kScanPer; ++j) o[j] = offsets[i + j < count ? i + j : count];
     }
-    __syncthreads();
-}
-
-__device__ __forceinline__ unsigned long long count_at(const unsigned long long *__restrict__ offsets, unsigned long long i,
-                                                       const uint32_t *cnt, unsigned local) {
-    const uint32_t c = cnt[local];
-    return c == 0xFFFFFFFFu ? words_of(offsets, i) : c;
 }
 
 __global__ void __launch_bounds__(kBlock)
 word_offsets_block_sums(const unsigned long long *__restrict__ offsets, unsigned long long count,
                         unsigned long long *__restrict__ block_sums) {
-    __shared__ uint32_t cnt[kScanTile];
-    const unsigned long long i0 = (unsigned long long)blockIdx.x * kScanTile;
-    load_counts_to_lds(offsets, count, i0, cnt);
-    unsigned long long s = 0;
-    for (int j = 0; j < kScanItems; ++j) {
-        const unsigned local = threadIdx.x * kScanItems + j;
-        if (i0 + local < count) s += count_at(offsets, i0 + local, cnt, local);
-    }
+    const unsigned long long i = (unsigned long long)blockIdx.x * kScanTile + (unsigned long long)threadIdx.x * kScanPer;
+    unsigned long long o[kScanPer + 1], s = 0;
+    load_offsets9(offsets, count, i, o);
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) s += (o[j + 1] - o[j] + 31) >> 5;
     unsigned long long total;
     block_exclusive_scan(s, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
+// one workgroup: exclusive scan of the block sums in place; block_sums[nblocks .. nblocks+2] = the grand total, offsets[0],
+// offsets[count] (what the host needs to size a plan: one 24-byte copy)
 __global__ void __launch_bounds__(kBlock)
-word_offsets_scan_sums(unsigned long long *__restrict__ block_sums, unsigned long long nblocks) {
-    // single workgroup: thread t owns a contiguous chunk of the block sums
+word_offsets_scan_sums(unsigned long long *__restrict__ block_sums, unsigned long long nblocks, const unsigned long long *__restrict__ offsets,
+                       unsigned long long count) {
     const unsigned long long per = (nblocks + kBlock - 1) / kBlock;
-    const unsigned long long b0 = threadIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    const unsigned long long b0 = threadIdx.x * per < nblocks ? threadIdx.x * per : nblocks, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     unsigned long long s = 0;
     for (unsigned long long b = b0; b < b1; ++b) s += block_sums[b];
     unsigned long long total;
@@ -220,34 +219,71 @@ word_offsets_scan_sums(unsigned long long *__restrict__ block_sums, unsigned lon
         block_sums[b] = run;
         run += v;
     }
+    if (threadIdx.x == 0) {
+        block_sums[nblocks] = total;
+        block_sums[nblocks + 1] = offsets[0];
+        block_sums[nblocks + 2] = offsets[count];
+    }
 }
 
+// The plan entries of one sequence: words [a, b), bytes [o, e).  P[b] = what its last word lacks (seen by the word after
+// it); tile_base[t] for every 64-word tile whose first word it owns.  Call from all 64 lanes (wave-uniform control flow):
+// a long sequence hands its tile bases to the whole wave.
+__device__ __forceinline__ void plan_emit_sequence(unsigned long long a, unsigned long long b, unsigned long long o, unsigned long long e, bool valid,
+                                                   uint8_t *__restrict__ P, unsigned long long *__restrict__ tile_base) {
+    const unsigned lane = threadIdx.x & 63;
+    const bool has_words = valid && b > a;
+    if (has_words) P[b] = (uint8_t)(32ull * (b - a) - (e - o));
+    const unsigned long long t0 = (a + 63) >> 6, t1 = has_words ? (b + 63) >> 6 : t0; // tile boundaries 64 t inside [a, b)
+    const bool is_long = t1 - t0 > 8;
+    if (!is_long)
+        for (unsigned long long t = t0; t < t1; ++t) tile_base[t] = o + (((t << 6) - a) << 5);
+    unsigned long long m = __ballot(is_long);
+    while (m) {
+        const unsigned l = (unsigned)__builtin_ctzll(m);
+        m &= m - 1;
+        const unsigned long long A = read_lane_u64(a, l), O = read_lane_u64(o, l), T0 = read_lane_u64(t0, l), T1 = read_lane_u64(t1, l);
+        for (unsigned long long t = T0 + lane; t < T1; t += 64) tile_base[t] = O + (((t << 6) - A) << 5);
+    }
+}
+
+template <bool EMIT>
 __global__ void __launch_bounds__(kBlock)
 word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned long long count,
-                    const unsigned long long *__restrict__ block_sums, unsigned long long *__restrict__ word_offsets) {
-    __shared__ uint32_t cnt[kScanTile];
-    __shared__ unsigned long long res[kScanTile];
-    const unsigned long long i0 = (unsigned long long)blockIdx.x * kScanTile;
-    load_counts_to_lds(offsets, count, i0, cnt);
-    unsigned long long v[kScanItems], s = 0;
-    for (int j = 0; j < kScanItems; ++j) {
-        const unsigned local = threadIdx.x * kScanItems + j;
-        v[j] = i0 + local < count ? count_at(offsets, i0 + local, cnt, local) : 0;
-        s += v[j];
+                    const unsigned long long *__restrict__ block_sums, unsigned long long *__restrict__ word_offsets,
+                    uint8_t *__restrict__ P /* EMIT: zeroed, total_words + 1 */, unsigned long long *__restrict__ tile_base) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * kScanTile + (unsigned long long)threadIdx.x * kScanPer;
+    unsigned long long o[kScanPer + 1], c[kScanPer], s = 0;
+    load_offsets9(offsets, count, i, o);
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        c[j] = (o[j + 1] - o[j] + 31) >> 5;
+        s += c[j];
     }
     unsigned long long total;
     unsigned long long run = block_sums[blockIdx.x] + block_exclusive_scan(s, &total);
-    for (int j = 0; j < kScanItems; ++j) {
-        res[threadIdx.x * kScanItems + j] = run;
-        run += v[j];
+    unsigned long long w[kScanPer + 1];
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        w[j] = run;
+        run += c[j];
     }
-    __syncthreads();
-    for (int j = 0; j < kScanItems; ++j) { // coalesced write-out
-        const unsigned local = j * kBlock + threadIdx.x;
-        if (i0 + local < count) word_offsets[i0 + local] = res[local];
+    w[kScanPer] = run;
+    if (i + kScanPer <= count) {
+        u32x4_u *dst = reinterpret_cast<u32x4_u *>(word_offsets + i);
+#pragma unroll
+        for (int q = 0; q < kScanPer / 2; ++q)
+            dst[q] = u32x4{(uint32_t)w[2 * q], (uint32_t)(w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)(w[2 * q + 1] >> 32)};
+        if (i + kScanPer == count) word_offsets[count] = run; // the grand total, by the thread that holds the last sequence
+    } else {
+#pragma unroll
+        for (int j = 0; j <= kScanPer; ++j)
+            if (i + j <= count) word_offsets[i + j] = w[j]; // j with i + j == count: the grand total
     }
-    // total number of words: written by the workgroup that holds the last sequence
-    if (threadIdx.x == kBlock - 1 && i0 + kScanTile >= count) word_offsets[count] = block_sums[blockIdx.x] + total;
+    if constexpr (EMIT) {
+#pragma unroll
+        for (int j = 0; j < kScanPer; ++j) plan_emit_sequence(w[j], w[j + 1], o[j], o[j + 1], i + j < count, P, tile_base);
+    }
 }
 
 // ---- the wave-private LDS strip of 32-bit chunk words (codes of 16 bases), shared by every tile kernel below ----------
@@ -836,36 +872,12 @@ decode_batch2_kernel(const unsigned long long *__restrict__ words, const unsigne
 // and often many times.  The plan therefore holds, per layout:
 //   tile_base[t]  byte offset of word 64 t (one u64 per wave tile), and
 //   P[w]          one byte per word: the padding of the sequence that ENDS at word w-1 (0..31; 0 when word w does
-//                 not start a sequence) -- written by one streaming pass over the two offset tables (plan_emit_kernel).
+//                 not start a sequence) -- written by the last pass of the word-offsets scan (word_offsets_finish<true>).
 // A lane's lookup is then ONE byte load, issued together with the tile's data, and a DPP prefix sum:
 //   n  = P[wb + lane + 1]          what word (wb + lane) lacks to 32 bases,
 //   nb = 32 - n,    first byte = tile_base + 32 lane - (sum of n over the lanes before it).
 // No window, no search, no LDS for the lookup, no dependent global load, no per-call pre-kernel.
-__global__ void __launch_bounds__(kBlock)
-plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets, unsigned long long count,
-                 uint8_t *__restrict__ P /* zeroed, total_words + 1 */, unsigned long long *__restrict__ tile_base) {
-    const unsigned lane = threadIdx.x & 63;
-    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < count; base += (unsigned long long)gridDim.x * kBlock) { // block-uniform trip count
-        const unsigned long long i = base + threadIdx.x;
-        const bool valid = i < count;
-        const unsigned long long a = valid ? word_offsets[i] : 0, b = valid ? word_offsets[i + 1] : 0;
-        const unsigned long long o = valid ? offsets[i] : 0, e = valid ? offsets[i + 1] : 0;
-        const bool has_words = b > a;
-        if (has_words) P[b] = (uint8_t)(32ull * (b - a) - (e - o)); // what this sequence's last word lacks; seen by the word after it
-        // tile boundaries 64 t inside [a, b): this sequence owns the first word of tile t
-        const unsigned long long t0 = (a + 63) >> 6, t1 = has_words ? (b + 63) >> 6 : t0;
-        const bool is_long = t1 - t0 > 8;
-        if (!is_long)
-            for (unsigned long long t = t0; t < t1; ++t) tile_base[t] = o + (((t << 6) - a) << 5);
-        unsigned long long m = __ballot(is_long); // long sequences: the whole wave writes their tile records
-        while (m) {
-            const unsigned l = (unsigned)__builtin_ctzll(m);
-            m &= m - 1;
-            const unsigned long long A = read_lane_u64(a, l), O = read_lane_u64(o, l), T0 = read_lane_u64(t0, l), T1 = read_lane_u64(t1, l);
-            for (unsigned long long t = T0 + lane; t < T1; t += 64) tile_base[t] = O + (((t << 6) - A) << 5);
-        }
-    }
-}
+// (The plan is written by word_offsets_finish<true> above: plan_emit_sequence.)
 
 // One tile of the plan encode.  issue: the tile's 16-byte chunks (2 per lane), one dword of the 129th chunk (an unaligned
 // tile's last <= 15 bytes; lanes 0-3) and the lane's pad byte.  Every load is unconditional with a clamped, in-bounds

@@ -1270,13 +1270,13 @@ int bitnuc_batch_word_offsets_dev(bitnuc_ctx *c, const uint64_t *d_offsets, size
     }
     const size_t per_block = (size_t)kScanTile;
     const size_t nblocks = (count + per_block - 1) / per_block;
-    if (int st = ensure_scratch(c, 3, nblocks * sizeof(uint64_t), err)) return st;
+    if (int st = ensure_scratch(c, 3, (nblocks + 3) * sizeof(uint64_t), err)) return st;
     unsigned long long *sums = reinterpret_cast<unsigned long long *>(c->scratch[3]);
     const unsigned long long *off = reinterpret_cast<const unsigned long long *>(d_offsets);
     unsigned long long *wo = reinterpret_cast<unsigned long long *>(d_word_offsets);
     word_offsets_block_sums<<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums);
-    word_offsets_scan_sums<<<1, kBlock, 0, c->stream>>>(sums, nblocks);
-    word_offsets_finish<<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums, wo);
+    word_offsets_scan_sums<<<1, kBlock, 0, c->stream>>>(sums, nblocks, off, count);
+    word_offsets_finish<false><<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums, wo, nullptr, nullptr);
     HIPCHK(hipGetLastError());
     uint64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, d_word_offsets + count, sizeof total, hipMemcpyDeviceToHost, c->stream));
@@ -1481,27 +1481,36 @@ int bitnuc_batch_plan_build_dev(bitnuc_ctx *c, bitnuc_batch_plan *p, const uint6
     DeviceGuard g(c->device);
     p->built = false;
     if (int st = plan_reserve(&p->d_wo, &p->cap_wo, count + 1, c->stream, err)) return st;
-    size_t total = 0;
-    if (int st = bitnuc_batch_word_offsets_dev(c, d_offsets, count, reinterpret_cast<uint64_t *>(p->d_wo), &total, err)) return st; // synchronous: total is known
+    // sums -> scan of the sums -> (host learns the total and sizes the plan) -> offsets + pad bytes + tile bases in one pass
+    unsigned long long ends[3] = {0, 0, 0}; // total words, offsets[0], offsets[count]
+    const size_t nblocks = (count + kScanTile - 1) / kScanTile;
+    const unsigned long long *off = reinterpret_cast<const unsigned long long *>(d_offsets);
+    unsigned long long *sums = nullptr;
+    if (count) {
+        if (int st = ensure_scratch(c, 3, (nblocks + 3) * sizeof(uint64_t), err)) return st;
+        sums = reinterpret_cast<unsigned long long *>(c->scratch[3]);
+        word_offsets_block_sums<<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums);
+        word_offsets_scan_sums<<<1, kBlock, 0, c->stream>>>(sums, nblocks, off, count);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ends, sums + nblocks, sizeof ends, hipMemcpyDeviceToHost, c->stream)); // total, offsets[0], offsets[count]
+        HIPCHK(hipStreamSynchronize(c->stream));
+    } else {
+        HIPCHK(hipMemsetAsync(p->d_wo, 0, sizeof(uint64_t), c->stream));
+    }
+    const size_t total = (size_t)ends[0];
     p->count = count;
     p->total_words = total;
-    unsigned long long ends[2] = {0, 0};
-    if (count) {
-        HIPCHK(hipMemcpyAsync(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(&ends[1], d_offsets + count, 8, hipMemcpyDeviceToHost, c->stream));
-    }
     const size_t ntiles = (total + kBatchTile - 1) / kBatchTile;
     if (int st = plan_reserve(&p->d_base, &p->cap_base, ntiles + 1, c->stream, err)) return st;
     if (int st = plan_reserve(&p->d_P, &p->cap_P, total + 2 + kBatchTile, c->stream, err)) return st;
     HIPCHK(hipMemsetAsync(p->d_P, 0, total + 2 + kBatchTile, c->stream));
-    if (count && total) {
-        const unsigned long long blocks = (count + kBlock - 1) / kBlock, cap = (unsigned long long)c->num_cu * 16;
-        plan_emit_kernel<<<(unsigned)(blocks < cap ? blocks : cap), kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_offsets), p->d_wo, count, p->d_P, p->d_base);
+    if (count) {
+        word_offsets_finish<true><<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums, p->d_wo, p->d_P, p->d_base);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    p->seq_begin = ends[0];
-    p->seq_end = ends[1];
+    HIPCHK(hipStreamSynchronize(c->stream)); // the build is synchronous: the plan's tables may be read on any stream afterwards
+    p->seq_begin = ends[1];
+    p->seq_end = ends[2];
     p->built = true;
     if (total_words) *total_words = total;
     return BITNUC_OK;
