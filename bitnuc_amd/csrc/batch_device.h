@@ -25,6 +25,15 @@ constexpr int kBatchTile = 64;                      // words per WAVE: every wav
 constexpr int kBatchStage = kBatchTile * 32 + 128;  // 2 KiB span + alignment / read-ahead slack, per wave
 constexpr int kBatchWaves = kBlock / 64;            // waves (= tiles in flight) per workgroup
 
+// Cache policy of the PACKED-WORD stores of every read-batch encode (0.25 B per base): streaming (nt).  Allocating stores --
+// what the bulk encode's variant 14 uses, where they won the PAIR sweep of round 1 -- make these kernels 3-13 % slower in
+// encode-only bursts (profiles/r02_ab_encode_word_store_policy.txt).
+constexpr bool kEncWordsNT = true;
+template <class T> __device__ __forceinline__ void store_packed(T v, T *p) {
+    if constexpr (kEncWordsNT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // index of the sequence that owns word w: upper_bound(word_offsets[0..count], w) - 1
 __device__ __forceinline__ unsigned long long owner_of_word(const unsigned long long *__restrict__ wo,
                                                             unsigned long long count, unsigned long long w) {
@@ -416,7 +425,7 @@ encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned
         if (!GAPS && use_stream) { // back-to-back reads: cut the tile's 2-bit stream at the word starts
             const unsigned long long word = encode_word_from_stream(seq, seq_end, span_lo, read_lane_u64(base + nb, last), base, nb,
                                                                     reinterpret_cast<uint32_t *>(my.stage), slot);
-            if (active) __builtin_nontemporal_store(word, out + w);
+            if (active) store_packed(word, out + w);
             continue;
         }
         const bool staged = hi - lo16 <= (uintptr_t)(kBatchStage - 16); // wave-uniform
@@ -459,7 +468,7 @@ encode_fixed_kernel(const uint8_t *__restrict__ seq, unsigned read_len, unsigned
         const unsigned long long keep = nb >= 32 ? ~0ull : ((1ull << (2 * nb)) - 1);
         wlo &= (uint32_t)keep;
         whi &= (uint32_t)(keep >> 32);
-        __builtin_nontemporal_store(((unsigned long long)whi << 32) | wlo, out + w);
+        store_packed(((unsigned long long)whi << 32) | wlo, out + w);
         if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(seq, base, nb, slot);
     }
 }
@@ -781,8 +790,8 @@ encode_batch2_kernel(const uint8_t *__restrict__ seq, const unsigned long long *
             uint32_t bad = 0;
             uint32_t *o32 = reinterpret_cast<uint32_t *>(out + wb);
             const uint32_t c0 = enc16(v0, bad), c1 = enc16(v1, bad);
-            __builtin_nontemporal_store(c0, o32 + lane);
-            __builtin_nontemporal_store(c1, o32 + 64 + lane);
+            store_packed(c0, o32 + lane);
+            store_packed(c1, o32 + 64 + lane);
             if (__builtin_expect(residue_is_bad(bad), 0)) {
                 rescan_bytes(seq, rec.base0 + 16 * lane, 16, slot);
                 rescan_bytes(seq, rec.base0 + 16 * (lane + 64), 16, slot);
@@ -805,7 +814,7 @@ encode_batch2_kernel(const uint8_t *__restrict__ seq, const unsigned long long *
         else tile_lookup(offsets, word_offsets, count, rec, wo, so, wb, wb + last, my.pads, base_rel, nb); // its fences order the strip stores too
         if (lane <= last) {
             const unsigned long long word = stream_cut(my.strip, (unsigned)(lo - lo16) + base_rel, nb);
-            __builtin_nontemporal_store(word, out + wb + lane);
+            store_packed(word, out + wb + lane);
         }
     }
 }
@@ -905,13 +914,18 @@ __device__ __forceinline__ PlanEncGeom plan_enc_geom(const uint8_t *seq, unsigne
     g.nchunk = (long long)hi > g.off16 ? (unsigned)(((long long)hi - g.off16 + 15) >> 4) : 1u;         // a tile holds >= 1 base
     return g;
 }
+// ABL (evidence build, tools/ab_plan_enc_ablate.py; right only for batches of 32-base reads, whose tiles are dense and aligned):
+// bit 0 = tile base by arithmetic instead of the tile_base load, bit 1 = no pad-byte load, bit 2 = no load of the 129th chunk.
+template <int ABL = 0>
 __device__ __forceinline__ void plan_enc_issue(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ P, const PlanEncGeom &g, unsigned lane, PlanEncTile &t) {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(seq + g.off16); // derived from the kernel argument: global_load, not flat_load
     const unsigned top = g.nchunk - 1;
-    t.n = (uint32_t)P[g.wb + (lane < g.last ? lane : g.last) + 1]; // the whole lookup: one byte
+    if constexpr (ABL & 2) t.n = 0u;
+    else t.n = (uint32_t)P[g.wb + (lane < g.last ? lane : g.last) + 1]; // the whole lookup: one byte
     t.v0 = __builtin_nontemporal_load(src + (lane < top ? lane : top));
     t.v1 = __builtin_nontemporal_load(src + (lane + 64 < top ? lane + 64 : top));
-    t.x2 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src + (top < 128u ? top : 128u)) + (lane & 3));
+    if constexpr (ABL & 4) t.x2 = 0x41414141u;
+    else t.x2 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src + (top < 128u ? top : 128u)) + (lane & 3));
 }
 __device__ __forceinline__ void plan_enc_finish(const uint8_t *__restrict__ seq, const PlanEncGeom &g, const PlanEncTile &t, unsigned long long base0,
                                                 unsigned long long seq_begin, unsigned long long seq_end, uint32_t *strip, unsigned lane,
@@ -928,8 +942,8 @@ __device__ __forceinline__ void plan_enc_finish(const uint8_t *__restrict__ seq,
         uint32_t bad = 0;
         uint32_t *o32 = reinterpret_cast<uint32_t *>(out + g.wb);
         const uint32_t c0 = enc16(t.v0, bad), c1 = enc16(t.v1, bad);
-        __builtin_nontemporal_store(c0, o32 + lane);
-        __builtin_nontemporal_store(c1, o32 + 64 + lane);
+        store_packed(c0, o32 + lane);
+        store_packed(c1, o32 + 64 + lane);
         if (__builtin_expect(residue_is_bad(bad), 0)) {
             rescan_bytes(seq, base0 + 16 * lane, 16, slot);
             rescan_bytes(seq, base0 + 16 * (lane + 64), 16, slot);
@@ -952,7 +966,7 @@ __device__ __forceinline__ void plan_enc_finish(const uint8_t *__restrict__ seq,
     wave_lds_fence();
     if (lane <= g.last) {
         const unsigned long long word = stream_cut(strip, g.lead + base_rel, nb);
-        __builtin_nontemporal_store(word, out + g.wb + lane);
+        store_packed(word, out + g.wb + lane);
     }
 }
 
@@ -961,7 +975,7 @@ __device__ __forceinline__ void plan_enc_finish(const uint8_t *__restrict__ seq,
 // measured 3-12 % SLOWER at every grid size: profiles/r02_plan_encode_walking_waves.txt.)
 // U = consecutive tiles per wave trip: their bases come from one scalar load and all their chunk loads are issued before the
 // first tile is encoded (tile_base[t] -> data address is a dependent pair of round trips; U tiles share it).
-template <int U>
+template <int U, int ABL = 0>
 __global__ void __launch_bounds__(kBlock)
 encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
                          unsigned long long total_words, unsigned long long seq_begin, unsigned long long seq_end,
@@ -975,11 +989,15 @@ encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long lo
         PlanEncGeom g[U];
         PlanEncTile t[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) base0[u] = tile_base[t0 + u < ntiles ? t0 + u : ntiles - 1]; // clamp: redundant but in bounds
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long tile = t0 + u < ntiles ? t0 + u : ntiles - 1; // clamp: redundant but in bounds
+            if constexpr (ABL & 1) base0[u] = seq_begin + tile * (kBatchTile * 32ull);
+            else base0[u] = tile_base[tile];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             g[u] = plan_enc_geom(seq, t0 + u < ntiles ? t0 + u : ntiles - 1, base0[u], total_words, seq_end);
-            plan_enc_issue(seq, P, g[u], lane, t[u]);
+            plan_enc_issue<ABL>(seq, P, g[u], lane, t[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
