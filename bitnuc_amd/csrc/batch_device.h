@@ -984,7 +984,8 @@ encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long lo
     const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
     uint32_t *strip = strips[wave];
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
-    for (unsigned long long t0 = ((unsigned long long)blockIdx.x * kBatchWaves + wave) * U; t0 < ntiles; t0 += (unsigned long long)gridDim.x * kBatchWaves * U) {
+    const unsigned waves = blockDim.x >> 6; // <= kBatchWaves
+    for (unsigned long long t0 = ((unsigned long long)blockIdx.x * waves + wave) * U; t0 < ntiles; t0 += (unsigned long long)gridDim.x * waves * U) {
         unsigned long long base0[U];
         PlanEncGeom g[U];
         PlanEncTile t[U];

@@ -73,6 +73,7 @@ struct bitnuc_ctx {
     bitnuc_batch_plan *host_plan = nullptr; // ... kept by the context
     int plan_tiles = 1;                    // decode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
     int plan_enc_abl = 0;                  // evidence build: timing-only ablations of the plan encode's loads (see plan_enc_issue)
+    int plan_enc_block = 256;              // threads per workgroup of the plan encode (64, 128, 256)
     int plan_enc_tiles = 1;                // encode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
     int plan_store = 2;                    // decode_batch_plan_kernel's whole-chunk store policy: 0 nt, 1 plain, 2 plain on the shared edge lines + nt elsewhere
     int batch_abl = 0;                     // timing-only ablation mask of the second formulation (tools/ab_batch_ablate.py); 0 in normal use
@@ -796,6 +797,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "batch_host_plan")) { prev = c->batch_host_plan; if (value == 0 || value == 1) c->batch_host_plan = value; }
     else if (!strcmp(key, "plan_tiles")) { prev = c->plan_tiles; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->plan_tiles = value; }
     else if (!strcmp(key, "plan_enc_abl")) { prev = c->plan_enc_abl; if (value >= 0 && !kEvidenceBuild && value != 0) return -2; if (value >= 0 && value <= 7) c->plan_enc_abl = value; }
+    else if (!strcmp(key, "plan_enc_block")) { prev = c->plan_enc_block; if (value == 64 || value == 128 || value == 256) c->plan_enc_block = value; }
     else if (!strcmp(key, "plan_enc_tiles")) { prev = c->plan_enc_tiles; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->plan_enc_tiles = value; }
     else if (!strcmp(key, "slide_rounds")) { prev = c->slide_rounds; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4 || value == 8) c->slide_rounds = value; }
     else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && !kEvidenceBuild && value != 2) return -2; if (value >= 0 && value <= 2) c->plan_store = value; }
@@ -1527,14 +1529,15 @@ int bitnuc_encode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, cons
     DeviceGuard g(c->device);
     unsigned long long *slot;
     if (int st = take_slot(c, 0, &slot, err)) return st;
-    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
+    const int threads = c->plan_enc_block; // 64, 128 or 256 threads: a wave owns a tile, so any number of waves per workgroup works
+    const size_t per_block = (size_t)kBatchTile * (size_t)(threads / 64);
     const unsigned long long blocks = (p->total_words + per_block - 1) / per_block;
     unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
     const unsigned long long U = (unsigned long long)c->plan_enc_tiles;
-    const unsigned grid = grid_for(c, (blocks + U - 1) / U);
-#define PLAN_ENC(UU) encode_batch_plan_kernel<UU><<<grid, kBlock, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end, o, slot)
+    const unsigned grid = grid_for(c, (blocks + U - 1) / U, threads);
+#define PLAN_ENC(UU) encode_batch_plan_kernel<UU><<<grid, threads, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end, o, slot)
     if constexpr (kEvidenceBuild) {
-#define PLAN_ENC_ABL(A) encode_batch_plan_kernel<1, A><<<grid, kBlock, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end, o, slot)
+#define PLAN_ENC_ABL(A) encode_batch_plan_kernel<1, A><<<grid, threads, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end, o, slot)
         if (U == 2) PLAN_ENC(2);
         else if (U == 4) PLAN_ENC(4);
         else switch (c->plan_enc_abl) { // timing-only ablations, right only for 32-base reads (tools/ab_plan_enc_ablate.py)

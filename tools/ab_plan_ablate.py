@@ -27,8 +27,10 @@ plan = bitnuc_amd.BatchPlan(ctx, off, count)
 total = plan.total_words
 words = torch.empty(total + 64, dtype=torch.int64, device=dev)
 bw = torch.empty(N // 32 + 64, dtype=torch.int64, device=dev)
+bw2 = torch.empty(N // 32 + 64, dtype=torch.int64, device=dev)  # inputs alternate too: 250 MB would live in the Infinity Cache
 plan.encode_dev(seq, words)
 ctx.encode_dev(seq, N, bw)
+ctx.encode_dev(seq, N, bw2)
 ctx.sync()
 
 
@@ -68,7 +70,7 @@ for rnd in range(7):
     ctx.set_variant("plan_store", 2)
     ctx.set_variant("plan_tiles", 1)
     t = once(lambda: ctx.decode_fixed_dev(words, L, L, count, alt()))
-    u = once(lambda: ctx.decode_dev(bw, N // 32, N, alt()))
+    u = once(lambda: ctx.decode_dev(bw if flip[0] else bw2, N // 32, N, alt()))
     if rnd >= 2:
         res["fixed"].append(t)
         res["bulk"].append(u)

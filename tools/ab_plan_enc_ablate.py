@@ -24,11 +24,12 @@ torch.cuda.synchronize()
 plan = bitnuc_amd.BatchPlan(ctx, off, count)
 total = plan.total_words
 outs = [torch.empty(total + 64, dtype=torch.int64, device=dev) for _ in range(2)]
-bw = torch.empty(N // 32 + 64, dtype=torch.int64, device=dev)
+bws = [torch.empty(N // 32 + 64, dtype=torch.int64, device=dev) for _ in range(2)]  # alternate: one 250 MB output would live in the Infinity Cache
 ref = torch.empty(total + 64, dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
 plan.encode_dev(seq, ref)
 ctx.sync()
+BLOCKS = (256, 128, 64)
 NAMES = {0: "as shipped", 1: "tile base by arithmetic (no tile_base load)", 2: "no pad-byte load", 4: "no 129th-chunk load", 6: "no pad-byte and no 129th-chunk load",
          7: "none of the three (two chunk loads per lane only)"}
 BURST = 12
@@ -53,6 +54,8 @@ def run():
 
 res = {k: [] for k in NAMES}
 res["bulk"] = []
+for b in BLOCKS[1:]:
+    res[("block", b)] = []
 ok = {}
 for rnd in range(7):
     for abl in NAMES:
@@ -67,7 +70,13 @@ for rnd in range(7):
         if rnd >= 2:
             res[abl].append(t)
     ctx.set_variant("plan_enc_abl", 0)
-    u = once(lambda: ctx.encode_dev(seq, N, bw))
+    for b in BLOCKS[1:]:
+        ctx.set_variant("plan_enc_block", b)
+        t = once(run)
+        if rnd >= 2:
+            res[("block", b)].append(t)
+    ctx.set_variant("plan_enc_block", 256)
+    u = once(lambda: ctx.encode_dev(seq, N, bws[flip.__setitem__(0, flip[0] ^ 1) or flip[0]]))
     if rnd >= 2:
         res["bulk"].append(u)
 alg = N + 8 * total
@@ -75,5 +84,8 @@ print(f"plan encode of {count} reads of 32 bases (every tile dense and aligned),
 for abl in NAMES:
     m = statistics.median(res[abl])
     print(f"  {NAMES[abl]:52s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s  {'same words' if ok[abl] else 'MISMATCH'}")
+for b in BLOCKS[1:]:
+    m = statistics.median(res[("block", b)])
+    print(f"  {'as shipped, ' + str(b) + '-thread workgroups':52s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
 m = statistics.median(res["bulk"])
 print(f"  {'bulk encode_kernel on the same bytes':52s} {m:.4f} ms  {alg/m/1e6:6.0f} GB/s")
