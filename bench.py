@@ -840,7 +840,7 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
 
 
 def sustained_shape_probes(args, ctx, torch, stream, seqs, words, backs, n, R):
-    """Kernels with exactly the codec's access shapes and no arithmetic (encode shape: 16 B nt-loads + 4 B stores per
+    """Kernels with exactly the codec's access shapes and no arithmetic (encode shape: 16 B nt-loads + 4 B nt-stores, XCD-contiguous tile order, per
     lane, 2 in flight, 128-thread workgroups; decode shape: 4 B loads + 16 B nt-stores, 256-thread workgroups), run
     back to back in the timed loop's rotation (the decode shape reads what was written R-1 steps earlier), per-kernel
     HIP events on the launch stream.  What this box sustains for this traffic pattern; the codec cannot be faster than

@@ -60,7 +60,7 @@ struct bitnuc_ctx {
     unsigned long long *d_acc = nullptr; // accumulators of the single-launch reductions, zero between launches: [0..2] base_counts C,G,T; [4] hdist (u32)
     unsigned *d_tickets = nullptr;       // [0] base_counts, [1] hdist: arrival counters, zero between launches
     unsigned reduce_blocks = 512;
-    int enc_variant = 14, dec_variant = 22; // kDefaultEnc / kDefaultDec
+    int enc_variant = 39, dec_variant = 22; // kDefaultEnc / kDefaultDec
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int slide_rounds = 1;                // kmer_slide_kernel: consecutive 992-base rounds per wave trip (1, 2 or 4)
@@ -414,21 +414,22 @@ constexpr bool kEvidenceBuild = false;
 #define BITNUC_VARIANTS(X)                            \
     X(0, 4, 256, false, false, false, false)          \
     X(3, 2, 256, true, false, false, false)           \
-    X(14, 2, 128, true, false, false, false)          \
-    X(22, 2, 256, false, true, false, false)
+    X(22, 2, 256, false, true, false, false)          \
+    X(39, 2, 128, true, true, false, true)
 #endif
 constexpr int kNumVariants = 47;    // ids 0..46; which of them this build holds: variant_info(id).built
 [[maybe_unused]] constexpr int kBallotVariant = 100; // encode only: lane-per-base + ballot (sweep build; set_variant("encode", 100))
 // defaults from the sustained (back-to-back) pair sweeps in profiles/ (10^9 bases, one tile per
-// workgroup, 15 interleaved rounds in one process, decode reading words written two steps
+// workgroup, interleaved rounds in one process, decode reading words written two steps
 // earlier so that none of its input is Infinity-Cache resident -- what bench.py times):
-//   encode 14: nt loads + plain stores, 2 groups in flight per lane, 128-thread workgroups -> 6.86 TB/s
-//   decode 22: plain loads + nt stores, 2 groups per lane                                   -> 5.93 TB/s
-// The pair is tuned, not each kernel: encode's 250 MB of plain-stored words sit dirty in the
-// 256 MiB Infinity Cache; decode's plain (allocating) loads push them out while decode runs,
-// nt loads would leave that write-back to the next encode.  All good pairs land on the same
-// plateau of ~0.40 ms per step = 6.3 TB/s of mixed read/write HBM traffic.
-constexpr int kDefaultEnc = 14, kDefaultDec = 22;
+//   encode 39: nt loads + nt stores, 2 groups in flight per lane, 128-thread workgroups, XCD-contiguous tile order
+//   decode 22: plain loads + nt stores, 2 groups per lane
+// The pair is tuned, not each kernel, and every good pair lands on the same plateau of ~0.40 ms per step = 6.3 TB/s of
+// mixed read/write HBM traffic (all 47 x 47 pairs: profiles/r02_sweep_pairs_all_cold.txt; the ten best are within 0.6 %).
+// What differs is how the step divides: with encode 14 (plain, allocating stores -- the round-1 default) the 250 MB of
+// packed words sit dirty in the 256 MiB Infinity Cache and are written back while the DECODE runs: encode 0.182 ms, decode
+// 0.214 ms.  With nt stores the encode pays for its own writes: 0.199 / 0.196 ms, and the step is 0.5-0.9 % shorter.
+constexpr int kDefaultEnc = 39, kDefaultDec = 22;
 
 struct VariantInfo { int unroll, block; bool ntld, ntst, xpose, xcd, built; };
 constexpr VariantInfo variant_info(int id) {
@@ -961,10 +962,10 @@ int bitnuc_stream_probe_dev(bitnuc_ctx *c, int mode, const void *d_src, void *d_
         if (!d_dst || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
         if (nts) PROBE((probe_fill_kernel<4, true>), dst, n16); else PROBE((probe_fill_kernel<4, false>), dst, n16);
         break;
-    case 3: { // encode_kernel's shape (variant 14: 2 rounds, 128 threads, nt loads, plain stores): `bytes` of ASCII-side input
+    case 3: { // encode_kernel's shape (variant 39: 2 rounds, 128 threads, nt loads, nt stores, XCD-contiguous tiles): `bytes` of ASCII-side input
         if (!d_src || !d_dst || !aligned16(d_src) || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
         const unsigned g3 = grid_for(c, n16 / (128 * 2) + 1, 128);
-        probe_enc_shape_kernel<2, 128, true, false><<<g3, 128, 0, c->stream>>>(src, static_cast<uint32_t *>(d_dst), n16);
+        probe_enc_shape_kernel<2, 128, true, true, true><<<g3, 128, 0, c->stream>>>(src, static_cast<uint32_t *>(d_dst), n16);
         break;
     }
     case 4: { // decode_kernel's shape (variant 22: 2 rounds, 256 threads, plain loads, nt stores): `bytes` of ASCII-side output

@@ -546,12 +546,12 @@ probe_fill_kernel(u32x4 *__restrict__ dst, unsigned long long n16) {
 // The codec kernels' exact access shapes with no arithmetic between load and store (bench.py's *_shape probes):
 // ENC: 16 B load + 4 B store per lane and round (1 : 0.25), DEC: 4 B load + 16 B store.  Same tile walk, block size,
 // rounds in flight and cache policy as encode_kernel / decode_kernel.
-template <int UNROLL, int BLOCK, bool NTLD, bool NTST>
+template <int UNROLL, int BLOCK, bool NTLD, bool NTST, bool XCD = false>
 __global__ void __launch_bounds__(BLOCK)
 probe_enc_shape_kernel(const u32x4 *__restrict__ src, uint32_t *__restrict__ dst, unsigned long long n16) {
     constexpr unsigned long long TILE = (unsigned long long)BLOCK * UNROLL;
     const unsigned long long full_tiles = n16 / TILE;
-    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+    for (unsigned long long tile = first_tile<XCD>(blockIdx.x, gridDim.x); tile < full_tiles; tile += gridDim.x) {
         u32x4 v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {

@@ -150,9 +150,9 @@ def test_decode_x2_variants_vs_oracle(sweep_ctx, oracle):
 def test_product_ships_only_the_variants_in_use(ctx, oracle):
     assert ctx.get("sweep_build") == 0
     built = [v for v in range(47) if ctx.set_variant("encode", v) != -2]
-    ctx.set_variant("encode", 14)
-    assert built == [0, 3, 14, 22]
-    assert ctx.set_variant("encode", 100) == -2 and ctx.get("encode") == 14  # the ballot formulation is evidence, not product
+    ctx.set_variant("encode", 39)
+    assert built == [0, 3, 22, 39]
+    assert ctx.set_variant("encode", 100) == -2 and ctx.get("encode") == 39  # the ballot formulation is evidence, not product
     assert all(ctx.set_variant("decode", v) == -2 for v in range(47, 56)) and ctx.get("decode") == 22  # decode_x2_kernel: evidence build
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
