@@ -169,8 +169,9 @@ struct CopyPool {
         cv_work.notify_all();
         for (auto &t : threads) t.join();
     }
+    int skip = 0; // 1 while an asynchronous copy runs: worker i then owns slice i - 1 (the caller takes none)
     void copy_slice(int i) const {
-        const size_t a = slice * (size_t)i;
+        const size_t a = slice * (size_t)(i - skip);
         if (a >= bytes) return;
         const size_t m = bytes - a < slice ? bytes - a : slice;
         memcpy(dst + a, src + a, m);
@@ -191,6 +192,31 @@ struct CopyPool {
             }
         }
     }
+    // asynchronous form: the workers copy, the caller goes on (wait() before touching either buffer again).  Pools used this way
+    // are created with one thread more than the copies should use: the caller's slice index 0 is then an empty slice.
+    bool busy = false;
+    void start(void *d, const void *s_, size_t nbytes) {
+        wait();
+        if (n == 1 || nbytes == 0) { if (nbytes) memcpy(d, s_, nbytes); return; }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            dst = static_cast<uint8_t *>(d);
+            src = static_cast<const uint8_t *>(s_);
+            bytes = nbytes;
+            slice = ((nbytes + (n - 1) - 1) / (n - 1) + 4095) & ~(size_t)4095; // n - 1 workers
+            skip = 1;
+            pending = (unsigned)(n - 1);
+            ++generation;
+            busy = true;
+        }
+        cv_work.notify_all();
+    }
+    void wait() {
+        if (!busy) return;
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return pending == 0; });
+        busy = false;
+    }
     void copy(void *d, const void *s_, size_t nbytes) { // blocking parallel memcpy
         if (n == 1 || nbytes < ((size_t)1 << 20)) { memcpy(d, s_, nbytes); return; }
         {
@@ -199,6 +225,7 @@ struct CopyPool {
             src = static_cast<const uint8_t *>(s_);
             bytes = nbytes;
             slice = ((nbytes + n - 1) / n + 4095) & ~(size_t)4095;
+            skip = 0;
             pending = (unsigned)(n - 1);
             ++generation;
         }
@@ -215,7 +242,8 @@ struct HostPipe {
     hipEvent_t ev_in[kPipeDepth] = {}, ev_k[kPipeDepth] = {}, ev_out[kPipeDepth] = {};
     uint8_t *pin_a[kPipeDepth] = {}, *pin_b[kPipeDepth] = {}; // a: ASCII-sized (chunk + 64), b: word-sized (chunk / 4 + 64)
     uint8_t *dev_a[kPipeDepth] = {}, *dev_b[kPipeDepth] = {};
-    CopyPool *pool = nullptr;
+    CopyPool *pool = nullptr;     // stage-in: blocking, the calling thread takes a slice
+    CopyPool *pool_out = nullptr; // hand-back to the caller: asynchronous, overlaps the next chunk's stage-in
     size_t chunk = kPipeChunkDefault; // bases per chunk (a multiple of 32)
     bool ok = false;
 };
@@ -247,6 +275,7 @@ void pipe_destroy(HostPipe *p) {
     if (p->s_in) (void)hipStreamDestroy(p->s_in);
     if (p->s_out) (void)hipStreamDestroy(p->s_out);
     delete p->pool;
+    delete p->pool_out;
     delete p;
 }
 
@@ -271,6 +300,7 @@ int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err) {
     }
     if (rc != hipSuccess) { pipe_destroy(p); return fail_hip(err, rc); }
     p->pool = new CopyPool(host_threads());
+    p->pool_out = new CopyPool(host_threads() / 2 + 1); // its workers only: the calling thread is busy staging the next chunk in
     p->ok = true;
     c->pipe = p;
     *out = p;
@@ -993,6 +1023,7 @@ static inline bool on_host(const bitnuc_ctx *c, size_t n) {
 static int encode_pipelined(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint64_t *out, size_t *n_words, bitnuc_err *err) {
     HostPipe *p;
     if (int st = pipe_get(c, &p, err)) return st;
+    struct HandBackDone { CopyPool *q; ~HandBackDone() { q->wait(); } } hand_back_done{p->pool_out}; // no return leaves workers writing into `out`
     const size_t kPipeChunk = p->chunk;
     const size_t nchunks = (len + kPipeChunk - 1) / kPipeChunk;
     auto chunk_len = [&](size_t ci) { return len - ci * kPipeChunk < kPipeChunk ? len - ci * kPipeChunk : kPipeChunk; };
@@ -1013,16 +1044,18 @@ static int encode_pipelined(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint6
             HIPCHK(launch_encode(c, p->dev_a[b], reinterpret_cast<uint64_t *>(p->dev_b[b]), n, slot));
             HIPCHK(hipEventRecord(p->ev_k[b], c->stream));
             HIPCHK(hipStreamWaitEvent(p->s_out, p->ev_k[b], 0));
-            HIPCHK(hipMemcpyAsync(p->pin_b[b], p->dev_b[b], nw * 8, hipMemcpyDeviceToHost, p->s_out)); // pinned output b was handed to the caller one iteration ago
+            p->pool_out->wait(); // pinned output b is being handed to the caller since the previous iteration
+            HIPCHK(hipMemcpyAsync(p->pin_b[b], p->dev_b[b], nw * 8, hipMemcpyDeviceToHost, p->s_out));
             HIPCHK(hipEventRecord(p->ev_out[b], p->s_out));
         }
         if (ci >= (size_t)LAG) { // hand chunk ci-LAG's words to the caller: its D2H finished long ago, the DMA queues stay full meanwhile
             const size_t j = ci - LAG;
             const int pb = (int)(j % D);
             HIPCHK(hipEventSynchronize(p->ev_out[pb]));
-            p->pool->copy(out + j * (kPipeChunk / 32), p->pin_b[pb], words_for(chunk_len(j)) * 8);
+            p->pool_out->start(out + j * (kPipeChunk / 32), p->pin_b[pb], words_for(chunk_len(j)) * 8); // overlaps the next chunk's stage-in
         }
     }
+    p->pool_out->wait();
     bitnuc_err e;
     const int st = drain(c, &e); // one drain at the end: slots are examined in launch order = sequence order
     if (st != BITNUC_OK) {
@@ -1037,6 +1070,7 @@ static int encode_pipelined(bitnuc_ctx *c, const uint8_t *seq, size_t len, uint6
 static int decode_pipelined(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_bases, uint8_t *out, bitnuc_err *err) {
     HostPipe *p;
     if (int st = pipe_get(c, &p, err)) return st;
+    struct HandBackDone { CopyPool *q; ~HandBackDone() { q->wait(); } } hand_back_done{p->pool_out}; // no return leaves workers writing into `out`
     const size_t kPipeChunk = p->chunk;
     const size_t nchunks = (n_bases + kPipeChunk - 1) / kPipeChunk;
     auto chunk_len = [&](size_t ci) { return n_bases - ci * kPipeChunk < kPipeChunk ? n_bases - ci * kPipeChunk : kPipeChunk; };
@@ -1055,6 +1089,7 @@ static int decode_pipelined(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_bases,
             HIPCHK(launch_decode(c, reinterpret_cast<const uint64_t *>(p->dev_b[b]), p->dev_a[b], n));
             HIPCHK(hipEventRecord(p->ev_k[b], c->stream));
             HIPCHK(hipStreamWaitEvent(p->s_out, p->ev_k[b], 0));
+            p->pool_out->wait(); // pinned output b is being handed to the caller since the previous iteration
             HIPCHK(hipMemcpyAsync(p->pin_a[b], p->dev_a[b], n, hipMemcpyDeviceToHost, p->s_out));
             HIPCHK(hipEventRecord(p->ev_out[b], p->s_out));
         }
@@ -1062,9 +1097,10 @@ static int decode_pipelined(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_bases,
             const size_t j = ci - LAG;
             const int pb = (int)(j % D);
             HIPCHK(hipEventSynchronize(p->ev_out[pb]));
-            p->pool->copy(out + j * kPipeChunk, p->pin_a[pb], chunk_len(j));
+            p->pool_out->start(out + j * kPipeChunk, p->pin_a[pb], chunk_len(j)); // overlaps the next chunk's stage-in
         }
     }
+    p->pool_out->wait();
     HIPCHK(hipStreamSynchronize(c->stream));
     return BITNUC_OK;
 }
