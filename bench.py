@@ -120,8 +120,18 @@ def csrc_sha16():
 
 
 def git_head():
+    """HEAD of the repository, or -- on a box that received a snapshot without history -- the commit the product library was
+    built at (bitnuc_amd/BUILD_INFO.json, written by bitnuc_amd.build), marked as such."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        if head:
+            return head
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        with open(os.path.join(ROOT, "bitnuc_amd", "BUILD_INFO.json")) as f:
+            info = json.load(f)
+        return f"{info['commit']}{'+uncommitted csrc' if info.get('csrc_dirty') else ''} (library built at)"
     except Exception:  # noqa: BLE001
         return None
 

@@ -50,7 +50,29 @@ def build_library(force=False, verbose=True, extra_flags=(), sweep=False):
     finally:
         if os.path.exists(tmp):
             os.unlink(tmp)
+    if not sweep:
+        write_build_info()
     return lib
+
+
+BUILD_INFO = os.path.join(HERE, "BUILD_INFO.json")
+
+
+def write_build_info():
+    """Where the library came from, for machines without the repository's history (the GPU box gets a snapshot without .git):
+    the commit the tree was at when the product library was built, and whether the tree had uncommitted changes."""
+    import datetime
+    import json
+    root = os.path.dirname(HERE)
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "bitnuc_amd/csrc", "include"], capture_output=True, text=True, timeout=10).stdout.strip())
+    except Exception:  # noqa: BLE001
+        head, dirty = "", False
+    if not head:
+        return  # no history here either: keep whatever travelled with the snapshot
+    with open(BUILD_INFO, "w") as f:
+        json.dump({"commit": head, "csrc_dirty": dirty, "built": datetime.datetime.now().isoformat(timespec="seconds")}, f)
 
 
 def ensure_built(sweep=False):
