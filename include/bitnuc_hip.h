@@ -144,7 +144,11 @@ int bitnuc_hdist_dev(bitnuc_ctx *ctx, const uint64_t *d_a, size_t na, const uint
  * and its ceil(len_i/32) words start at out[word_offsets[i]], where
  * word_offsets[i] = sum_{j<i} ceil(len_j/32) and word_offsets[count] = total words.
  * Zero-length sequences produce no words (the reference panics on them).  The first
- * invalid byte in buffer order -> INVALID_BASE{byte, index = byte offset in seq}. */
+ * invalid byte in buffer order -> INVALID_BASE{byte, index = byte offset in seq}.
+ * Memory access: the batch and fixed-length kernels LOAD whole 16-byte aligned chunks, so up to
+ * 15 bytes before seq[offsets[0]] and after seq[offsets[count]-1] are read (never validated, never
+ * part of a word; an aligned 16-byte chunk cannot cross a page, so this cannot fault).  Stores
+ * touch exactly the bytes of the batch: neighbours of an unaligned output are never written. */
 /* Compute word_offsets (count+1 entries, device memory) from device offsets; synchronous;
  * *total_words = word_offsets[count]. */
 int bitnuc_batch_word_offsets_dev(bitnuc_ctx *ctx, const uint64_t *d_offsets, size_t count, uint64_t *d_word_offsets, size_t *total_words, bitnuc_err *err);
