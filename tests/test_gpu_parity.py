@@ -912,6 +912,44 @@ def test_batch_fuzz_vs_oracle_loop(ctx, oracle):
                 ctx.set_variant("batch_host_plan", prev)
 
 
+def test_batch_tables_at_odd_word_addresses(ctx, oracle):
+    """The offsets / word-offsets tables only have to be 8-byte aligned: device tables that start one entry into an allocation (the scan
+    kernels load them 16 bytes at a time), counts around the scan's 8-per-thread and 2048-per-workgroup granularity."""
+    import torch
+    import bitnuc_amd as bn
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    for count in (1, 7, 8, 9, 2047, 2048, 2049, 5000, 16385):
+        lengths = rng.integers(0, 90, size=count)
+        off = np.zeros(count + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lengths)
+        seq = rand_seq(int(off[-1]) + 1)
+        d_seq = torch.from_numpy(seq).to(dev)
+        hold = torch.zeros(count + 2, dtype=torch.int64, device=dev)
+        hold[1:] = torch.from_numpy(off).to(dev)
+        d_off = hold[1:]                       # 8 bytes into the allocation
+        assert d_off.data_ptr() % 16 == 8
+        wo_hold = torch.zeros(count + 2, dtype=torch.int64, device=dev)
+        d_wo = wo_hold[1:]
+        torch.cuda.synchronize()
+        total = ctx.batch_word_offsets_dev(d_off, count, d_wo)
+        exp_wo = np.zeros(count + 1, dtype=np.int64)
+        exp_wo[1:] = np.cumsum((lengths + 31) // 32)
+        assert total == int(exp_wo[-1]) and np.array_equal(d_wo.cpu().numpy(), exp_wo), count
+        ew, _ = _oracle_batch(oracle, seq[: int(off[-1])], off.astype(np.uint64))
+        plan = bn.BatchPlan(ctx, d_off, count)
+        assert plan.total_words == total
+        words = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+        back = torch.zeros(int(off[-1]) + 1, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        plan.encode_dev(d_seq, words)
+        plan.decode_dev(words, back)
+        ctx.sync()
+        assert np.array_equal(words[:total].cpu().numpy().view(np.uint64), ew), count
+        assert bytes(back[: int(off[-1])].cpu().numpy()) == bytes(seq[: int(off[-1])]).upper(), count
+        plan.close()
+
+
 def test_hbm_scale_round_trip(ctx, oracle):
     """One sequence sized for the 288 GB of HBM: up to 10^11 bases (100 GB ASCII + 25 GB packed + 100 GB decoded),
     scaled down to what the box has free.  Round-trip identity, spot blocks against the oracle, error index."""
