@@ -35,7 +35,11 @@ constexpr size_t kPipeChunkDefault = (size_t)32 << 20; // bases per chunk of the
 constexpr size_t kPipeMin = (size_t)8 << 20;     // inputs below this stay on the simple path (latency, not bandwidth, matters there)
 // Bulk host-pointer calls below this many bases run on the host (host_word.h): a launch with its two copies
 // costs ~35 us, the SWAR loop moves ~2-4 GB/s, so the crossover sits near 10^5 bases (tools/latency.py).
-constexpr size_t kDefaultHostCutoff = (size_t)64 << 10;
+// Size dispatch of the host-pointer bulk calls: the measured crossover between the library's host SWAR code (one
+// thread, 9-10 Gbases/s) and the GPU path (stage in, launch, stage out, one wait: 33-40 us + PCIe) on the GPU box, tools/host_cutoff.py,
+// profiles/r02_host_cutoff.txt: encode 1 Mi bases (101 vs 104 us), decode 512 Ki bases (62 vs 63 us).
+constexpr size_t kDefaultHostCutoff = (size_t)1 << 20;       // encode, hdist
+constexpr size_t kDefaultHostCutoffDecode = (size_t)1 << 19; // decode
 
 struct Pending {
     unsigned long long base;   // added to the slot's index (host path chunk offset)
@@ -82,7 +86,8 @@ struct bitnuc_ctx {
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
     int scan_impl = 1;                     // 1 = line-aligned rounds of 1024 windows (kmer_scan2_kernel), 0 = rounds of 992 windows (kmer_scan_kernel)
     int force_gpu = 0;                     // 1: single-word and below-cutoff calls launch kernels too (GPU parity tests, BITNUC_FORCE_GPU=1)
-    size_t host_cutoff = kDefaultHostCutoff; // bulk host-pointer calls below this many bases run on the host (host_word.h)
+    size_t host_cutoff = kDefaultHostCutoff; // bulk host-pointer encode / hdist below this many bases run on the host (host_word.h)
+    size_t host_cutoff_decode = kDefaultHostCutoffDecode; // ... decode
     int host_pipeline = 1;                 // large host-pointer encode / decode: pinned double buffers + overlapped H2D / kernel / D2H
     struct HostPipe *pipe = nullptr;       // created on the first large host-pointer call
 };
@@ -728,7 +733,7 @@ int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, 
     if (rc == hipSuccess) rc = hipMemset(c->d_slots, 0xFF, sizeof(unsigned long long) * kSlots);
     if (rc == hipSuccess) rc = hipMemset(c->d_sink, 0, 64);
     if (const char *e = getenv("BITNUC_FORCE_GPU")) c->force_gpu = atoi(e) != 0;
-    if (const char *e = getenv("BITNUC_HOST_CUTOFF")) { const long long v = atoll(e); if (v >= 0) c->host_cutoff = (size_t)v; }
+    if (const char *e = getenv("BITNUC_HOST_CUTOFF")) { const long long v = atoll(e); if (v >= 0) c->host_cutoff = c->host_cutoff_decode = (size_t)v; }
     c->reduce_blocks = (unsigned)c->num_cu * 2; // a resident grid of 2 workgroups of 256 threads per CU (profiles/r01_sweep13_reduce_grid.txt: the tail of atomics + ticket grows with the grid)
     if (rc == hipSuccess) rc = hipMalloc(&c->d_acc, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_acc, 0, 64);
@@ -808,7 +813,8 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     }
     else if (!strcmp(key, "decode")) { prev = c->dec_variant; if (value >= 0) { if (!(kEvidenceBuild && value >= kX2First && value <= kX2Last) && !variant_info(value).built) return -2; c->dec_variant = value; } }
     else if (!strcmp(key, "force_gpu")) { prev = c->force_gpu; if (value == 0 || value == 1) c->force_gpu = value; }
-    else if (!strcmp(key, "host_cutoff")) { prev = (int)(c->host_cutoff > 0x7FFFFFFF ? 0x7FFFFFFF : c->host_cutoff); if (value >= 0) c->host_cutoff = (size_t)value; }
+    else if (!strcmp(key, "host_cutoff")) { prev = (int)(c->host_cutoff > 0x7FFFFFFF ? 0x7FFFFFFF : c->host_cutoff); if (value >= 0) c->host_cutoff = c->host_cutoff_decode = (size_t)value; } // sets both
+    else if (!strcmp(key, "host_cutoff_decode")) { prev = (int)(c->host_cutoff_decode > 0x7FFFFFFF ? 0x7FFFFFFF : c->host_cutoff_decode); if (value >= 0) c->host_cutoff_decode = (size_t)value; }
     else if (!strcmp(key, "host_pipeline")) { prev = c->host_pipeline; if (value == 0 || value == 1) c->host_pipeline = value; }
     else if (!strcmp(key, "sweep_build")) {
 #ifdef BITNUC_SWEEP_VARIANTS
@@ -1015,8 +1021,9 @@ int bitnuc_stream_probe_dev(bitnuc_ctx *c, int mode, const void *d_src, void *d_
 // ---- host-pointer entry points (synchronous, staged through device scratch) -------------------
 // true when a bulk host-pointer call of n bases belongs on the host: below the cutoff and not forced to the GPU.
 // A NULL context is accepted for such calls (the reference's functions need no context either).
-static inline bool on_host(const bitnuc_ctx *c, size_t n) {
-    return c ? (!c->force_gpu && n < c->host_cutoff) : n < kDefaultHostCutoff;
+static inline bool on_host(const bitnuc_ctx *c, size_t n, bool decode = false) {
+    if (c) return !c->force_gpu && n < (decode ? c->host_cutoff_decode : c->host_cutoff);
+    return n < (decode ? kDefaultHostCutoffDecode : kDefaultHostCutoff);
 }
 
 // encode / decode of a large pageable buffer: pinned double buffers, three streams (see HostPipe)
@@ -1153,7 +1160,7 @@ int bitnuc_decode(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_words, size_t n_
     if (n_words < words_for(n_bases)) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
     if (n_bases == 0) return BITNUC_OK;
     if (!ebuf || !out) return fail(err, BITNUC_UNSUPPORTED);
-    if (on_host(c, n_bases)) {
+    if (on_host(c, n_bases, true)) {
         bitnuc_host::decode_small(ebuf, n_bases, out);
         return BITNUC_OK;
     }

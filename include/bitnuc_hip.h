@@ -16,7 +16,7 @@
  * Size dispatch: the reference's as_2bit / from_2bit / hdist_scalar are
  * #[inline(always)] nanosecond functions, and a kernel launch with its copies costs
  * ~35 us, so the three single-word entry points and bulk HOST-POINTER calls below
- * `host_cutoff` bases (default 65 536; bitnuc_ctx_set_variant(ctx, "host_cutoff", n) or
+ * `host_cutoff` bases (default: the measured host / GPU crossover, 1 Mi bases for encode and hdist, 512 Ki for decode; bitnuc_ctx_set_variant(ctx, "host_cutoff", n) or
  * BITNUC_HOST_CUTOFF) run as the library's own SWAR host code (csrc/host_word.h) and
  * accept ctx == NULL.  bitnuc_ctx_set_variant(ctx, "force_gpu", 1) or BITNUC_FORCE_GPU=1
  * sends every call to the kernels (batches of one) -- the GPU parity tests run that way.

@@ -148,9 +148,9 @@ def host_ctx():
 
 
 def test_host_code_and_kernels_agree_around_the_cutoff(host_ctx, ctx, oracle):
-    cutoff = host_ctx.get("host_cutoff")
-    assert cutoff == 65536 and host_ctx.get("force_gpu") == 0 and ctx.get("force_gpu") == 1
-    for n in (1, 31, 32, 33, 1000, cutoff - 1, cutoff, cutoff + 1, 3 * cutoff + 5):
+    cutoff, cutoff_d = host_ctx.get("host_cutoff"), host_ctx.get("host_cutoff_decode")
+    assert (cutoff, cutoff_d) == (1 << 20, 1 << 19) and host_ctx.get("force_gpu") == 0 and ctx.get("force_gpu") == 1  # the measured crossovers
+    for n in (1, 31, 32, 33, 1000, cutoff_d - 1, cutoff_d, cutoff_d + 1, cutoff - 1, cutoff, cutoff + 1, 3 * cutoff + 5):
         s = rand_seq(n)
         wh, wg = host_ctx.encode_array(s), ctx.encode_array(s)
         assert np.array_equal(wh, wg) and np.array_equal(wh, oracle.encode(s)), n

@@ -157,11 +157,16 @@ def test_decode_short_buffer_and_hdist(host, oracle, golden):
 
 def test_large_inputs_need_a_device(host):
     # at or above the cutoff a NULL context is refused: bulk work is the kernels' and there is no CPU fallback for it
-    s = np.full(1 << 16, ord("A"), dtype=np.uint8)
+    s = np.full(1 << 20, ord("A"), dtype=np.uint8)  # the encode cutoff (the measured host / GPU crossover)
     with pytest.raises(bitnuc_amd.NucleotideError) as ei:
         host.encode_array(s)
     assert ei.value.kind == "Unsupported"
-    assert host.encode_array(s[:-1]).size == (s.size - 1 + 31) // 32
+    w = host.encode_array(s[:-1])
+    assert w.size == (s.size - 1 + 31) // 32
+    with pytest.raises(bitnuc_amd.NucleotideError) as ei:  # decode's cutoff is lower: 512 Ki bases
+        host.decode_array(w, 1 << 19)
+    assert ei.value.kind == "Unsupported"
+    assert bytes(host.decode_array(w, (1 << 19) - 1)) == b"A" * ((1 << 19) - 1)
 
 
 def test_packed_sequence_get_is_shift_and_mask():
