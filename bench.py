@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--bases", type=int, default=10**9, help="bases per GPU per step (BASELINE configs[1]: 1e9)")
     ap.add_argument("--rotate", type=int, default=3, help="buffer sets rotated so the 256 MiB Infinity Cache cannot serve a step (>= 2)")
+    ap.add_argument("--evidence-build", action="store_true", help="load libbitnuc_hip_sweep.so (every kernel variant) instead of the product library: for --enc-variant / --dec-variant studies only")
     ap.add_argument("--enc-variant", type=int, default=-1)
     ap.add_argument("--dec-variant", type=int, default=-1)
     ap.add_argument("--grid-mult", type=int, default=-1)
@@ -435,7 +436,12 @@ def run_rank(args, real_stdout, traffic):
         ctx = stream = None
     else:
         stream = torch.cuda.current_stream()
-        ctx = bitnuc_amd.Context(local_rank, stream=stream.cuda_stream)
+        if args.evidence_build:
+            from bitnuc_amd import build as _build
+            ctx = bitnuc_amd.Context(local_rank, stream=stream.cuda_stream, lib_path=_build.ensure_built(sweep=True))
+            state["line_extra"]["library"] = "evidence build (libbitnuc_hip_sweep.so): not the product"
+        else:
+            ctx = bitnuc_amd.Context(local_rank, stream=stream.cuda_stream)
         ctx.set_variant("force_gpu", 1)  # the bench measures kernels only; the small-input host path is reported separately
         if args.enc_variant >= 0:
             ctx.set_variant("encode", args.enc_variant)

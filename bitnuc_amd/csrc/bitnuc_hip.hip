@@ -463,7 +463,8 @@ constexpr int kNumVariants = 47;    // ids 0..46; which of them this build holds
 // mixed read/write HBM traffic (all 47 x 47 pairs: profiles/r02_sweep_pairs_all_cold.txt; the ten best are within 0.6 %).
 // What differs is how the step divides: with encode 14 (plain, allocating stores -- the round-1 default) the 250 MB of
 // packed words sit dirty in the 256 MiB Infinity Cache and are written back while the DECODE runs: encode 0.182 ms, decode
-// 0.214 ms.  With nt stores the encode pays for its own writes: 0.199 / 0.196 ms, and the step is 0.5-0.9 % shorter.
+// 0.214 ms.  With nt stores the encode pays for its own writes: 0.199-0.204 / 0.194 ms; the step is the same (five processes each:
+// 0.4019 vs 0.4024 ms, profiles/r02_encode_variant_stability.txt): a choice of attribution, not of speed.
 constexpr int kDefaultEnc = 39, kDefaultDec = 22;
 
 struct VariantInfo { int unroll, block; bool ntld, ntst, xpose, xcd, built; };
