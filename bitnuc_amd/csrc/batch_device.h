@@ -570,10 +570,14 @@ __device__ __forceinline__ void strip_or_word(uint32_t *strip, unsigned bit, uns
 }
 // strip dword c is the 16-byte chunk at lo16 + 16c: decode and store it.  The run's first / last chunk is shared with the
 // neighbouring tiles when lo / hi are not 16-byte aligned.  Those two edges are NOT written byte by byte (that cost ~30
-// memory instructions per tile for two lanes' worth of data): lane 0 stores the run's FIRST 16 bytes [lo, lo+16) and lane 1
-// its LAST 16 bytes [hi-16, hi) as one unaligned dwordx4 each, cut from the bit strip at an arbitrary 2-bit position (two
-// dword reads + v_alignbit).  They overlap this tile's own aligned chunks with identical bytes and never touch a
-// neighbour's.  Runs shorter than 16 bytes (the last tile of a small batch) take the byte-wise path.
+// memory instructions per tile for two lanes' worth of data): the lane that holds the partial first chunk stores the run's
+// FIRST 16 bytes [lo, lo+16), the lane that holds the partial last chunk its LAST 16 bytes [hi-16, hi), as one unaligned
+// dwordx4 each.  They overlap this tile's own aligned chunks with identical bytes and never touch a neighbour's.  Every lane
+// takes its 32 code bits from the strip at a BIT position (two dword reads + v_alignbit; shift 0 for the whole chunks), so
+// the two edges ride in the same pass as the whole chunks -- a separate pass for them cost a second whole-wave dec16 per
+// tile -- and which chunks are whole / on a shared line is decided by comparing the 32-bit chunk index with wave-uniform
+// bounds, not by 64-bit address arithmetic per lane.  Runs shorter than 16 bytes (the last tile of a small batch) take the
+// byte-wise path.
 // POLICY: cache policy of the whole-chunk stores.  0 = streaming (nt), 1 = allocating (plain), 2 (shipped) = plain for the chunks
 // of the run's first / last 128-byte cache line (shared with the neighbouring tiles, so that the two parts of a line can meet in
 // L2), nt for everything else (inline asm: written as two C++ stores the compiler merges them into one plain flat store).
@@ -582,38 +586,54 @@ __device__ __forceinline__ void strip_or_word(uint32_t *strip, unsigned bit, uns
 template <int POLICY = 2>
 __device__ __forceinline__ void strip_drain(const uint32_t *strip, uint8_t (*edge)[16], uint8_t *__restrict__ out, uintptr_t lo16, uintptr_t lo, uintptr_t hi, unsigned lane) {
     const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4); // <= 130
-    const bool wide = hi - lo >= 16;                           // wave-uniform
     const uintptr_t op = reinterpret_cast<uintptr_t>(out);
+    if (hi - lo >= 16) { // wave-uniform
+        const unsigned lead = (unsigned)(lo - lo16), tail = (unsigned)(hi - lo16); // bytes from lo16: first base, one past the last
+        const unsigned c0 = lead ? 1u : 0u, c1 = tail >> 4;                        // whole chunks: c0 <= c < c1
+        // chunks on the run's first / last 128-byte line: c < cl0, c >= cl1
+        const unsigned cl0 = (unsigned)((((lo | 127) + 1) - lo16) >> 4);
+        const uintptr_t last_line = (hi - 1) & ~(uintptr_t)127;
+        const unsigned cl1 = last_line > lo16 ? (unsigned)((last_line - lo16) >> 4) : 0u;
+        uint8_t *base = out + (lo16 - op); // derived from `out`: global (not flat) stores
+        if (lead == 0 && (tail & 15u) == 0) { // wave-uniform: a run of whole chunks only (e.g. 100-base reads: a tile is 16 reads = 1600 bytes)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < 2; ++j) {
+                const unsigned c = lane + 64 * j;
+                if (c >= nchunk) break;
+                const u32x4 d = dec16(strip[c]);
+                uint8_t *dst = base + 16u * c;
+                bool plain = POLICY == 1;
+                if constexpr (POLICY == 2) plain = c < cl0 || c >= cl1;
+                if (plain) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned c = lane + 64 * j;
+            if (c >= nchunk) break;
+            const bool whole = c >= c0 && c < c1;
+            const unsigned boff = whole ? 16u * c : (c == 0 ? lead : tail - 16u); // first byte (from lo16) of the 16 this lane stores
+            const unsigned bit = 2u * boff;
+            const uint32_t w0 = strip[bit >> 5], w1 = strip[(bit >> 5) + 1];
+            const u32x4 d = dec16(__builtin_amdgcn_alignbit(w1, w0, bit & 31));
+            uint8_t *dst = base + boff;
+            bool plain = !whole || POLICY == 1;
+            if constexpr (POLICY == 2) plain = plain || c < cl0 || c >= cl1;
+            if (plain) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory"); // any byte address (unaligned-access mode)
+            else asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { // a run shorter than 16 bytes: byte-wise through the wave's stage buffer
         const unsigned c = lane + 64 * j;
         if (c >= nchunk) break;
         const uintptr_t g = lo16 + 16 * (uintptr_t)c;
-        if (g >= lo && g + 16 <= hi) {
-            const u32x4 d = dec16(strip[c]);
-            u32x4 *dst = reinterpret_cast<u32x4 *>(out + (g - op)); // derived from `out`: a global (not flat) store
-            if constexpr (POLICY == 0) {
-                __builtin_nontemporal_store(d, dst);
-            } else if constexpr (POLICY == 1) {
-                *dst = d;
-            } else {
-                if ((g >> 7) == (lo >> 7) || (g >> 7) == ((hi - 1) >> 7)) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
-            }
-        } else if (!wide) {
-            uint8_t *e = edge[c ? 1 : 0];
-            *reinterpret_cast<u32x4 *>(e) = dec16(strip[c]);
-            store_stage_chunk(e, g, lo, hi);
-        }
-    }
-    if (wide && lane < 2) {
-        const bool head = lane == 0;
-        if (head ? (lo & 15) != 0 : (hi & 15) != 0) {
-            const uintptr_t a = head ? lo : hi - 16;
-            const unsigned bit = 2u * (unsigned)(a - lo16);
-            const uint32_t w0 = strip[bit >> 5], w1 = strip[(bit >> 5) + 1];
-            *reinterpret_cast<u32x4_u *>(out + (a - op)) = dec16(__builtin_amdgcn_alignbit(w1, w0, bit & 31));
-        }
+        uint8_t *e = edge[c ? 1 : 0];
+        *reinterpret_cast<u32x4 *>(e) = dec16(strip[c]);
+        store_stage_chunk(e, g, lo, hi);
     }
 }
 
