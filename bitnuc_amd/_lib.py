@@ -86,36 +86,56 @@ SIGNATURES = {
     "bitnuc_comm_rank": (C.c_int, [_P]),
     "bitnuc_allgather_words_dev": (C.c_int, [_P, _P, _P, _SZ, _P, _ERR]),
     "bitnuc_encode_sharded_allgather_dev": (C.c_int, [_P, _P, _P, _SZ, _P, _ERR]),
+    "bitnuc_encode_sharded_allgather_overlapped_dev": (C.c_int, [_P, _P, _P, _SZ, C.c_int, _P, _ERR]),
     "bitnuc_encode_sharded_allgather_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, C.POINTER(_P), _ERR]),
     "bitnuc_nucgen_dev": (C.c_int, [_P, _P, _SZ, _U64, _U64, C.c_int, _ERR]),
     "bitnuc_stream_probe_dev": (C.c_int, [_P, C.c_int, _P, _P, _SZ, _ERR]),
     "bitnuc_selftime_small": (C.c_double, [C.c_int, _SZ, _SZ]),
     "bitnuc_selftime_host_copy": (C.c_double, [_SZ, C.c_int, C.c_int]),
+    "bitnuc_host_pipe_info": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int, _ERR]),
+    "bitnuc_peer_link_probe": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int, _SZ, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _ERR]),
 }
 
 _libs = {}
+
+
+hip_runtime_choice = None  # what _share_torch_hip_runtime decided, for logs and tests: (reason, path or None)
 
 
 def _share_torch_hip_runtime():
     """PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as /opt/rocm's, requested under another name).
     If libbitnuc_hip.so pulls in the system runtime first, a later `import torch` loads a SECOND HIP runtime into the
     process and fails with "No HIP GPUs are available".  Loading torch's copy first makes both sides share one runtime
-    (our DT_NEEDED libamdhip64.so.7 then resolves to it by soname) -- the order `import torch; import bitnuc_amd` gives."""
+    (our DT_NEEDED libamdhip64.so.7 then resolves to it by soname) -- the order `import torch; import bitnuc_amd` gives.
+    A plain C-ABI consumer that never imports torch can opt out with BITNUC_NO_TORCH_HIP_PRELOAD=1 and gets the runtime the
+    library was linked against; BITNUC_LOG=1 prints the choice to stderr."""
     import importlib.util
     import sys
-    if "torch" in sys.modules or os.environ.get("BITNUC_NO_TORCH_HIP_PRELOAD"):
-        return
+    global hip_runtime_choice
+
+    def decided(reason, path=None):
+        global hip_runtime_choice
+        hip_runtime_choice = (reason, path)
+        if os.environ.get("BITNUC_LOG"):
+            print(f"bitnuc_amd: HIP runtime: {reason}" + (f" ({path})" if path else ""), file=sys.stderr)
+
+    if os.environ.get("BITNUC_NO_TORCH_HIP_PRELOAD"):
+        return decided("system runtime (BITNUC_NO_TORCH_HIP_PRELOAD set)")
+    if "torch" in sys.modules:
+        return decided("torch already imported: its runtime is in the process")
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
-        return
+        return decided("system runtime (torch not installed)")
     if spec and spec.origin:
         cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
         if os.path.exists(cand):
             try:
                 C.CDLL(cand, mode=C.RTLD_GLOBAL)
-            except OSError:
-                pass
+                return decided("preloaded torch's bundled runtime", cand)
+            except OSError as e:
+                return decided(f"system runtime (preload of torch's runtime failed: {e})")
+    return decided("system runtime (torch bundles no libamdhip64.so)")
 
 
 def load(path=None):

@@ -480,6 +480,17 @@ class Context:
     def nucgen_dev(self, d_out, length, seed, first=0, flags=0):
         self._call_dev(self._lib.bitnuc_nucgen_dev, _dev_ptr(d_out), int(length), C.c_uint64(seed), C.c_uint64(first), int(flags))
 
+    def host_pipe_info(self):
+        """Configuration and creation-time measurements of the pipelined host-pointer path (creates it if needed)."""
+        names = ["cores_visible", "cores_quota", "cores_usable", "chunk_bases", "depth", "encode_stage_in_threads", "encode_hand_back_threads",
+                 "decode_stage_in_threads", "decode_hand_back_threads", "pinned_h2d_gb_s", "pinned_d2h_gb_s", "stage_in_memcpy_gb_s",
+                 "hand_back_memcpy_gb_s", "heavy_side_thread_cap", "calibrated"]
+        out = (C.c_double * len(names))()
+        err = L.BitnucErr()
+        if self._lib.bitnuc_host_pipe_info(self._h, out, len(names), C.byref(err)) != L.OK:
+            _raise(err)
+        return {k: (round(v, 1) if "gb_s" in k else int(v)) for k, v in zip(names, out)}
+
     def stream_probe_dev(self, mode, d_src, d_dst, nbytes):
         self._call_dev(self._lib.bitnuc_stream_probe_dev, int(mode), _dev_ptr(d_src), _dev_ptr(d_dst), int(nbytes))
 
@@ -572,12 +583,33 @@ class Comm:
         if self._lib.bitnuc_encode_sharded_allgather_dev(self._ctx._h, self._h, _dev_ptr(d_seq_shard), int(shard_len), _dev_ptr(d_all), C.byref(err)) != L.OK:
             _raise(err)
 
+    def encode_sharded_allgather_overlapped_dev(self, d_seq_shard, shard_len, n_chunks, d_all):
+        """Same result as encode_sharded_allgather_dev, the exchange hidden behind the encode: n_chunks pieces, each moved in
+        place by a second stream as soon as it is encoded (include/bitnuc_hip.h)."""
+        err = L.BitnucErr()
+        if self._lib.bitnuc_encode_sharded_allgather_overlapped_dev(self._ctx._h, self._h, _dev_ptr(d_seq_shard), int(shard_len), int(n_chunks), _dev_ptr(d_all), C.byref(err)) != L.OK:
+            _raise(err)
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._lib.bitnuc_comm_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
+
+
+def peer_link_probe(src_device, dst_devices, nbytes=256 << 20, reps=3, lib_path=None):
+    """xGMI link probe: hipMemcpyPeerAsync from src_device to each of dst_devices, one link at a time and all at once.
+    Returns {"gb_s_each": [...], "gb_s_all": x}; raises NucleotideError('Unsupported') with fewer than two devices."""
+    lib = L.load(lib_path)
+    n = len(dst_devices)
+    dst = (C.c_int * max(n, 1))(*dst_devices)
+    each = (C.c_double * max(n, 1))()
+    allv = C.c_double(0)
+    err = L.BitnucErr()
+    if lib.bitnuc_peer_link_probe(int(src_device), dst, n, int(nbytes), int(reps), each, C.byref(allv), C.byref(err)) != L.OK:
+        _raise(err)
+    return {"gb_s_each": [round(each[i], 1) for i in range(n)], "gb_s_all": round(allv.value, 1)}
 
 
 # ---- module-level functions with the reference's names (default context, device 0) ----------

@@ -12,10 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbitnuc_hip.so")
 LIB_SWEEP = os.path.join(HERE, "libbitnuc_hip_sweep.so")  # evidence build: all 47 codec variants + the ballot formulation
-SOURCES = [os.path.join(CSRC, "bitnuc_hip.hip")]
+# one translation unit per kernel family + the runtime + the RCCL layer (csrc/runtime.h says who owns what)
+UNITS = ["runtime", "codec", "kmer", "batch", "analysis", "comm"]
+SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
 import glob
 
 DEPS = SOURCES + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]
+CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 
 
 def hipcc_path():
@@ -32,24 +35,40 @@ def is_stale(lib=LIB):
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build_library(force=False, verbose=True, extra_flags=(), sweep=False):
+def build_library(force=False, verbose=True, extra_flags=(), sweep=False, jobs=None):
     """sweep=False: the product (libbitnuc_hip.so, the shipped codec variants).  sweep=True: the evidence build
-    (libbitnuc_hip_sweep.so, -DBITNUC_SWEEP_VARIANTS) that tools/sweep*.py and the all-variants parity test load."""
+    (libbitnuc_hip_sweep.so, -DBITNUC_SWEEP_VARIANTS) that tools/sweep*.py and the all-variants parity test load.
+    The units are compiled side by side (`jobs` at a time, default: the CPUs of this process, at most one per unit) and linked
+    into one shared library; objects live in a private temporary directory, the library appears atomically."""
+    import concurrent.futures
+    import tempfile
     lib = LIB_SWEEP if sweep else LIB
     if not force and not is_stale(lib):
         return lib
+    hipcc = hipcc_path()
+    flags = CXXFLAGS + list(extra_flags) + (["-DBITNUC_SWEEP_VARIANTS"] if sweep else [])
+    if jobs is None:
+        jobs = max(1, min(len(UNITS), len(os.sched_getaffinity(0))))
     tmp = f"{lib}.tmp.{os.getpid()}"  # other processes (bench ranks) only ever see a complete library
-    flags = list(extra_flags) + (["-DBITNUC_SWEEP_VARIANTS"] if sweep else [])
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-fno-gpu-rdc", *flags, "-o", tmp, *SOURCES, "-ldl", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd).replace(tmp, lib), file=sys.stderr)
-    try:
-        subprocess.run(cmd, check=True, cwd=HERE)
-        os.replace(tmp, lib)
-    finally:
-        if os.path.exists(tmp):
-            os.unlink(tmp)
+    with tempfile.TemporaryDirectory(prefix="bitnuc_obj_") as objdir:
+        def compile_unit(unit):
+            obj = os.path.join(objdir, unit + ".o")
+            cmd = [hipcc, *flags, "-c", os.path.join(CSRC, unit + ".hip"), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True, cwd=HERE)
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+            objs = list(ex.map(compile_unit, UNITS))
+        link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-fno-gpu-rdc", "-o", tmp, *objs, "-ldl", "-lpthread"]
+        if verbose:
+            print(" ".join(link).replace(tmp, lib), file=sys.stderr)
+        try:
+            subprocess.run(link, check=True, cwd=HERE)
+            os.replace(tmp, lib)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
     if not sweep:
         write_build_info()
     return lib

@@ -7,7 +7,7 @@
 //   hdist_pairs : dist[i] = hdist_scalar(a[i], b[i], len)   (hamming/scalar.rs:11-48), many pairs
 //   hdist_query : dist[i] = hdist_scalar(query, t[i], len), one query against many targets
 #pragma once
-#include "codec_device.h"
+#include "device_prims.h"
 
 namespace bitnuc_dev {
 

@@ -16,7 +16,7 @@
 //     (one binary search per tile, all in parallel), then each lane searches the wave's LDS
 //     window of the next offsets (global fallback if a run of empty sequences overflows it).
 #pragma once
-#include "codec_device.h"
+#include "device_prims.h"
 
 namespace bitnuc_dev {
 

@@ -1,0 +1,339 @@
+// comm.hip -- multi-GPU: shard + concatenate (BASELINE config 4) and the xGMI link probe.
+// u64 words never share state (the reference's loop has no carry, src/utils/packing/avx.rs:138-145), so shards encode
+// independently; the only exchange of the path is the final concatenation of the packed words over xGMI:
+//   * one shot: ncclAllGather in place on the context's stream;
+//   * chunked overlap (SURVEY 8e iii): the shard is encoded piece by piece on the context's stream while a second stream
+//     moves the finished pieces, IN PLACE, with grouped point-to-point ncclSend / ncclRecv -- on MI355X's full mesh of
+//     point-to-point xGMI links that uses all P-1 links of a GPU at once (a ring would be per-link bound).
+// RCCL is bound at run time (dlopen) so that single-GPU users do not need librccl.so.  No kernels here.
+#include "runtime.h"
+
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include <mutex>
+#include <vector>
+
+using namespace bitnuc_rt;
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    void *CommInitRank = nullptr; // takes ncclUniqueId by value: called through a typed pointer below
+    bool ok = false;
+};
+struct UniqueIdBytes { char internal[BITNUC_UNIQUE_ID_BYTES]; }; // == ncclUniqueId
+constexpr int kNcclUint64 = 5;                                     // ncclUint64 (rccl.h)
+
+RcclApi &rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) return;
+        api.GetUniqueId = reinterpret_cast<int (*)(void *)>(dlsym(api.handle, "ncclGetUniqueId"));
+        api.CommInitAll = reinterpret_cast<int (*)(void **, int, const int *)>(dlsym(api.handle, "ncclCommInitAll"));
+        api.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(dlsym(api.handle, "ncclAllGather"));
+        api.Send = reinterpret_cast<int (*)(const void *, size_t, int, int, void *, hipStream_t)>(dlsym(api.handle, "ncclSend"));
+        api.Recv = reinterpret_cast<int (*)(void *, size_t, int, int, void *, hipStream_t)>(dlsym(api.handle, "ncclRecv"));
+        api.Broadcast = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(dlsym(api.handle, "ncclBroadcast"));
+        api.GroupStart = reinterpret_cast<int (*)()>(dlsym(api.handle, "ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<int (*)()>(dlsym(api.handle, "ncclGroupEnd"));
+        api.CommInitRank = dlsym(api.handle, "ncclCommInitRank");
+        api.ok = api.GetUniqueId && api.CommInitAll && api.CommDestroy && api.AllGather && api.Send && api.Recv && api.Broadcast &&
+                 api.GroupStart && api.GroupEnd && api.CommInitRank;
+    });
+    return api;
+}
+int fail_rccl(bitnuc_err *e, int rc) { // ncclResult_t in backend_code, offset so it cannot be mistaken for a hipError_t
+    if (e) { memset(e, 0, sizeof *e); e->status = BITNUC_BACKEND_ERROR; e->backend_code = 10000 + rc; }
+    return BITNUC_BACKEND_ERROR;
+}
+
+double now_s() {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+} // namespace
+
+struct bitnuc_comm {
+    void *nccl = nullptr; // ncclComm_t
+    int nranks = 0, rank = 0, device = 0;
+    hipStream_t xfer = nullptr;        // the second stream of the chunked overlap (created on first use)
+    std::vector<hipEvent_t> piece_done; // piece c encoded (recorded on the context's stream)
+    hipEvent_t all_moved = nullptr;     // every piece exchanged (recorded on xfer)
+};
+
+namespace {
+
+int comm_overlap_resources(bitnuc_comm *comm, int n_chunks, bitnuc_err *err) {
+    if (!comm->xfer) HIPCHK(hipStreamCreateWithFlags(&comm->xfer, hipStreamNonBlocking));
+    if (!comm->all_moved) HIPCHK(hipEventCreateWithFlags(&comm->all_moved, hipEventDisableTiming));
+    while ((int)comm->piece_done.size() < n_chunks) {
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        comm->piece_done.push_back(e);
+    }
+    return BITNUC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int bitnuc_comm_get_unique_id(uint8_t id[BITNUC_UNIQUE_ID_BYTES], bitnuc_err *err) {
+    clear_err(err);
+    if (!id) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    UniqueIdBytes u;
+    if (int rc = r.GetUniqueId(&u)) return fail_rccl(err, rc);
+    memcpy(id, u.internal, BITNUC_UNIQUE_ID_BYTES);
+    return BITNUC_OK;
+}
+
+int bitnuc_comm_init_rank(bitnuc_ctx *c, int nranks, int rank, const uint8_t id[BITNUC_UNIQUE_ID_BYTES], bitnuc_comm **out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(err, BITNUC_UNSUPPORTED);
+    *out = nullptr;
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    DeviceGuard g(c->device);
+    UniqueIdBytes u;
+    memcpy(u.internal, id, BITNUC_UNIQUE_ID_BYTES);
+    void *comm = nullptr;
+    auto init = reinterpret_cast<int (*)(void **, int, UniqueIdBytes, int)>(r.CommInitRank);
+    if (int rc = init(&comm, nranks, u, rank)) return fail_rccl(err, rc);
+    bitnuc_comm *bc = new bitnuc_comm();
+    bc->nccl = comm; bc->nranks = nranks; bc->rank = rank; bc->device = c->device;
+    *out = bc;
+    return BITNUC_OK;
+}
+
+int bitnuc_comm_init_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, bitnuc_err *err) {
+    clear_err(err);
+    if (n_gpus < 1 || n_gpus > 64 || !ctxs || !comms) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    for (int i = 0; i < n_gpus; ++i) { ctxs[i] = nullptr; comms[i] = nullptr; }
+    for (int i = 0; i < n_gpus; ++i)
+        if (int st = bitnuc_ctx_create(i, &ctxs[i], err)) {
+            for (int j = 0; j < i; ++j) { bitnuc_ctx_destroy(ctxs[j]); ctxs[j] = nullptr; }
+            return st;
+        }
+    void *raw[64];
+    int devs[64];
+    for (int i = 0; i < n_gpus; ++i) devs[i] = i;
+    if (int rc = r.CommInitAll(raw, n_gpus, devs)) {
+        for (int j = 0; j < n_gpus; ++j) { bitnuc_ctx_destroy(ctxs[j]); ctxs[j] = nullptr; }
+        return fail_rccl(err, rc);
+    }
+    for (int i = 0; i < n_gpus; ++i) {
+        bitnuc_comm *bc = new bitnuc_comm();
+        bc->nccl = raw[i]; bc->nranks = n_gpus; bc->rank = i; bc->device = i;
+        comms[i] = bc;
+    }
+    return BITNUC_OK;
+}
+
+void bitnuc_comm_destroy(bitnuc_comm *comm) {
+    if (!comm) return;
+    DeviceGuard g(comm->device);
+    if (comm->xfer) (void)hipStreamSynchronize(comm->xfer);
+    RcclApi &r = rccl();
+    if (r.ok && comm->nccl) (void)r.CommDestroy(comm->nccl);
+    for (hipEvent_t e : comm->piece_done) (void)hipEventDestroy(e);
+    if (comm->all_moved) (void)hipEventDestroy(comm->all_moved);
+    if (comm->xfer) (void)hipStreamDestroy(comm->xfer);
+    delete comm;
+}
+
+int bitnuc_comm_nranks(const bitnuc_comm *comm) { return comm ? comm->nranks : 0; }
+int bitnuc_comm_rank(const bitnuc_comm *comm) { return comm ? comm->rank : -1; }
+
+int bitnuc_allgather_words_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint64_t *d_local, size_t count, uint64_t *d_all, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!comm || comm->device != c->device) return fail(err, BITNUC_UNSUPPORTED);
+    if (count == 0) return BITNUC_OK;
+    if (!d_local || !d_all) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    DeviceGuard g(c->device);
+    if (int rc = r.AllGather(d_local, d_all, count, kNcclUint64, comm->nccl, c->stream)) return fail_rccl(err, rc);
+    return BITNUC_OK;
+}
+
+int bitnuc_encode_sharded_allgather_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, uint64_t *d_all, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!comm || comm->device != c->device) return fail(err, BITNUC_UNSUPPORTED);
+    // every rank contributes the same number of whole words: shard_len must be a multiple of 32
+    // (ragged tails belong in the last rank of a bitnuc_amd.dist.shard_range-style split + padding)
+    if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
+    if (shard_len == 0) return BITNUC_OK;
+    const size_t count = shard_len / 32;
+    uint64_t *mine = d_all + (size_t)comm->rank * count;
+    if (int st = bitnuc_encode_dev(c, d_seq_shard, shard_len, mine, err)) return st;
+    return bitnuc_allgather_words_dev(c, comm, mine, count, d_all, err);
+}
+
+// Chunked overlap, in place.  Piece p = words [count p / n, count (p+1) / n) of every rank's shard.  The context's stream
+// encodes the pieces back to back; after each one an event lets the transfer stream exchange that piece: this rank SENDS
+// its piece to every peer and RECEIVES every peer's piece straight into d_all + peer * count + w0 -- no staging buffer, no
+// strided copy.  The context's stream finally waits for the transfer stream, so bitnuc_ctx_sync covers the whole call.
+// BITNUC_GATHER_MODE=bcast moves a piece with P grouped ncclBroadcast calls (root = owner, in place) instead.
+int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, int n_chunks, uint64_t *d_all, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!comm || comm->device != c->device || n_chunks < 1 || n_chunks > 4096) return fail(err, BITNUC_UNSUPPORTED);
+    if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
+    if (shard_len == 0) return BITNUC_OK;
+    if (!d_seq_shard || !d_all || (reinterpret_cast<uintptr_t>(d_all) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    DeviceGuard g(c->device);
+    if (int st = comm_overlap_resources(comm, n_chunks, err)) return st;
+    static const bool bcast = [] { const char *e = getenv("BITNUC_GATHER_MODE"); return e && !strcmp(e, "bcast"); }();
+    const size_t count = shard_len / 32;
+    const int P = comm->nranks, me = comm->rank;
+    uint64_t *mine = d_all + (size_t)me * count;
+    // the transfer stream must not run ahead of what the caller already queued on the context's stream (d_all's previous readers)
+    HIPCHK(hipEventRecord(comm->all_moved, c->stream));
+    HIPCHK(hipStreamWaitEvent(comm->xfer, comm->all_moved, 0));
+    for (int p = 0; p < n_chunks; ++p) {
+        const size_t w0 = count * (size_t)p / (size_t)n_chunks, w1 = count * (size_t)(p + 1) / (size_t)n_chunks;
+        if (w1 == w0) continue;
+        if (int st = encode_dev_at(c, d_seq_shard + 32 * w0, 32 * (w1 - w0), mine + w0, 32ull * w0, err)) return st;
+        HIPCHK(hipEventRecord(comm->piece_done[(size_t)p], c->stream));
+        HIPCHK(hipStreamWaitEvent(comm->xfer, comm->piece_done[(size_t)p], 0));
+        if (P == 1) continue;
+        if (int rc = r.GroupStart()) return fail_rccl(err, rc);
+        int rc = 0;
+        for (int s = 0; s < P && rc == 0; ++s) {
+            uint64_t *theirs = d_all + (size_t)s * count + w0;
+            if (bcast) rc = r.Broadcast(theirs, theirs, w1 - w0, kNcclUint64, s, comm->nccl, comm->xfer);
+            else if (s != me) {
+                rc = r.Send(mine + w0, w1 - w0, kNcclUint64, s, comm->nccl, comm->xfer);
+                if (rc == 0) rc = r.Recv(theirs, w1 - w0, kNcclUint64, s, comm->nccl, comm->xfer);
+            }
+        }
+        const int rc_end = r.GroupEnd();
+        if (rc) return fail_rccl(err, rc);
+        if (rc_end) return fail_rccl(err, rc_end);
+    }
+    HIPCHK(hipEventRecord(comm->all_moved, comm->xfer));
+    HIPCHK(hipStreamWaitEvent(c->stream, comm->all_moved, 0));
+    return BITNUC_OK;
+}
+
+int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err) {
+    clear_err(err);
+    if (n_gpus < 1 || !ctxs || !comms || !d_seq_shards || !d_alls) return fail(err, BITNUC_UNSUPPORTED);
+    if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
+    if (shard_len == 0) return BITNUC_OK;
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    const size_t count = shard_len / 32;
+    for (int i = 0; i < n_gpus; ++i) // encode phase: independent, no communication
+        if (int st = bitnuc_encode_dev(ctxs[i], d_seq_shards[i], shard_len, d_alls[i] + (size_t)i * count, err)) return st;
+    if (int rc = r.GroupStart()) return fail_rccl(err, rc);
+    for (int i = 0; i < n_gpus; ++i) {
+        DeviceGuard g(ctxs[i]->device);
+        if (int rc = r.AllGather(d_alls[i] + (size_t)i * count, d_alls[i], count, kNcclUint64, comms[i]->nccl, ctxs[i]->stream)) {
+            (void)r.GroupEnd();
+            return fail_rccl(err, rc);
+        }
+    }
+    if (int rc = r.GroupEnd()) return fail_rccl(err, rc);
+    for (int i = 0; i < n_gpus; ++i) {
+        bitnuc_err e;
+        if (int st = bitnuc_ctx_sync(ctxs[i], &e)) { if (err) *err = e; return st; }
+    }
+    return BITNUC_OK;
+}
+
+// ---- xGMI link probe (measure the per-link rate on the box before quoting a fabric roofline) -----------
+// hipMemcpyPeerAsync of `bytes` from src_device to each of dst_devices[0..n): one link at a time (gb_s_each[i], best of
+// `reps`), then all n at once on n streams (*gb_s_all = aggregate outbound rate of src_device).  Host wall clock around
+// stream synchronisation; buffers are allocated and freed here.  Needs every device visible in THIS process.
+int bitnuc_peer_link_probe(int src_device, const int *dst_devices, int n, size_t bytes, int reps, double *gb_s_each, double *gb_s_all, bitnuc_err *err) {
+    clear_err(err);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (n < 1 || n > 63 || !dst_devices || bytes < 4096 || reps < 1 || src_device < 0 || src_device >= ndev) return fail(err, BITNUC_UNSUPPORTED, (uint64_t)ndev);
+    for (int i = 0; i < n; ++i)
+        if (dst_devices[i] < 0 || dst_devices[i] >= ndev || dst_devices[i] == src_device) return fail(err, BITNUC_UNSUPPORTED, (uint64_t)ndev);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    std::vector<void *> dst((size_t)n, nullptr);
+    std::vector<hipStream_t> streams((size_t)n, nullptr);
+    void *src = nullptr;
+    hipError_t rc = hipSuccess;
+    for (int i = 0; i < n && rc == hipSuccess; ++i) {
+        int can = 0;
+        rc = hipDeviceCanAccessPeer(&can, src_device, dst_devices[i]);
+        if (rc == hipSuccess && !can) rc = hipErrorPeerAccessUnsupported;
+        if (rc != hipSuccess) break;
+        rc = hipSetDevice(dst_devices[i]);
+        if (rc == hipSuccess) { const hipError_t e = hipDeviceEnablePeerAccess(src_device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = e; else (void)hipGetLastError(); }
+        if (rc == hipSuccess) rc = hipMalloc(&dst[(size_t)i], bytes);
+        if (rc == hipSuccess) rc = hipSetDevice(src_device);
+        if (rc == hipSuccess) { const hipError_t e = hipDeviceEnablePeerAccess(dst_devices[i], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = e; else (void)hipGetLastError(); }
+        if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&streams[(size_t)i], hipStreamNonBlocking);
+    }
+    if (rc == hipSuccess) rc = hipSetDevice(src_device);
+    if (rc == hipSuccess) rc = hipMalloc(&src, bytes);
+    if (rc == hipSuccess) rc = hipMemset(src, 0x5A, bytes);
+    if (rc == hipSuccess) rc = hipDeviceSynchronize();
+    double all = 0.0;
+    if (rc == hipSuccess) {
+        for (int i = 0; i < n && rc == hipSuccess; ++i) { // one link at a time
+            double best = 0.0;
+            for (int rep = 0; rep <= reps && rc == hipSuccess; ++rep) { // rep 0 = warm-up
+                const double t0 = now_s();
+                rc = hipMemcpyPeerAsync(dst[(size_t)i], dst_devices[i], src, src_device, bytes, streams[(size_t)i]);
+                if (rc == hipSuccess) rc = hipStreamSynchronize(streams[(size_t)i]);
+                const double gbs = (double)bytes / (now_s() - t0) / 1e9;
+                if (rep > 0 && gbs > best) best = gbs;
+            }
+            if (gb_s_each) gb_s_each[i] = best;
+        }
+        for (int rep = 0; rep <= reps && rc == hipSuccess; ++rep) { // all links at once
+            const double t0 = now_s();
+            for (int i = 0; i < n && rc == hipSuccess; ++i) rc = hipMemcpyPeerAsync(dst[(size_t)i], dst_devices[i], src, src_device, bytes, streams[(size_t)i]);
+            for (int i = 0; i < n && rc == hipSuccess; ++i) rc = hipStreamSynchronize(streams[(size_t)i]);
+            const double gbs = (double)bytes * n / (now_s() - t0) / 1e9;
+            if (rep > 0 && gbs > all) all = gbs;
+        }
+    }
+    if (gb_s_all) *gb_s_all = all;
+    (void)hipSetDevice(src_device);
+    for (int i = 0; i < n; ++i) if (streams[(size_t)i]) (void)hipStreamDestroy(streams[(size_t)i]);
+    if (src) (void)hipFree(src);
+    for (int i = 0; i < n; ++i)
+        if (dst[(size_t)i]) { (void)hipSetDevice(dst_devices[i]); (void)hipFree(dst[(size_t)i]); }
+    (void)hipSetDevice(prev);
+    if (rc != hipSuccess) return fail_hip(err, rc);
+    return BITNUC_OK;
+}
+
+} // extern "C"

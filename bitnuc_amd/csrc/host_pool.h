@@ -1,0 +1,167 @@
+// host_pool.h -- the host-side staging pool of the pipelined host-pointer path (codec.hip: encode_pipelined /
+// decode_pipelined) and the CPU budget it is sized from.  Plain C++17 + pthreads, NO HIP: tests/c/host_sanitize.cpp
+// compiles this header (and host_word.h) with -fsanitize=address,undefined and -fsanitize=thread on the CPU build.
+//
+// The reference is single-threaded (src/utils/unpacking/avx.rs:37 holds its only static); these threads exist only to
+// move the caller's pageable bytes to and from pinned memory at PCIe speed, they never touch codec arithmetic.
+#pragma once
+#include <sched.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace bitnuc_host {
+
+// CPUs this process may run on (affinity mask) and the CPU-time quota of its cgroup, in cores (0 = no quota).
+// A container with a 16-core quota on a 256-thread host reports 256 in its affinity mask: sizing thread pools
+// from the mask alone oversubscribes the quota, sizing them from a fixed guess undersubscribes it.
+inline int cores_visible() {
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int n = CPU_COUNT(&set);
+        if (n >= 1) return n;
+    }
+    return 1;
+}
+inline int cores_quota() {
+    // cgroup v2: "<quota> <period>" or "max <period>"; cgroup v1: two files
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long long period = 0;
+        const int got = fscanf(f, "%31s %lld", q, &period);
+        fclose(f);
+        if (got == 2 && period > 0 && strcmp(q, "max") != 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) return (int)((quota + period - 1) / period);
+        }
+        return 0;
+    }
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%lld", &quota) != 1) quota = -1; fclose(f); }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%lld", &period) != 1) period = 0; fclose(f); }
+    if (quota > 0 && period > 0) return (int)((quota + period - 1) / period);
+    return 0;
+}
+inline int cores_usable() {
+    const int vis = cores_visible(), quota = cores_quota();
+    return quota > 0 && quota < vis ? quota : vis;
+}
+inline int env_threads(const char *name) { // 0 = not set / out of range
+    if (const char *e = getenv(name)) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) return v;
+    }
+    return 0;
+}
+
+constexpr int kPoolMaxThreads = 12; // copy threads a pool is created with (the per-call count is chosen below this)
+
+// A pool of copy threads.  Two ways to use it, never mixed while a job is outstanding:
+//   copy(d, s, n, use)   blocking: `use` threads (the caller is one of them) copy disjoint 4 KiB-aligned slices;
+//   start(d, s, n, use)  asynchronous: `use` WORKERS copy, the caller goes on and calls wait() before it touches
+//                        either buffer again or starts the next job.
+// One caller thread per pool (the context's single-thread contract, include/bitnuc_hip.h).  Every shared field is
+// written under `mu` before the generation counter moves and read by a worker only after it has seen the new
+// generation under `mu`; a new job cannot be posted before `pending` of the previous one has reached zero.
+struct CopyPool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    uint8_t *dst = nullptr;
+    const uint8_t *src = nullptr;
+    size_t bytes = 0, slice = 0;
+    unsigned generation = 0, pending = 0;
+    bool stop = false;
+    int skip = 0;      // 1 while an asynchronous job runs: worker i then owns slice i - 1 (the caller takes none)
+    bool busy = false; // caller-side only: an asynchronous job has been started and not yet waited for
+    int n = 1;         // workers + the calling thread
+
+    explicit CopyPool(int nthreads) : n(nthreads < 1 ? 1 : nthreads) {
+        for (int i = 1; i < n; ++i) threads.emplace_back([this, i] { run(i); });
+    }
+    ~CopyPool() {
+        wait();
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    CopyPool(const CopyPool &) = delete;
+    CopyPool &operator=(const CopyPool &) = delete;
+
+    void copy_slice(int i) const {
+        const size_t a = slice * (size_t)(i - skip);
+        if (a >= bytes) return;
+        const size_t m = bytes - a < slice ? bytes - a : slice;
+        memcpy(dst + a, src + a, m);
+    }
+    void run(int i) {
+        unsigned seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv_work.wait(g, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            copy_slice(i);
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    static size_t slice_for(size_t nbytes, int parts) { return ((nbytes + (size_t)parts - 1) / (size_t)parts + 4095) & ~(size_t)4095; }
+    int clamp_use(int use, int most) const { return use < 1 ? 1 : (use > most ? most : use); }
+
+    void start(void *d, const void *s_, size_t nbytes, int use = kPoolMaxThreads) {
+        wait();
+        if (n == 1 || nbytes == 0) { if (nbytes) memcpy(d, s_, nbytes); return; }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            dst = static_cast<uint8_t *>(d);
+            src = static_cast<const uint8_t *>(s_);
+            bytes = nbytes;
+            slice = slice_for(nbytes, clamp_use(use, n - 1)); // workers only
+            skip = 1;
+            pending = (unsigned)(n - 1);
+            ++generation;
+        }
+        busy = true;
+        cv_work.notify_all();
+    }
+    void wait() {
+        if (!busy) return;
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return pending == 0; });
+        busy = false;
+    }
+    void copy(void *d, const void *s_, size_t nbytes, int use = kPoolMaxThreads) { // blocking parallel memcpy
+        wait();
+        if (n == 1 || use <= 1 || nbytes < ((size_t)1 << 20)) { if (nbytes) memcpy(d, s_, nbytes); return; }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            dst = static_cast<uint8_t *>(d);
+            src = static_cast<const uint8_t *>(s_);
+            bytes = nbytes;
+            slice = slice_for(nbytes, clamp_use(use, n));
+            skip = 0;
+            pending = (unsigned)(n - 1);
+            ++generation;
+        }
+        cv_work.notify_all();
+        copy_slice(0);
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return pending == 0; });
+    }
+};
+
+} // namespace bitnuc_host

@@ -1,0 +1,321 @@
+// kmer.hip -- k-mer compositions of the hot path behind the C ABI (include/bitnuc_hip.h): batched as_2bit over many
+// <= 32-mers (BASELINE config 3, README.md:52-56), every window of a sequence (src/lib.rs:170-173), the sliding pack +
+// Hamming scan (config 5: packing/mod.rs:80-110 o hamming/scalar.rs:11-48) and bulk hdist (hamming/multi.rs:121-160).
+// Kernels: kmer_device.h.
+#include "runtime.h"
+#include "kmer_device.h"
+#include "host_word.h"
+
+using namespace bitnuc_dev;
+using namespace bitnuc_rt;
+
+namespace {
+hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t stride, size_t count, uint64_t *out,
+                        unsigned long long *slot) {
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
+    size_t done = 0;
+    if (stride == k && count >= 64 && c->batch_dense) {
+        // dense layout: whole waves of 64 k-mers go through the bulk-encode-shaped kernel
+        const unsigned long long items = count / 64;
+        const int un = c->dense_unroll, kb = c->kmer_block;
+        const unsigned grid = grid_for(c, (items + (kb / 64) * un - 1) / ((kb / 64) * un), kb);
+#define DENSE_LAUNCH(AL, NL, NS, U) kmer_dense_kernel<AL, NL, NS, U><<<grid, kb, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot)
+#define DENSE_POLICY(U)                                              \
+    switch (c->dense_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    case 0: DENSE_LAUNCH(true, false, false, U); break;              \
+    case 1: DENSE_LAUNCH(true, true, false, U); break;               \
+    case 2: DENSE_LAUNCH(true, false, true, U); break;               \
+    default: DENSE_LAUNCH(true, true, true, U); break;               \
+    }
+        if (!aligned16(kmers)) { DENSE_LAUNCH(false, false, false, 1); }
+        else if constexpr (!kEvidenceBuild) { DENSE_LAUNCH(true, true, true, 1); } // the shipped form: dense_policy 3, dense_unroll 1
+        else if (un == 1) { DENSE_POLICY(1) }
+        else if (un == 2) { DENSE_POLICY(2) }
+        else { DENSE_POLICY(4) }
+#undef DENSE_POLICY
+#undef DENSE_LAUNCH
+        hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+        done = items * 64;
+        if (done == count) return hipSuccess;
+    }
+    // (k >= stride: every byte of the span belongs to some k-mer, so validating whole 16-byte groups examines no byte the
+    // reference's loop would not; with gaps between k-mers the general kernel looks at each k-mer's own bytes only)
+    if ((stride == 1 || stride == 2 || stride == 4 || stride == 8 || stride == 16) && k >= stride && done == 0 && c->batch_slide &&
+        aligned16(kmers) && aligned16(out) && (count - 1) * stride + k >= 1024) {
+        // windows at a small power-of-two stride (1 = every window of a sequence): whole 1 KiB wave rounds through the
+        // sliding kernel, 992 / stride windows each; the round that would read past the batch's last byte is left over
+        const unsigned long long rounds = ((count - 1) * stride + k - 1024) / kScanWaveWindows + 1;
+        const unsigned long long per_wave = (unsigned long long)c->slide_rounds;
+        const unsigned grid = grid_for(c, (rounds + per_wave * (kBlock / 64) - 1) / (per_wave * (kBlock / 64)));
+        const bool nts = (c->dense_policy & 2) != 0;
+#define SLIDE_U(S, NT) do { if constexpr (kEvidenceBuild) { \
+                              if (per_wave == 2) { kmer_slide_kernel<S, NT, 2><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); break; } \
+                              if (per_wave == 4) { kmer_slide_kernel<S, NT, 4><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); break; } \
+                              if (per_wave == 8) { kmer_slide_kernel<S, NT, 8><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); break; } } \
+                            kmer_slide_kernel<S, NT, 1><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); } while (0)
+#define SLIDE(S) do { if (nts) SLIDE_U(S, true); else SLIDE_U(S, false); } while (0)
+        switch (stride) {
+        case 1: SLIDE(1); break;
+        case 2: SLIDE(2); break;
+        case 4: SLIDE(4); break;
+        case 8: SLIDE(8); break;
+        default: SLIDE(16); break;
+        }
+#undef SLIDE
+#undef SLIDE_U
+        hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+        done = (size_t)(rounds * (kScanWaveWindows / stride));
+        if (done >= count) return hipSuccess;
+    }
+    if (stride >= 3 && stride < 32 && k >= stride && done == 0 && c->batch_slide && aligned16(kmers) &&
+        (count - 1) * stride + k >= 1024) {
+        // any other small stride with overlapping k-mers: the sliding round with per-lane window selection
+        const unsigned long long rounds = ((count - 1) * stride + k - 1024) / kScanWaveWindows + 1;
+        const unsigned grid = grid_for(c, (rounds + kBlock / 64 - 1) / (kBlock / 64));
+        const unsigned magic = (unsigned)((0x100000000ull + stride - 1) / stride); // exact floor(t / stride) for t < 2^16
+        const unsigned long long magic64 = ~0ull / stride + 1; // stride >= 3: no overflow
+        kmer_slide_any_kernel<<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, (unsigned)stride, magic, magic64, rounds, o, slot);
+        hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+        done = (size_t)((rounds * kScanWaveWindows + stride - 1) / stride); // k-mers that start before the last round's end
+        if (done >= count) return hipSuccess;
+    }
+    // general strides, and the < 64 k-mers a dense batch leaves over.  The error slot holds
+    // byte offsets relative to `kmers`, so the leftover launch passes the offset it starts at.
+    const size_t rest = count - done;
+    const unsigned grid = grid_for(c, (rest + kBlock - 1) / kBlock);
+    if (stride <= (size_t)kStagedMaxStride)
+        kmer_batch_kernel<true><<<grid, kBlock, 0, c->stream>>>(kmers + done * stride, (unsigned)k, stride, rest, o + done, slot, done * stride);
+    else
+        kmer_batch_kernel<false><<<grid, kBlock, 0, c->stream>>>(kmers + done * stride, (unsigned)k, stride, rest, o + done, slot, done * stride);
+    return hipGetLastError();
+}
+
+// de-interleave a packed query into its two bit-planes (bit i = low / high code bit of base i)
+void query_planes(uint64_t query, size_t k, uint32_t *ql, uint32_t *qh) {
+    *ql = *qh = 0;
+    for (unsigned i = 0; i < k; ++i) {
+        *ql |= (uint32_t)((query >> (2 * i)) & 1) << i;
+        *qh |= (uint32_t)((query >> (2 * i + 1)) & 1) << i;
+    }
+}
+
+hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist,
+                       unsigned long long *slot) {
+    uint32_t ql, qh;
+    query_planes(query, k, &ql, &qh);
+    const int unroll = c->scan_unroll, kb = c->kmer_block;
+    const bool al = aligned16(ref) && aligned16(dist);
+    if (c->scan_impl == 1 && al) { // line-aligned rounds of 1024 windows
+        const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+        const unsigned grid = grid_for(c, rounds / ((kb / 64) * unroll) + 1, kb);
+#define SCAN2(NL, NS, U) kmer_scan2_kernel<true, NL, NS, U, false><<<grid, kb, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, 0u, dist, nullptr, nullptr, nullptr, slot)
+#define SCAN2_POLICY(U)                                              \
+    switch (c->scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    case 0: SCAN2(false, false, U); break;                           \
+    case 1: SCAN2(true, false, U); break;                            \
+    case 2: SCAN2(false, true, U); break;                            \
+    default: SCAN2(true, true, U); break;                            \
+    }
+        if constexpr (!kEvidenceBuild) { SCAN2(true, true, 4); } // the shipped form: scan_policy 3, scan_unroll 4
+        else if (unroll == 1) { SCAN2_POLICY(1) } else if (unroll == 2) { SCAN2_POLICY(2) } else { SCAN2_POLICY(4) }
+#undef SCAN2_POLICY
+#undef SCAN2
+        return hipGetLastError();
+    }
+    const unsigned long long rounds = n >= 1024 ? (n - 1024) / kScanWaveWindows + 1 : 0;
+    const unsigned grid = grid_for(c, rounds / ((kb / 64) * unroll) + 1, kb);
+#define SCAN_LAUNCH(AL, NL, NS, U) \
+    kmer_scan_kernel<AL, NL, NS, U><<<grid, kb, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot)
+#define SCAN_POLICY(U)                                             \
+    switch (c->scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    case 0: SCAN_LAUNCH(true, false, false, U); break;             \
+    case 1: SCAN_LAUNCH(true, true, false, U); break;              \
+    case 2: SCAN_LAUNCH(true, false, true, U); break;              \
+    default: SCAN_LAUNCH(true, true, true, U); break;              \
+    }
+    if (!al || !kEvidenceBuild) { // the product reaches this only for unaligned pointers
+        SCAN_LAUNCH(false, false, false, 1);
+    } else if constexpr (kEvidenceBuild) {
+        if (unroll == 1) { SCAN_POLICY(1) } else if (unroll == 2) { SCAN_POLICY(2) } else { SCAN_POLICY(4) }
+    }
+#undef SCAN_POLICY
+#undef SCAN_LAUNCH
+    return hipGetLastError();
+}
+} // namespace
+
+extern "C" {
+
+int bitnuc_as_2bit_batch_dev(bitnuc_ctx *c, const uint8_t *d_kmers, size_t k, size_t stride, size_t count, uint64_t *d_out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0) return BITNUC_OK;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k); // packing/naive.rs:5-7, before any base
+    if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 7) || stride == 0) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (k == 0) { // as_2bit(b"") == Ok(0)
+        HIPCHK(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * count, c->stream));
+        return BITNUC_OK;
+    }
+    if (!d_kmers) return fail(err, BITNUC_UNSUPPORTED);
+    unsigned long long *slot;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
+    HIPCHK(launch_batch(c, d_kmers, k, stride, count, d_out, slot));
+    return BITNUC_OK;
+}
+
+int bitnuc_kmer_hdist_scan_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, size_t k, uint64_t query, uint8_t *d_dist, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k);
+    if (k == 0 || n < k) return BITNUC_OK; // no windows
+    if (!d_ref || !d_dist) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    unsigned long long *slot;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
+    HIPCHK(launch_scan(c, d_ref, n, k, query, d_dist, slot));
+    return BITNUC_OK;
+}
+
+int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, size_t k, uint64_t query, unsigned tau, uint64_t *d_count, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k);
+    if (!d_count || (reinterpret_cast<uintptr_t>(d_count) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (k == 0 || n < k) { // no windows
+        HIPCHK(hipMemsetAsync(d_count, 0, sizeof(uint64_t), c->stream));
+        return BITNUC_OK;
+    }
+    if (!d_ref) return fail(err, BITNUC_UNSUPPORTED);
+    unsigned long long *slot;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
+    uint32_t ql, qh;
+    query_planes(query, k, &ql, &qh);
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+    // a resident grid (the accumulator's ticket needs every workgroup to arrive; 4 trips of 4 rounds per wave keep the tail short)
+    const unsigned long long want = rounds / ((kBlock / 64) * 4) + 1, cap = (unsigned long long)c->num_cu * 8;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    unsigned long long *res = reinterpret_cast<unsigned long long *>(d_count);
+    if (aligned16(d_ref)) kmer_scan2_kernel<true, true, false, 4, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
+    else kmer_scan2_kernel<false, false, false, 1, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+int bitnuc_hdist_dev(bitnuc_ctx *c, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, size_t n_bases, uint32_t *d_result, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    const size_t need = words_for(n_bases);
+    if (na < need || nb < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases); // hamming/multi.rs:124-127
+    if (!d_result) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (n_bases == 0) {
+        HIPCHK(hipMemsetAsync(d_result, 0, sizeof(uint32_t), c->stream));
+        return BITNUC_OK;
+    }
+    if (!d_a || !d_b) return fail(err, BITNUC_UNSUPPORTED);
+    const unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1;
+    const unsigned grid = (unsigned)(tiles < c->reduce_blocks ? tiles : c->reduce_blocks);
+    hdist_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
+                                                 reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result, reinterpret_cast<unsigned *>(c->d_acc + 4), c->d_tickets + 1);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+int bitnuc_as_2bit_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t stride, size_t count, uint64_t *out, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (count == 0) return BITNUC_OK;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k);
+    if (!out || stride == 0) return fail(err, BITNUC_UNSUPPORTED);
+    if (k == 0) { memset(out, 0, sizeof(uint64_t) * count); return BITNUC_OK; }
+    if (!kmers) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (int st = flush_pending(c, err)) return st;
+    // chunk by k-mers so a staged chunk stays <= kHostChunk bytes
+    size_t per = kHostChunk / stride;
+    if (per == 0) per = 1;
+    if (per > count) per = count;
+    if (int st = ensure_scratch(c, 0, (per - 1) * stride + k + 16, err)) return st;
+    if (int st = ensure_scratch(c, 1, per * 8, err)) return st;
+    for (size_t j0 = 0; j0 < count; j0 += per) {
+        const size_t m = count - j0 < per ? count - j0 : per;
+        const size_t bytes = (m - 1) * stride + k;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], kmers + j0 * stride, bytes, hipMemcpyHostToDevice, c->stream));
+        unsigned long long *slot;
+        if (int st = take_slot(c, (unsigned long long)j0 * stride, &slot, err)) return st;
+        HIPCHK(launch_batch(c, c->scratch[0], k, stride, m, reinterpret_cast<uint64_t *>(c->scratch[1]), slot));
+        HIPCHK(hipMemcpyAsync(out + j0, c->scratch[1], m * 8, hipMemcpyDeviceToHost, c->stream));
+        bitnuc_err e;
+        int st = drain(c, &e);
+        if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    }
+    return BITNUC_OK;
+}
+
+int bitnuc_kmer_hdist_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (k > 32) return fail(err, BITNUC_SEQUENCE_TOO_LONG, k);
+    if (k == 0 || n < k) return BITNUC_OK;
+    if (!ref || !dist) return fail(err, BITNUC_UNSUPPORTED);
+    DeviceGuard g(c->device);
+    if (int st = flush_pending(c, err)) return st;
+    const size_t nwin = n - k + 1;
+    const size_t chunk = nwin < kHostChunk ? nwin : kHostChunk; // windows per staged chunk
+    if (int st = ensure_scratch(c, 0, chunk + k + 16, err)) return st;
+    if (int st = ensure_scratch(c, 2, chunk + 16, err)) return st;
+    for (size_t off = 0; off < nwin; off += chunk) {
+        const size_t w = nwin - off < chunk ? nwin - off : chunk;
+        const size_t bytes = w + k - 1;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], ref + off, bytes, hipMemcpyHostToDevice, c->stream));
+        unsigned long long *slot;
+        if (int st = take_slot(c, off, &slot, err)) return st;
+        HIPCHK(launch_scan(c, c->scratch[0], bytes, k, query, c->scratch[2], slot));
+        HIPCHK(hipMemcpyAsync(dist + off, c->scratch[2], w, hipMemcpyDeviceToHost, c->stream));
+        bitnuc_err e;
+        int st = drain(c, &e);
+        if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    }
+    return BITNUC_OK;
+}
+
+int bitnuc_hdist(bitnuc_ctx *c, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, size_t n_bases, uint32_t *out, bitnuc_err *err) {
+    clear_err(err);
+    const size_t need = words_for(n_bases);
+    if (na < need || nb < need) return fail(err, BITNUC_INVALID_LENGTH, n_bases);
+    if (!out) return fail(err, BITNUC_UNSUPPORTED);
+    if (n_bases == 0) { *out = 0; return BITNUC_OK; }
+    if (!a || !b) return fail(err, BITNUC_UNSUPPORTED);
+    if (on_host(c, n_bases)) { *out = bitnuc_host::hdist_small(a, b, n_bases); return BITNUC_OK; }
+    if (int st = check_ctx(c, err)) return st;
+    DeviceGuard g(c->device);
+    const size_t chunk_words = kHostChunk / 8;
+    const size_t cw = need < chunk_words ? need : chunk_words;
+    if (int st = ensure_scratch(c, 0, cw * 8, err)) return st;
+    if (int st = ensure_scratch(c, 1, cw * 8, err)) return st;
+    if (int st = ensure_scratch(c, 2, 64, err)) return st;
+    uint32_t total = 0;
+    for (size_t w0 = 0; w0 < need; w0 += cw) {
+        const size_t m = need - w0 < cw ? need - w0 : cw;
+        const size_t bases = (w0 + m == need) ? n_bases - w0 * 32 : m * 32;
+        HIPCHK(hipMemcpyAsync(c->scratch[0], a + w0, m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->scratch[1], b + w0, m * 8, hipMemcpyHostToDevice, c->stream));
+        bitnuc_err e;
+        int st = bitnuc_hdist_dev(c, reinterpret_cast<const uint64_t *>(c->scratch[0]), m,
+                                  reinterpret_cast<const uint64_t *>(c->scratch[1]), m, bases,
+                                  reinterpret_cast<uint32_t *>(c->scratch[2]), &e);
+        if (st != BITNUC_OK) { if (err) *err = e; return st; }
+        uint32_t part = 0;
+        HIPCHK(hipMemcpyAsync(&part, c->scratch[2], 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        total += part; // u32 wrap-around like the reference's accumulator (multi.rs:130)
+    }
+    *out = total;
+    return BITNUC_OK;
+}
+
+} // extern "C"

@@ -6,7 +6,7 @@
 // Values follow src/utils/packing/naive.rs:8-18 (pack) and
 // src/utils/functions/hamming/scalar.rs:22-47 (distance of two packed words).
 #pragma once
-#include "codec_device.h"
+#include "device_prims.h"
 
 namespace bitnuc_dev {
 

@@ -19,7 +19,22 @@
  * `host_cutoff` bases (default: the measured host / GPU crossover, 1 Mi bases for encode and hdist, 512 Ki for decode; bitnuc_ctx_set_variant(ctx, "host_cutoff", n) or
  * BITNUC_HOST_CUTOFF) run as the library's own SWAR host code (csrc/host_word.h) and
  * accept ctx == NULL.  bitnuc_ctx_set_variant(ctx, "force_gpu", 1) or BITNUC_FORCE_GPU=1
- * sends every call to the kernels (batches of one) -- the GPU parity tests run that way.
+ * sends every call MADE WITH THAT CONTEXT to the kernels (batches of one) -- the GPU parity
+ * tests run that way; calls with ctx == NULL have no context to carry the flag and stay on the host.
+ *
+ * Asynchronous launches and their data errors.  Every _dev launch that can meet an invalid base owns
+ * one device-resident error slot; bitnuc_ctx_sync() waits for the stream and reports the first latched
+ * error: ordinary launches in launch order, then launches recorded into a hipGraph in capture order.
+ *   - The slot ring starts at 4096 launches and GROWS (device + pinned allocation, no stream
+ *     synchronisation) when more are queued between two syncs; only past 2 Mi unsynced launches does a
+ *     _dev call drain the stream itself (the error it finds is kept for the next bitnuc_ctx_sync).
+ *   - While the context's stream is being CAPTURED (hipStreamBeginCapture / torch.cuda.graph) a launch
+ *     gets a persistent slot instead: the captured kernel runs again at every replay, so every later
+ *     bitnuc_ctx_sync() examines that slot and re-arms it.  An InvalidBase met by a replay is therefore
+ *     reported by the first sync after it, and never against another launch.  A context holds at most
+ *     1024 captured launches over its life (BITNUC_UNSUPPORTED, err.value = 1024 beyond that); replay the
+ *     graph on the context's stream, or order it before the sync yourself.  Entry points documented as
+ *     synchronous (word offsets, plan build, every host-pointer call, bitnuc_ctx_sync) cannot be captured.
  *
  * Conventions
  *   - plain pointers + sizes, no torch / C++ types in signatures;
@@ -27,7 +42,9 @@
  *   - "host" entry points take host pointers and are synchronous; large encode / decode
  *     calls (>= 8 Mi bases) are pipelined: a worker pool copies the caller's pageable memory
  *     into pinned double buffers while H2D, kernel and D2H of the neighbouring 32 Mi-base
- *     chunks overlap on three streams (BITNUC_HOST_THREADS sets the pool size, default 8);
+ *     chunks overlap on three streams; how many threads copy is chosen per direction from rates
+ *     measured on this host and the CPUs this process may use (affinity AND cgroup quota;
+ *     BITNUC_HOST_THREADS fixes the count, bitnuc_host_pipe_info reports it);
  *     the other host entry points stage through device scratch in 128 Mbase chunks;
  *     "_dev" entry points take device pointers, are enqueued
  *     on the context's stream and return immediately -- data-dependent errors
@@ -256,9 +273,22 @@ int bitnuc_allgather_words_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, const uint64_
  * into its slot of d_all and all-gather in place: every rank ends with the packed words of the
  * whole nranks*shard_len-base sequence, bit-identical to a single-GPU encode of it. */
 int bitnuc_encode_sharded_allgather_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, uint64_t *d_all, bitnuc_err *err);
+/* The same result with the exchange hidden behind the encode (SURVEY 8e iii): the shard is encoded in
+ * n_chunks pieces on the context's stream while a second stream moves each finished piece IN PLACE
+ * (grouped ncclSend / ncclRecv straight into d_all + peer*count + w0: no staging buffer, no strided copy;
+ * BITNUC_GATHER_MODE=bcast uses grouped in-place ncclBroadcast instead).  The context's stream waits for
+ * the exchange, so bitnuc_ctx_sync() covers the whole call; an InvalidBase index is relative to the shard. */
+int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, int n_chunks, uint64_t *d_all, bitnuc_err *err);
 /* Single-process form over bitnuc_comm_init_all's contexts: one call drives all n GPUs
  * (encode on every device, then one grouped all-gather), then synchronises all streams. */
 int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err);
+
+/* xGMI link probe (no reference counterpart; SURVEY section 5 asks for the measured per-link rate before any
+ * fabric fraction is quoted): hipMemcpyPeerAsync of `bytes` from src_device to each of dst_devices[0..n), one
+ * link at a time (gb_s_each[i], best of reps) and then all n at once (*gb_s_all, the aggregate outbound rate).
+ * All devices must be visible in this process and peer-accessible; fewer than two devices -> BITNUC_UNSUPPORTED
+ * with err.value = the device count. */
+int bitnuc_peer_link_probe(int src_device, const int *dst_devices, int n, size_t bytes, int reps, double *gb_s_each, double *gb_s_all, bitnuc_err *err);
 
 /* ---- synthetic input (the reference's tests use nucgen::Sequence::fill_buffer,
  * src/utils/mod.rs:116-121; its stream is unpinned, so the build ships its own) ---- */
@@ -290,6 +320,12 @@ double bitnuc_selftime_small(int op, size_t n, size_t iters);
 /* GB/s of the host-path staging pool's parallel memcpy (tools/host_path.py): mode 0 pageable -> pageable, 1 pageable -> pinned,
  * 2 pinned -> pageable; < 0 on failure. */
 double bitnuc_selftime_host_copy(size_t bytes, int threads, int mode);
+
+/* Configuration and creation-time measurements of this context's pipelined host-pointer path (creates it if needed):
+ * out[0..n) = cores_visible, cores_quota (0 = none), cores_usable, chunk_bases, depth, encode stage-in / hand-back threads,
+ * decode stage-in / hand-back threads, pinned H2D GB/s, pinned D2H GB/s, stage-in memcpy GB/s and hand-back memcpy GB/s at
+ * the chosen thread counts, heavy_cap, calibrated. */
+int bitnuc_host_pipe_info(bitnuc_ctx *ctx, double *out, int n, bitnuc_err *err);
 
 #ifdef __cplusplus
 }
