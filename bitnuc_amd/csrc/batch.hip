@@ -9,6 +9,7 @@ using namespace bitnuc_rt;
 
 extern "C" {
 
+#ifdef BITNUC_SWEEP_VARIANTS // round 2's table-driven form (tile records by a search pre-kernel): evidence build only
 // ---- ragged batches ---------------------------------------------------------------------------
 // rec[b] = {owner, first byte} of every 64-word wave tile, into context scratch (enqueued on the stream)
 static int batch_owners(bitnuc_ctx *c, const uint64_t *d_offsets, const uint64_t *d_word_offsets, size_t count, size_t total_words,
@@ -30,6 +31,7 @@ static int batch_owners(bitnuc_ctx *c, const uint64_t *d_offsets, const uint64_t
     *recs = o;
     return BITNUC_OK;
 }
+#endif
 
 static int check_offsets(const uint64_t *offsets, size_t count, bitnuc_err *err) {
     for (size_t i = 0; i < count; ++i)
@@ -68,29 +70,110 @@ int bitnuc_batch_word_offsets_dev(bitnuc_ctx *c, const uint64_t *d_offsets, size
     return BITNUC_OK;
 }
 
+// The table-driven forms.  Everything the layout plan depends on is in the caller's two tables and `total_words`, so ONE
+// asynchronous launch (plan_emit_kernel: no scan, no host synchronisation, no memset) emits the plan's pad bytes, tile bases and
+// buffer bounds into context scratch and the plan kernels do the work.  The scratch plan lives until the next table-driven call
+// on this context (stream order).  Scratch grows on the first call / a larger batch (an allocation, which waits for the stream).
+static int emit_scratch_plan(bitnuc_ctx *c, const uint64_t *d_offsets, const uint64_t *d_word_offsets, size_t count, size_t total_words,
+                             uint8_t **P, unsigned long long **tile_base, unsigned long long **bounds, bitnuc_err *err) {
+    const size_t ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    if (int st = ensure_scratch(c, 6, total_words + 2 + kBatchTile, err)) return st;
+    if (int st = ensure_scratch(c, 7, (ntiles + 1 + 2) * sizeof(unsigned long long), err)) return st;
+    *P = c->scratch[6];
+    *tile_base = reinterpret_cast<unsigned long long *>(c->scratch[7]);
+    *bounds = *tile_base + ntiles + 1;
+    const size_t threads = (count + kScanPer - 1) / kScanPer;
+    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
+    plan_emit_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_offsets),
+                                                      reinterpret_cast<const unsigned long long *>(d_word_offsets), count, *P, *tile_base, *bounds);
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+static int launch_plan_encode(bitnuc_ctx *c, const unsigned long long *d_base, const uint8_t *d_P, size_t total_words, const unsigned long long *d_bounds,
+                              const uint8_t *d_seq, uint64_t *d_out, bitnuc_err *err) {
+    unsigned long long *slot;
+    if (int st = take_slot(c, 0, &slot, err)) return st;
+    const int threads = c->plan_enc_block; // 64, 128 or 256 threads: a wave owns a tile, so any number of waves per workgroup works
+    const size_t per_block = (size_t)kBatchTile * (size_t)(threads / 64);
+    const unsigned long long blocks = (total_words + per_block - 1) / per_block;
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
+    const unsigned long long U = (unsigned long long)c->plan_enc_tiles;
+    const unsigned grid = grid_for(c, (blocks + U - 1) / U, threads);
+#define PLAN_ENC(UU) encode_batch_plan_kernel<UU><<<grid, threads, 0, c->stream>>>(d_seq, d_base, d_P, total_words, d_bounds, o, slot)
+    if constexpr (kEvidenceBuild) {
+#define PLAN_ENC_ABL(A) encode_batch_plan_kernel<1, A><<<grid, threads, 0, c->stream>>>(d_seq, d_base, d_P, total_words, d_bounds, o, slot)
+        if (U == 2) PLAN_ENC(2);
+        else if (U == 4) PLAN_ENC(4);
+        else switch (c->plan_enc_abl) { // timing-only ablations, right only for 32-base reads (tools/ab_plan_enc_ablate.py)
+        case 1: PLAN_ENC_ABL(1); break;
+        case 2: PLAN_ENC_ABL(2); break;
+        case 4: PLAN_ENC_ABL(4); break;
+        case 6: PLAN_ENC_ABL(6); break;
+        case 7: PLAN_ENC_ABL(7); break;
+        default: PLAN_ENC(1); break;
+        }
+#undef PLAN_ENC_ABL
+    } else {
+        PLAN_ENC(1);
+    }
+#undef PLAN_ENC
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
+static int launch_plan_decode(bitnuc_ctx *c, const unsigned long long *d_base, const uint8_t *d_P, size_t total_words, const uint64_t *d_words,
+                              uint8_t *d_out, bitnuc_err *err) {
+    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
+    const int tiles_per_wave = c->plan_tiles;
+    const size_t per_block2 = (size_t)kBatchTile * kBatchWaves * (size_t)tiles_per_wave;
+    const unsigned grid2 = grid_for(c, (total_words + per_block2 - 1) / per_block2);
+#define PLAN_DEC(POL, U) decode_batch_plan_kernel<POL, U><<<grid2, kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out)
+#define PLAN_DEC_U(POL) do { if (tiles_per_wave == 1) PLAN_DEC(POL, 1); else if (tiles_per_wave == 2) PLAN_DEC(POL, 2); else PLAN_DEC(POL, 4); } while (0)
+    if constexpr (kEvidenceBuild) {
+        if (c->plan_store == 0) PLAN_DEC_U(0);
+        else if (c->plan_store == 1) PLAN_DEC_U(1);
+        else PLAN_DEC_U(2);
+    } else {
+        PLAN_DEC(2, 1);
+    }
+#undef PLAN_DEC_U
+#undef PLAN_DEC
+    HIPCHK(hipGetLastError());
+    return BITNUC_OK;
+}
+
 int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, const uint64_t *d_word_offsets, size_t count, size_t total_words, uint64_t *d_out, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
     if (count == 0 || total_words == 0) return BITNUC_OK;
     if (!d_seq || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const unsigned long long *po = reinterpret_cast<const unsigned long long *>(d_offsets), *pw = reinterpret_cast<const unsigned long long *>(d_word_offsets);
-    unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
-    const TileRec *recs;
-    if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
-    unsigned long long *slot;
-    if (int st = take_slot(c, 0, &slot, err)) return st;
-    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
-    const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
-    switch (c->batch_abl) {
-#ifdef BITNUC_SWEEP_VARIANTS // timing-only ablations (tools/ab_batch_ablate.py, evidence build only): anything but 0 produces wrong words
-#define ABL_CASE(A) case A: encode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot); break;
-    ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11)
-#undef ABL_CASE
-#endif
-    default: encode_batch2_kernel<0><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot);
+    if (c->batch_tables_impl == 1 || !kEvidenceBuild) {
+        uint8_t *P;
+        unsigned long long *tile_base, *bounds;
+        if (int st = emit_scratch_plan(c, d_offsets, d_word_offsets, count, total_words, &P, &tile_base, &bounds, err)) return st;
+        return launch_plan_encode(c, tile_base, P, total_words, bounds, d_seq, d_out, err);
     }
-    HIPCHK(hipGetLastError());
+#ifdef BITNUC_SWEEP_VARIANTS
+    { // round 2's form: tile records by a search pre-kernel + O(1) window lookup inside the main kernel
+        const unsigned long long *po = reinterpret_cast<const unsigned long long *>(d_offsets), *pw = reinterpret_cast<const unsigned long long *>(d_word_offsets);
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
+        const TileRec *recs;
+        if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
+        unsigned long long *slot;
+        if (int st = take_slot(c, 0, &slot, err)) return st;
+        const size_t per_block = (size_t)kBatchTile * kBatchWaves;
+        const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
+        switch (c->batch_abl) { // timing-only ablations (tools/ab_batch_ablate.py): anything but 0 produces wrong words
+#define ABL_CASE(A) case A: encode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot); break;
+        ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11)
+#undef ABL_CASE
+        default: encode_batch2_kernel<0><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot);
+        }
+        HIPCHK(hipGetLastError());
+    }
+#endif
     return BITNUC_OK;
 }
 
@@ -100,21 +183,29 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64
     if (count == 0 || total_words == 0) return BITNUC_OK;
     if (!d_words || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const unsigned long long *po = reinterpret_cast<const unsigned long long *>(d_offsets), *pw = reinterpret_cast<const unsigned long long *>(d_word_offsets);
-    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
-    const TileRec *recs;
-    if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
-    const size_t per_block = (size_t)kBatchTile * kBatchWaves;
-    const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
-    switch (c->batch_abl) {
-#ifdef BITNUC_SWEEP_VARIANTS
-#define ABL_CASE(A) case A: decode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out); break;
-    ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11) ABL_CASE(15)
-#undef ABL_CASE
-#endif
-    default: decode_batch2_kernel<0><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out);
+    if (c->batch_tables_impl == 1 || !kEvidenceBuild) {
+        uint8_t *P;
+        unsigned long long *tile_base, *bounds;
+        if (int st = emit_scratch_plan(c, d_offsets, d_word_offsets, count, total_words, &P, &tile_base, &bounds, err)) return st;
+        return launch_plan_decode(c, tile_base, P, total_words, d_words, d_out, err);
     }
-    HIPCHK(hipGetLastError());
+#ifdef BITNUC_SWEEP_VARIANTS
+    {
+        const unsigned long long *po = reinterpret_cast<const unsigned long long *>(d_offsets), *pw = reinterpret_cast<const unsigned long long *>(d_word_offsets);
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
+        const TileRec *recs;
+        if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
+        const size_t per_block = (size_t)kBatchTile * kBatchWaves;
+        const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
+        switch (c->batch_abl) {
+#define ABL_CASE(A) case A: decode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out); break;
+        ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11) ABL_CASE(15)
+#undef ABL_CASE
+        default: decode_batch2_kernel<0><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out);
+        }
+        HIPCHK(hipGetLastError());
+    }
+#endif
     return BITNUC_OK;
 }
 
@@ -207,7 +298,8 @@ struct bitnuc_batch_plan {
     unsigned long long *d_wo = nullptr;   // count + 1 word offsets
     unsigned long long *d_base = nullptr; // one byte offset per 64-word tile
     uint8_t *d_P = nullptr;               // total_words + 1 pad bytes
-    size_t cap_wo = 0, cap_base = 0, cap_P = 0;
+    unsigned long long *d_bounds = nullptr; // offsets[0], offsets[count] (what the plan encode clips its loads to)
+    size_t cap_wo = 0, cap_base = 0, cap_P = 0, cap_bounds = 0;
     bool built = false;
 };
 
@@ -227,6 +319,7 @@ void bitnuc_batch_plan_destroy(bitnuc_batch_plan *p) {
     if (p->d_wo) (void)hipFree(p->d_wo);
     if (p->d_base) (void)hipFree(p->d_base);
     if (p->d_P) (void)hipFree(p->d_P);
+    if (p->d_bounds) (void)hipFree(p->d_bounds);
     delete p;
 }
 
@@ -291,9 +384,11 @@ int bitnuc_batch_plan_build_dev(bitnuc_ctx *c, bitnuc_batch_plan *p, const uint6
         word_offsets_finish<true><<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums, p->d_wo, p->d_P, p->d_base);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(c->stream)); // the build is synchronous: the plan's tables may be read on any stream afterwards
     p->seq_begin = ends[1];
     p->seq_end = ends[2];
+    if (int st = plan_reserve(&p->d_bounds, &p->cap_bounds, 2, c->stream, err)) return st;
+    HIPCHK(hipMemcpyAsync(p->d_bounds, &ends[1], 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream)); // the build is synchronous: the plan's tables may be read on any stream afterwards
     p->built = true;
     if (total_words) *total_words = total;
     return BITNUC_OK;
@@ -306,34 +401,7 @@ int bitnuc_encode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, cons
     if (p->total_words == 0) return BITNUC_OK;
     if (!d_seq || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    unsigned long long *slot;
-    if (int st = take_slot(c, 0, &slot, err)) return st;
-    const int threads = c->plan_enc_block; // 64, 128 or 256 threads: a wave owns a tile, so any number of waves per workgroup works
-    const size_t per_block = (size_t)kBatchTile * (size_t)(threads / 64);
-    const unsigned long long blocks = (p->total_words + per_block - 1) / per_block;
-    unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
-    const unsigned long long U = (unsigned long long)c->plan_enc_tiles;
-    const unsigned grid = grid_for(c, (blocks + U - 1) / U, threads);
-#define PLAN_ENC(UU) encode_batch_plan_kernel<UU><<<grid, threads, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end, o, slot)
-    if constexpr (kEvidenceBuild) {
-#define PLAN_ENC_ABL(A) encode_batch_plan_kernel<1, A><<<grid, threads, 0, c->stream>>>(d_seq, p->d_base, p->d_P, p->total_words, p->seq_begin, p->seq_end, o, slot)
-        if (U == 2) PLAN_ENC(2);
-        else if (U == 4) PLAN_ENC(4);
-        else switch (c->plan_enc_abl) { // timing-only ablations, right only for 32-base reads (tools/ab_plan_enc_ablate.py)
-        case 1: PLAN_ENC_ABL(1); break;
-        case 2: PLAN_ENC_ABL(2); break;
-        case 4: PLAN_ENC_ABL(4); break;
-        case 6: PLAN_ENC_ABL(6); break;
-        case 7: PLAN_ENC_ABL(7); break;
-        default: PLAN_ENC(1); break;
-        }
-#undef PLAN_ENC_ABL
-    } else {
-        PLAN_ENC(1);
-    }
-#undef PLAN_ENC
-    HIPCHK(hipGetLastError());
-    return BITNUC_OK;
+    return launch_plan_encode(c, p->d_base, p->d_P, p->total_words, p->d_bounds, d_seq, d_out, err);
 }
 
 int bitnuc_decode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, const uint64_t *d_words, uint8_t *d_out, bitnuc_err *err) {
@@ -343,23 +411,7 @@ int bitnuc_decode_batch_plan_dev(bitnuc_ctx *c, const bitnuc_batch_plan *p, cons
     if (p->total_words == 0) return BITNUC_OK;
     if (!d_words || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
-    const int tiles_per_wave = c->plan_tiles;
-    const size_t per_block2 = (size_t)kBatchTile * kBatchWaves * (size_t)tiles_per_wave;
-    const unsigned grid2 = grid_for(c, (p->total_words + per_block2 - 1) / per_block2);
-#define PLAN_DEC(POL, U) decode_batch_plan_kernel<POL, U><<<grid2, kBlock, 0, c->stream>>>(w, p->d_base, p->d_P, p->total_words, d_out)
-#define PLAN_DEC_U(POL) do { if (tiles_per_wave == 1) PLAN_DEC(POL, 1); else if (tiles_per_wave == 2) PLAN_DEC(POL, 2); else PLAN_DEC(POL, 4); } while (0)
-    if constexpr (kEvidenceBuild) {
-        if (c->plan_store == 0) PLAN_DEC_U(0);
-        else if (c->plan_store == 1) PLAN_DEC_U(1);
-        else PLAN_DEC_U(2);
-    } else {
-        PLAN_DEC(2, 1);
-    }
-#undef PLAN_DEC_U
-#undef PLAN_DEC
-    HIPCHK(hipGetLastError());
-    return BITNUC_OK;
+    return launch_plan_decode(c, p->d_base, p->d_P, p->total_words, d_words, d_out, err);
 }
 
 // ---- fixed-length reads ------------------------------------------------------------------------

@@ -34,6 +34,23 @@ template <class T> __device__ __forceinline__ void store_packed(T v, T *p) {
     else *p = v;
 }
 
+// The batch kernels load whole 16-byte ALIGNED chunks, so the chunk that holds the batch's first base may begin with up to 15
+// bytes that are not the batch's (a FASTA header's newline, another buffer).  They are never validated -- but enc4 compacts a
+// dword's four codes with a multiply-add, and a byte that is not a base leaves more than two bits there: a foreign byte in
+// the SAME dword as the batch's first bases would spill into their codes (found in round 3 by the first test that handed the
+// _dev entry points a batch starting mid-dword behind 'N' bytes; the host-pointer forms stage the batch at an aligned address and
+// never saw it).  The first chunk of the first tile therefore has its leading foreign bytes replaced by 'A' (code 0, valid).
+__device__ __forceinline__ u32x4 mask_lead_bytes(u32x4 v, unsigned lead /* 0..15 bytes to replace */) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nbytes = (int)lead - 4 * i;
+        const uint32_t m = nbytes >= 4 ? ~0u : (nbytes <= 0 ? 0u : (1u << (8 * nbytes)) - 1u);
+        w[i] = (w[i] & ~m) | (0x41414141u & m);
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
+
 // index of the sequence that owns word w: upper_bound(word_offsets[0..count], w) - 1
 __device__ __forceinline__ unsigned long long owner_of_word(const unsigned long long *__restrict__ wo,
                                                             unsigned long long count, unsigned long long w) {
@@ -295,6 +312,87 @@ word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned lon
     }
 }
 
+// ---------------------------------------------------------------------------------
+// layout plan from BOTH tables in one asynchronous pass (the table-driven entry points)
+// ---------------------------------------------------------------------------------
+// bitnuc_encode_batch_dev / bitnuc_decode_batch_dev receive offsets, word offsets and total_words: everything the plan's
+// two arrays depend on is on the device and their sizes are known to the host, so the plan can be emitted into context
+// scratch by ONE launch with no scan, no host synchronisation and no memset -- and the plan kernels run unchanged.  (Round 2's
+// table-driven form searched the owner of every tile in a pre-kernel and rebuilt the per-word lookup inside the main kernels:
+// 0.245 / 0.252 ms against 0.205 / 0.206 for the plan kernels, profiles/r02_batch_kernel_stats.txt.)
+// A thread owns kScanPer consecutive sequences (both tables: four 16-byte loads + one 8-byte load each) and with them the pad
+// bytes P[w0 + 1 .. w8] (w0 / w8 = its first / one-past-last word): it ZEROES that range itself with 16-byte stores (adjacent
+// threads own adjacent ranges: every P byte in 1..total_words is written exactly once, none needs a memset) and then drops
+// each sequence's pad byte on top (same thread, same address: program order).  A range longer than kEmitCoop bytes (long
+// sequences) is zeroed by the whole wave.  bounds[0..1] = offsets[0], offsets[count] for the plan encode's buffer clipping.
+constexpr unsigned kEmitCoop = 256;
+
+__device__ __forceinline__ void plan_emit_tile_bases(unsigned long long a, unsigned long long b, unsigned long long o, bool valid,
+                                                     unsigned long long *__restrict__ tile_base) {
+    const unsigned lane = threadIdx.x & 63;
+    const bool has_words = valid && b > a;
+    const unsigned long long t0 = (a + 63) >> 6, t1 = has_words ? (b + 63) >> 6 : t0; // tile boundaries 64 t inside [a, b)
+    const bool is_long = t1 - t0 > 8;
+    if (!is_long)
+        for (unsigned long long t = t0; t < t1; ++t) tile_base[t] = o + (((t << 6) - a) << 5);
+    unsigned long long m = __ballot(is_long);
+    while (m) {
+        const unsigned l = (unsigned)__builtin_ctzll(m);
+        m &= m - 1;
+        const unsigned long long A = read_lane_u64(a, l), O = read_lane_u64(o, l), T0 = read_lane_u64(t0, l), T1 = read_lane_u64(t1, l);
+        for (unsigned long long t = T0 + lane; t < T1; t += 64) tile_base[t] = O + (((t << 6) - A) << 5);
+    }
+}
+
+// zero P[lo .. lo + n): 16-byte stores at any byte address (gfx950 unaligned-access mode), then 8 / 4 / 2 / 1
+__device__ __forceinline__ void zero_bytes(uint8_t *__restrict__ p, unsigned long long n) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    unsigned long long k = 0;
+    for (; k + 16 <= n; k += 16) *reinterpret_cast<u32x4_u *>(p + k) = z;
+    if (n & 8) { *reinterpret_cast<u32x2_u *>(p + k) = u32x2{0u, 0u}; k += 8; }
+    if (n & 4) { *reinterpret_cast<u32_u *>(p + k) = 0u; k += 4; }
+    if (n & 2) { p[k] = 0; p[k + 1] = 0; k += 2; }
+    if (n & 1) p[k] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets, unsigned long long count,
+                 uint8_t *__restrict__ P, unsigned long long *__restrict__ tile_base, unsigned long long *__restrict__ bounds) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long i = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) * kScanPer;
+    unsigned long long o[kScanPer + 1], w[kScanPer + 1];
+    const unsigned long long ic = i < count ? i : count; // threads past the table hold nine copies of its last entry: nothing to write
+    load_offsets9(offsets, count, ic, o);
+    load_offsets9(word_offsets, count, ic, w);
+    if (i == 0) { bounds[0] = o[0]; bounds[1] = offsets[count]; }
+    // this thread's pad bytes: P[w[0] + 1 .. w[8]]
+    const unsigned long long len = w[kScanPer] - w[0];
+    uint8_t *mine = P + w[0] + 1;
+    const bool coop = len > kEmitCoop;
+    if (!coop) zero_bytes(mine, len);
+    unsigned long long m = __ballot(coop);
+    if (m) { // wave-uniform: some lane holds a long range (long sequences) -- the whole wave zeroes it
+        while (m) {
+            const unsigned l = (unsigned)__builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned long long W0 = read_lane_u64(w[0], l), L = read_lane_u64(len, l);
+            uint8_t *q = P + W0 + 1;
+            const unsigned long long body = L & ~15ull;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (unsigned long long k = 16ull * lane; k < body; k += 1024) *reinterpret_cast<u32x4_u *>(q + k) = z;
+            if (lane < (unsigned)(L - body)) q[body + lane] = 0;
+        }
+        // the pad bytes below land inside ranges other lanes have just zeroed: wait until those stores have been performed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // rare path (sequences of > 8 K bases): its cost does not matter
+    }
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        const bool valid = ic + j < count;
+        if (valid && w[j + 1] > w[j]) P[w[j + 1]] = (uint8_t)(32ull * (w[j + 1] - w[j]) - (o[j + 1] - o[j]));
+        plan_emit_tile_bases(w[j], w[j + 1], o[j], valid, tile_base);
+    }
+}
+
 // ---- the wave-private LDS strip of 32-bit chunk words (codes of 16 bases), shared by every tile kernel below ----------
 // Chunk c lives at strip_slot(c): EVEN chunks at strip[0..], ODD chunks at strip[kSplitOdd..].  A word is 2 chunks long, so
 // with a linear strip lane l's three funnel dwords (encode) or three OR targets (decode) start 2 dwords after lane l-1's:
@@ -378,6 +476,7 @@ encode_word_from_stream(const uint8_t *__restrict__ seq, unsigned long long seq_
         const unsigned c = lane + 64 * r;
         v[r] = c < nchunk ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(lo16 + 16 * (uintptr_t)c)) : u32x4{0, 0, 0, 0};
     }
+    if (span_lo == 0 && lane == 0) v[0] = mask_lead_bytes(v[0], (unsigned)(lo - lo16)); // bytes before the buffer (see mask_lead_bytes)
     wave_lds_fence(); // previous trip's strip readers are done
     stream_fill(v, nchunk, lo16, seq, seq_end, strip, slot);
     wave_lds_fence();
@@ -820,7 +919,8 @@ encode_batch2_kernel(const uint8_t *__restrict__ seq, const unsigned long long *
         }
         // code words of the chunks -> strip (chunks past the buffer end and the funnel's slack are zero)
         uint32_t b0 = 0, b1 = 0, b2 = 0;
-        const uint32_t c0 = enc16(v0, b0), c1 = enc16(v1, b1), c2 = enc16(v2, b2);
+        const u32x4 v0m = (tile == 0 && lane == 0) ? mask_lead_bytes(v0, (unsigned)(lo - lo16)) : v0; // see mask_lead_bytes
+        const uint32_t c0 = enc16(v0m, b0), c1 = enc16(v1, b1), c2 = enc16(v2, b2);
         wave_lds_fence(); // the previous trip's strip readers are done
         uint32_t *mine = strip_slot(my.strip, lane); // chunk `lane`; chunk lane + 64 has the same parity: 32 dwords further
         mine[0] = c0;
@@ -971,7 +1071,9 @@ __device__ __forceinline__ void plan_enc_finish(const uint8_t *__restrict__ seq,
         return;
     }
     uint32_t b0 = 0, b1 = 0, b2 = 0;
-    const uint32_t c0 = enc16(t.v0, b0), c1 = enc16(t.v1, b1), c2 = enc4(x2, b2);
+    u32x4 v0 = t.v0;
+    if (g.wb == 0 && g.lead != 0 && lane == 0) v0 = mask_lead_bytes(v0, g.lead); // the batch's first chunk: bytes before its first base are not its own
+    const uint32_t c0 = enc16(v0, b0), c1 = enc16(t.v1, b1), c2 = enc4(x2, b2);
     wave_lds_fence(); // the previous tile's strip readers are done
     uint32_t *mine = strip_slot(strip, lane); // chunk `lane`; chunk lane + 64 has the same parity: 32 dwords further
     mine[0] = c0;
@@ -998,9 +1100,10 @@ __device__ __forceinline__ void plan_enc_finish(const uint8_t *__restrict__ seq,
 template <int U, int ABL = 0>
 __global__ void __launch_bounds__(kBlock)
 encode_batch_plan_kernel(const uint8_t *__restrict__ seq, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
-                         unsigned long long total_words, unsigned long long seq_begin, unsigned long long seq_end,
+                         unsigned long long total_words, const unsigned long long *__restrict__ bounds /* offsets[0], offsets[count]: device memory */,
                          unsigned long long *__restrict__ out, unsigned long long *__restrict__ slot) {
     __shared__ uint32_t strips[kBatchWaves][kB2Strip];
+    const unsigned long long seq_begin = bounds[0], seq_end = bounds[1]; // wave-uniform (scalar loads), issued with the first tile base
     const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
     uint32_t *strip = strips[wave];
     const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;

@@ -114,9 +114,36 @@ hipError_t launch_encode_t(bitnuc_ctx *c, const uint8_t *seq, uint32_t *out32, u
     return hipGetLastError();
 }
 
+// encode variants 47..62 (evidence build): encode_quad_kernel (16-byte stores by a register quad transpose, 4 rounds per wave).
+// id - 47: bit 0 = nt loads, bit 1 = nt stores, bit 2 = XCD-contiguous tile order, bit 3 = 256 (not 128) threads per workgroup.
+constexpr int kQuadFirst = 47, kQuadLast = 62;
+template <int BLOCK>
+hipError_t launch_encode_quad_t(bitnuc_ctx *c, int mode, const uint8_t *seq, uint32_t *out32, unsigned long long len, unsigned long long *slot) {
+    const unsigned grid = grid_for(c, (len >> 4) / ((unsigned long long)BLOCK * 4) + 1, BLOCK);
+#define QUAD(NL, NS, XC) encode_quad_kernel<BLOCK, NL, NS, XC><<<grid, BLOCK, 0, c->stream>>>(seq, out32, len, slot)
+    switch (mode & 7) {
+    case 0: QUAD(false, false, false); break;
+    case 1: QUAD(true, false, false); break;
+    case 2: QUAD(false, true, false); break;
+    case 3: QUAD(true, true, false); break;
+    case 4: QUAD(false, false, true); break;
+    case 5: QUAD(true, false, true); break;
+    case 6: QUAD(false, true, true); break;
+    default: QUAD(true, true, true); break;
+    }
+#undef QUAD
+    return hipGetLastError();
+}
+
 hipError_t launch_encode(bitnuc_ctx *c, const uint8_t *seq, uint64_t *out, unsigned long long len, unsigned long long *slot) {
     uint32_t *o = reinterpret_cast<uint32_t *>(out);
     const bool in_al = aligned16(seq), out_al = aligned16(out);
+#ifdef BITNUC_SWEEP_VARIANTS
+    if (c->enc_variant >= kQuadFirst && c->enc_variant <= kQuadLast && in_al && out_al) {
+        const int mode = c->enc_variant - kQuadFirst;
+        return (mode & 8) ? launch_encode_quad_t<256>(c, mode, seq, o, len, slot) : launch_encode_quad_t<128>(c, mode, seq, o, len, slot);
+    }
+#endif
 #ifdef BITNUC_SWEEP_VARIANTS
     if (c->enc_variant == kBallotVariant) { // lane-per-base + ballot formulation (evidence variant)
         const unsigned grid = grid_for(c, ((len + 63) / 64 + (kBlock / 64) * 4 - 1) / ((kBlock / 64) * 4));
@@ -125,6 +152,7 @@ hipError_t launch_encode(bitnuc_ctx *c, const uint8_t *seq, uint64_t *out, unsig
     }
 #endif
     int v = c->enc_variant;
+    if (v >= kQuadFirst) v = kDefaultEnc; // a quad variant asked for unaligned buffers: the default kernel handles any alignment
     // the LDS-transpose variant needs 16-byte aligned buffers on both sides
     if (variant_info(v).xpose && !(in_al && out_al)) v = kDefaultEnc;
     switch (v) {
@@ -191,7 +219,7 @@ hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsi
 } // namespace
 
 namespace bitnuc_rt {
-bool codec_variant_built(int id) { return variant_info(id).built; }
+bool codec_variant_built(int id) { return (kEvidenceBuild && id >= kQuadFirst && id <= kQuadLast) || variant_info(id).built; }
 bool codec_decode_variant_ok(int id) { return (kEvidenceBuild && id >= kX2First && id <= kX2Last) || variant_info(id).built; }
 int codec_num_variants() { return kNumVariants; }
 int codec_ballot_variant() { return kEvidenceBuild ? kBallotVariant : -1; }

@@ -30,6 +30,41 @@
 
 namespace bitnuc_dev {
 
+// What the tiled loops leave over, done by ONE workgroup: the 16-base groups from `first_group` on (bounds-checked, plain
+// path), the last 1..15 bases, and the zero upper half of the final u64 when the number of 16-base groups is odd.
+template <int BLOCK, bool ALIGNED>
+__device__ __forceinline__ void encode_tail(const uint8_t *__restrict__ seq, uint32_t *__restrict__ out32, unsigned long long len,
+                                            unsigned long long first_group, unsigned long long *__restrict__ slot) {
+    const unsigned t = threadIdx.x;
+    const unsigned long long n16 = len >> 4;
+    for (unsigned long long g = first_group + t; g < n16; g += BLOCK) {
+        const u32x4 v = load_group<false, ALIGNED>(seq + (g << 4));
+        uint32_t b = 0;
+        const uint32_t r = enc16(v, b);
+        if (residue_is_bad(b)) rescan_bytes(seq, g << 4, 16, slot);
+        out32[g] = r;
+    }
+    if (t == 0) {
+        const unsigned rem = (unsigned)(len & 15);
+        unsigned long long ngroups = n16;
+        if (rem) {
+            uint32_t r = 0;
+            bool flagged = false;
+            for (unsigned i = 0; i < rem; ++i) {
+                const uint32_t b = seq[(n16 << 4) + i];
+                if (!valid_base(b) && !flagged) {
+                    latch_bad(slot, (n16 << 4) + i, b);
+                    flagged = true;
+                }
+                r |= code_of(b) << (2 * i);
+            }
+            out32[n16] = r;
+            ngroups = n16 + 1;
+        }
+        if (ngroups & 1) out32[ngroups] = 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // encode
 // ---------------------------------------------------------------------------------
@@ -86,36 +121,58 @@ encode_kernel(const uint8_t *__restrict__ seq, uint32_t *__restrict__ out32, uns
     }
 
     // groups past the last full tile: one block, bounds-checked, plain path
-    if (blockIdx.x == (unsigned)(full_tiles % gridDim.x)) {
-        for (unsigned long long g = full_tiles * TILE + t; g < n16; g += BLOCK) {
-            const u32x4 v = load_group<false, ALIGNED>(seq + (g << 4));
-            uint32_t b = 0;
-            const uint32_t r = enc16(v, b);
-            if (residue_is_bad(b)) rescan_bytes(seq, g << 4, 16, slot);
-            out32[g] = r;
+    if (blockIdx.x == (unsigned)(full_tiles % gridDim.x)) encode_tail<BLOCK, ALIGNED>(seq, out32, len, full_tiles * TILE, slot);
+}
+
+// ---------------------------------------------------------------------------------
+// encode, 16-byte stores by a register quad transpose (round 3, evidence build)
+// ---------------------------------------------------------------------------------
+// encode_kernel's stores are 4 bytes per lane (256 B per wave-instruction).  Here a wave owns 256 consecutive groups for 4
+// rounds (round u: lane l loads group 64 u + l, one contiguous KiB per instruction, as before); the 4 x 4 matrix that the four
+// lanes of a QUAD hold after the four rounds is transposed in registers (two DPP quad_perm butterflies, no LDS), after which
+// lane 4 q + u owns the four consecutive results 64 u + 4 q .. + 3 and stores them as ONE dwordx4: a quarter of the store
+// instructions, each wave-instruction still covering the same contiguous KiB (in a permuted lane order).
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true); }
+
+template <int BLOCK, bool NTLD, bool NTST, bool XCD>
+__global__ void __launch_bounds__(BLOCK)
+encode_quad_kernel(const uint8_t *__restrict__ seq, uint32_t *__restrict__ out32, unsigned long long len,
+                   unsigned long long *__restrict__ slot) {
+    constexpr unsigned long long TILE = (unsigned long long)BLOCK * 4;
+    const unsigned long long n16 = len >> 4;
+    const unsigned long long full_tiles = n16 / TILE;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool odd1 = (lane & 1u) != 0u, odd2 = (lane & 2u) != 0u;
+    for (unsigned long long tile = first_tile<XCD>(blockIdx.x, gridDim.x); tile < full_tiles; tile += gridDim.x) {
+        const unsigned long long gw = tile * TILE + (unsigned long long)wave * 256;
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load_group<NTLD, true>(seq + ((gw + u * 64 + lane) << 4));
+        uint32_t bad = 0, a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = enc16(v[u], bad);
+        if (__builtin_expect(residue_is_bad(bad), 0)) {
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) rescan_bytes(seq, (gw + u * 64 + lane) << 4, 16, slot);
         }
-        if (t == 0) {
-            // last 1..15 bases, and the zero upper half of the final u64 when the
-            // number of 16-base groups is odd
-            const unsigned rem = (unsigned)(len & 15);
-            unsigned long long ngroups = n16;
-            if (rem) {
-                uint32_t r = 0;
-                bool flagged = false;
-                for (unsigned i = 0; i < rem; ++i) {
-                    const uint32_t b = seq[(n16 << 4) + i];
-                    if (!valid_base(b) && !flagged) {
-                        latch_bad(slot, (n16 << 4) + i, b);
-                        flagged = true;
-                    }
-                    r |= code_of(b) << (2 * i);
-                }
-                out32[n16] = r;
-                ngroups = n16 + 1;
-            }
-            if (ngroups & 1) out32[ngroups] = 0;
-        }
+        // transpose inside each quad: b[j] on lane (4 q + u) = a[u] of lane (4 q + j)
+        // (every DPP move is pinned in wave-uniform control flow before the selects: hipcc may turn `c ? dpp(x) : y` into a branch
+        //  that runs the DPP move with the other lanes masked off, and a DPP read from a disabled lane returns 0 -- kmer_scan2_kernel)
+        uint32_t x0 = quad_xor1(a[0]), x1 = quad_xor1(a[1]), x2 = quad_xor1(a[2]), x3 = quad_xor1(a[3]);
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        const uint32_t s0 = odd1 ? x1 : a[0], s1 = odd1 ? a[1] : x0;
+        const uint32_t s2 = odd1 ? x3 : a[2], s3 = odd1 ? a[3] : x2;
+        uint32_t y0 = quad_xor2(s0), y1 = quad_xor2(s1), y2 = quad_xor2(s2), y3 = quad_xor2(s3);
+        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+        u32x4 r;
+        r.x = odd2 ? y2 : s0;
+        r.z = odd2 ? s2 : y0;
+        r.y = odd2 ? y3 : s1;
+        r.w = odd2 ? s3 : y1;
+        store_group<NTST, true>(reinterpret_cast<uint8_t *>(out32 + gw + 64 * (lane & 3u) + 4 * (lane >> 2)), r);
     }
+    if (blockIdx.x == (unsigned)(full_tiles % gridDim.x)) encode_tail<BLOCK, true>(seq, out32, len, full_tiles * TILE, slot);
 }
 
 // ---------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 u32x4_u __attribute__((aligned(1))); // any byte address (gfx950 unaligned-access mode)
 typedef uint32_t u32_u __attribute__((aligned(1)));
+typedef u32x2 u32x2_u __attribute__((aligned(1)));
 
 constexpr unsigned long long kNoBad = ~0ull;
 constexpr int kBlock = 256;

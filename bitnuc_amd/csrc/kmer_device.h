@@ -463,6 +463,77 @@ kmer_slide_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long lon
     }
 }
 
+// ---------------------------------------------------------------------------------
+// every window of a sequence, line-aligned rounds and no LDS strip (round 3)
+// ---------------------------------------------------------------------------------
+// kmer_slide_kernel<1> stops at 91 % of the box's fill rate: its rounds advance by 992 windows, so every 7.75 KiB wave store
+// starts and ends inside a line the neighbouring wave also writes, and its 9 KiB strip per wave limits a CU to 16 waves.
+// Here a round is 1024 windows at a 1024-byte aligned input offset -- 8 KiB of output = 64 whole lines per wave round -- and the
+// windows are not transposed at all: they are COMPUTED where they are stored.  Store instruction i (of 8) writes the contiguous
+// KiB of windows 128 i .. 128 i + 127, lane l the two windows at 128 i + 2 l.  Those 64 bits start at bit 256 i + 4 l of the
+// round's 2-bit stream, i.e. in code dword D = 8 i + (l >> 3) (dword d = the 16 bases packed by lane d), at bit 4 (l & 7): the
+// lane fetches dwords D, D+1, D+2 with three ds_bpermute_b32 (the LDS crossbar, no LDS memory: nothing is allocated, occupancy
+// is the register file's) and cuts both windows with v_alignbit.  24 bpermutes per round replace 8 + 8 b128 strip accesses.
+// Dwords 64 and 65 (the 30-base halo) are the first two code dwords of the NEXT round: inside a trip of U consecutive rounds
+// they are already in registers, the trip's last round gets them from one extra 16-byte load in lanes 0 and 1 (as kmer_scan2_kernel).
+// Needs bytes [1024 r, 1024 r + 1056) in bounds; the leftover windows go through kmer_batch_kernel.
+template <bool NTST, int U>
+__global__ void __launch_bounds__(kBlock)
+kmer_slide2_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned long long rounds, unsigned long long *__restrict__ out,
+                   unsigned long long *__restrict__ slot) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (kBlock / 64) + wave_in_block();
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * (kBlock / 64);
+    const uint32_t mlo = k >= 16 ? ~0u : (1u << (2 * k)) - 1u;
+    const uint32_t mhi = k <= 16 ? 0u : (k == 32 ? ~0u : (1u << (2 * k - 32)) - 1u);
+    const int src = (int)((lane >> 3) << 2);   // byte address of lane (l >> 3) for ds_bpermute; + 32 i + {0, 4, 8} as immediate offsets
+    const unsigned sh = 4u * (lane & 7u);      // bit offset of the lane's first window inside dword D
+    const bool g6 = (lane >> 3) == 6u, g7 = (lane >> 3) == 7u;
+    for (unsigned long long r0 = wave * U; r0 < rounds; r0 += nwaves * U) {
+        const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U; // valid rounds in this trip (wave-uniform)
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load_group<true, true>(seq + ((r0 + u < rounds ? r0 + u : rounds - 1) << 10) + 16 * lane);
+        u32x4 hv = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+        if (lane < 2) hv = load_group<false, true>(seq + ((r0 + m) << 10) + 16 * lane); // the halo of the trip's last round
+        uint32_t c[U + 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t bad = 0;
+            c[u] = enc16(v[u], bad);
+            if (__builtin_expect(residue_is_bad(bad) && (unsigned)u < m, 0)) rescan_bytes(seq, ((r0 + u) << 10) + 16 * lane, 16, slot);
+        }
+        {
+            uint32_t bad = 0; // halo bytes are validated by the round (or the tail) that owns them
+            c[U] = enc16(hv, bad);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((unsigned)u >= m) break; // wave-uniform
+            const uint32_t nx = (unsigned)(u + 1) < m ? c[u + 1] : c[U]; // code dwords of the next KiB (wave-uniform choice)
+            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)nx, 0), h1 = (uint32_t)__builtin_amdgcn_readlane((int)nx, 1);
+            unsigned long long *dst = out + ((r0 + u) << 10);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src + 32 * i, (int)c[u]);
+                uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src + 32 * i + 4, (int)c[u]);
+                uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src + 32 * i + 8, (int)c[u]);
+                if (i == 7) { // dwords 64 / 65 wrap around in the permute: they are the halo
+                    w1 = g7 ? h0 : w1;
+                    w2 = g6 ? h0 : (g7 ? h1 : w2);
+                }
+                u32x4 t;
+                t.x = __builtin_amdgcn_alignbit(w1, w0, sh) & mlo; // (a shift of 0 returns w0)
+                t.y = __builtin_amdgcn_alignbit(w2, w1, sh) & mhi;
+                t.z = __builtin_amdgcn_alignbit(w1, w0, sh + 2) & mlo;
+                t.w = __builtin_amdgcn_alignbit(w2, w1, sh + 2) & mhi;
+                u32x4 *d = reinterpret_cast<u32x4 *>(dst + 128 * i) + lane;
+                if constexpr (NTST) __builtin_nontemporal_store(t, d); else *d = t;
+            }
+        }
+    }
+}
+
 // Any other stride 3 <= S < 32 with k >= S: the same round, but a lane keeps only the windows whose position is a
 // multiple of S (at most ceil(16/S) of its 16, found with one wave-uniform division for the round's first base and a
 // 32-bit multiply-high step per lane), shifts them out with a per-lane v_alignbit amount, and drops them into the

@@ -156,7 +156,7 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     assert all(ctx.set_variant("decode", v) == -2 for v in range(47, 56)) and ctx.get("decode") == 22  # decode_x2_kernel: evidence build
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
-                                 ("slide_rounds", 1, (2, 4, 8)), ("scan_impl", 1, (0,)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
+                                 ("slide_rounds", 1, (8,)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 1, (0,)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,))):
         assert ctx.get(key) == shipped, key
         assert all(ctx.set_variant(key, v) == -2 for v in others) and ctx.get(key) == shipped, key
@@ -585,22 +585,25 @@ def _oracle_batch(oracle, seq, off):
     return (np.concatenate(words) if words else np.zeros(0, np.uint64)), np.array(wo, dtype=np.uint64)
 
 
-@pytest.fixture(params=[(1, 1), (1, 2), (1, 4), (0, 1)], ids=["plan", "plan-2tiles", "plan-4tiles", "tables"])
+@pytest.fixture(params=[(1, 1, 1), (1, 2, 1), (1, 4, 1), (0, 1, 1), (0, 1, 0)], ids=["plan", "plan-2tiles", "plan-4tiles", "tables", "tables-r2-kernels"])
 def batch_ctx(request, ctx, sweep_ctx):
     """A context set to one formulation of the ragged-batch kernels behind the host-pointer entry points: the layout plan
-    (bitnuc_batch_plan: one pad byte per word; what host calls use) or the table-driven kernels (tile records + O(1)
-    pad-scatter lookup from the two offset tables; what the *_dev table entry points use).  The plan kernels with 2 and 4
-    tiles per wave trip exist in the evidence build only (they lost their A/B)."""
-    use_plan, tiles = request.param
-    c = ctx if tiles == 1 else sweep_ctx
+    (bitnuc_batch_plan: one pad byte per word; what host calls use), the table-driven entry points (round 3: one asynchronous
+    pass emits the plan from the two offset tables into context scratch, then the plan kernels), or round 2's table-driven
+    kernels (tile records by a search pre-kernel + O(1) pad-scatter lookup), which live on in the evidence build.  The plan
+    kernels with 2 and 4 tiles per wave trip exist in the evidence build only (they lost their A/B)."""
+    use_plan, tiles, impl = request.param
+    c = ctx if (tiles == 1 and impl == 1) else sweep_ctx
     prev = c.set_variant("batch_host_plan", use_plan)
     prev_e = c.set_variant("plan_enc_tiles", tiles)
     prev_d = c.set_variant("plan_tiles", tiles)
-    assert c.get("plan_enc_tiles") == tiles and c.get("plan_tiles") == tiles
+    prev_i = c.set_variant("batch_tables_impl", impl)
+    assert c.get("plan_enc_tiles") == tiles and c.get("plan_tiles") == tiles and c.get("batch_tables_impl") == impl
     yield c
     c.set_variant("batch_host_plan", prev)
     c.set_variant("plan_enc_tiles", prev_e)
     c.set_variant("plan_tiles", prev_d)
+    c.set_variant("batch_tables_impl", prev_i)
 
 
 @pytest.mark.parametrize("shape", ["reads150", "tiny", "mixed", "with_empties", "one_long", "many_empties", "len32", "ones_and_empties", "unaligned_long"])

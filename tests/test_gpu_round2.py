@@ -5,7 +5,7 @@
   with (byte, index) and the words before the failing chunk checked (packing/mod.rs:181-196, packing/avx.rs:86-91,142-143);
 * the pipelined host-pointer path (pinned double buffers, three streams) against the oracle, errors in every chunk;
 * host code vs kernels on both sides of the size-dispatch cutoff;
-* config 4 on two GPUs through the C ABI (skipped on a one-GPU box): single-process init_all and per-rank init_rank;
+* (config 4 through the C ABI on 2 / 4 / 8 GPUs now lives in tests/test_gpu_round3.py)
 * bench.py --gpus 2 started with no launcher on one shared GPU.
 """
 import ctypes as C
@@ -204,103 +204,6 @@ def test_host_pointer_bulk_path_vs_oracle(host_ctx, oracle, pipeline):
         assert np.array_equal(ei.value.words, expect[: bad // 32]), bad
     # the context stays usable after an error
     assert np.array_equal(host_ctx.encode_array(s), expect)
-
-
-# ---- config 4 on two GPUs through the C ABI ---------------------------------------------------------------
-def _two_gpus():
-    import torch
-    return torch.cuda.device_count() >= 2
-
-
-def test_two_gpu_sharded_allgather_single_process(oracle):
-    """bitnuc_comm_init_all + bitnuc_encode_sharded_allgather_all on 2 GPUs == single-GPU encode of the concatenation."""
-    if not _two_gpus():
-        pytest.skip("needs >= 2 GPUs")
-    import torch
-    from bitnuc_amd import _lib as L
-    import bitnuc_amd as bn
-    lib = L.load()
-    n = 32 * 1_000_003  # per shard
-    ctxs, comms = (C.c_void_p * 2)(), (C.c_void_p * 2)()
-    err = L.BitnucErr()
-    assert lib.bitnuc_comm_init_all(2, ctxs, comms, C.byref(err)) == 0, err.backend_code
-    shards, alls = [], []
-    for r in range(2):
-        d = torch.device("cuda", r)
-        sq = torch.from_numpy(oracle.nucgen(n, SEED, r * n)).to(d)
-        shards.append(sq)
-        alls.append(torch.zeros(2 * n // 32, dtype=torch.int64, device=d))
-    for r in range(2):
-        torch.cuda.synchronize(r)
-    sp = (C.c_void_p * 2)(*[t.data_ptr() for t in shards])
-    ap = (C.c_void_p * 2)(*[t.data_ptr() for t in alls])
-    assert lib.bitnuc_encode_sharded_allgather_all(2, ctxs, comms, sp, n, ap, C.byref(err)) == 0, err.backend_code
-    # single-GPU encode of the concatenation
-    c0 = bn.Context(0)
-    c0.set_variant("force_gpu", 1)
-    whole = torch.cat([shards[0], shards[1].to("cuda:0")])
-    ref = torch.empty(2 * n // 32, dtype=torch.int64, device="cuda:0")
-    c0.encode_dev(whole, 2 * n, ref)
-    c0.sync()
-    assert torch.equal(alls[0], ref) and torch.equal(alls[1].to("cuda:0"), ref)
-    assert np.array_equal(ref[:4096].cpu().numpy().view(np.uint64), oracle.encode(oracle.nucgen(32 * 4096, SEED)))
-    c0.close()
-    for r in range(2):
-        lib.bitnuc_comm_destroy(comms[r])
-        lib.bitnuc_ctx_destroy(ctxs[r])
-
-
-def _rank_worker(rank, world, uid_path, n, q):
-    import time
-    import torch
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import bitnuc_amd as bn
-    import oracle_py
-    torch.cuda.set_device(rank)
-    c = bn.Context(rank)
-    c.set_variant("force_gpu", 1)
-    if rank == 0:
-        uid = bn.Comm.unique_id()
-        with open(uid_path + ".tmp", "wb") as f:
-            f.write(uid)
-        os.replace(uid_path + ".tmp", uid_path)
-    else:
-        t0 = time.time()
-        while not os.path.exists(uid_path):
-            if time.time() - t0 > 120:
-                raise RuntimeError("no unique id from rank 0")
-            time.sleep(0.05)
-        uid = open(uid_path, "rb").read()
-    comm = bn.Comm(c, world, rank, uid)
-    dev = torch.device("cuda", rank)
-    shard = torch.from_numpy(oracle_py.nucgen(n, SEED, rank * n)).to(dev)
-    allw = torch.zeros(world * n // 32, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    comm.encode_sharded_allgather_dev(shard, n, allw)
-    c.sync()
-    expect = oracle_py.encode(oracle_py.nucgen(world * n, SEED))
-    q.put((rank, bool(np.array_equal(allw.cpu().numpy().view(np.uint64), expect))))
-    comm.close()
-    c.close()
-
-
-def test_two_gpu_sharded_allgather_one_process_per_gpu(oracle, tmp_path):
-    """bitnuc_comm_init_rank in 2 processes (one per GPU): every rank ends with the packed words of the whole sequence."""
-    if not _two_gpus():
-        pytest.skip("needs >= 2 GPUs")
-    import torch.multiprocessing as mp
-    mctx = mp.get_context("spawn")
-    q = mctx.Queue()
-    uid_path = str(tmp_path / "uid.bin")
-    n = 32 * 250_001
-    procs = [mctx.Process(target=_rank_worker, args=(r, 2, uid_path, n, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
-    assert dict(q.get(timeout=10) for _ in range(2)) == {0: True, 1: True}
 
 
 def test_bench_self_launch_two_ranks_on_one_gpu():
