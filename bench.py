@@ -403,7 +403,10 @@ def run_rank(args, real_stdout, traffic):
 
     def barrier():
         if use_dist:
-            dist.barrier(group=ctl)
+            if on_gpu_collectives:
+                dist.barrier(group=ctl, device_ids=[local_rank])  # no rank -> device guessing inside the NCCL barrier
+            else:
+                dist.barrier(group=ctl)
 
     def fence():
         barrier()
@@ -561,9 +564,9 @@ def run_rank(args, real_stdout, traffic):
                                 traffic_source=tr.get("source") or tr.get("error"))
         line["roofline_encode"], line["roofline_decode"], line["roofline_step"] = r_enc, r_dec, r_step
         line.update(extra)
-        if with_cpu and world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps, all_cores=True)
+        if with_cpu and rank == 0 and not args.no_cpu_baseline:
+            try:  # north_star: the CPU SIMD path "in the same run" at every GPU count (N > 1: 3 repetitions on rank 0's host cores, the other ranks idle)
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps if world == 1 else min(args.cpu_reps, 3), all_cores=True)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)[:300]}
         return line
@@ -603,9 +606,8 @@ def run_rank(args, real_stdout, traffic):
             if on_gpu_collectives:
                 # encode + concatenation end to end, one shot vs chunked overlap (8 pieces: the
                 # fabric moves piece c while the GPU encodes piece c+1)
-                def enc_chunk(w0, w1):
-                    ctx.encode_dev(seqs[0][32 * w0:], min(n, 32 * w1) - 32 * w0, words[0][w0:])
-                    return words[0][w0:w1]
+                def enc_chunk(w0, w1, dst):  # in place: the piece is encoded straight into this rank's slot of the gathered buffer
+                    ctx.encode_dev(seqs[0][32 * w0:], min(n, 32 * w1) - 32 * w0, dst)
 
                 def one_shot():
                     ctx.encode_dev(seqs[0], n, words[0])
@@ -621,15 +623,31 @@ def run_rank(args, real_stdout, traffic):
                     e2e[name + "_ms"] = round((time.perf_counter() - t) / reps * 1e3, 3)
                     e2e[name + "_ok"] = bool(torch.equal(full, ref_full))
                     del full, ref_full
-                e2e["note"] = "encode of this rank's 10^9-base shard + all-gather of the packed words; fabric-bound, so it cannot scale like the step"
+                e2e["note"] = ("encode of this rank's 10^9-base shard + all-gather of the packed words; fabric-bound, so it cannot scale like the step; "
+                               "overlap8 = 8 pieces exchanged in place by grouped point-to-point sends while the next piece is encoded")
                 extra["encode_allgather_end_to_end"] = e2e
             else:
                 extra["encode_allgather_end_to_end"] = {"skipped": "needs RCCL (backend nccl on every rank)"}
+            # the fabric roofline of the gather -- the per-link rate is MEASURED on this node
+            # (hipMemcpyPeerAsync from rank 0's device to every other rank's device, one link at a time and all at once)
+            # while the other ranks wait at a host-side barrier; never quoted from the nominal figure alone.
+            wd.arm(args.dist_timeout, "xgmi link probe")
+            extra["allgather_packed"]["roofline"] = xgmi_roofline(args, torch, rank, world, local_rank, rehearse, extra["allgather_packed"])
+            dist.barrier()  # the default (gloo) group: host-side, the GPUs of the waiting ranks stay idle during the probe
         except Exception as e:  # noqa: BLE001 -- a failed collective is reported AND fails the run (rc 4): never a silent success
             extra.setdefault("allgather_packed", {})["error"] = repr(e)[:300]
             extra["collective_error"] = True
             state["rc"] = 4
         wd.disarm()
+
+    if use_dist and not rehearse:
+        # The same concatenation through the C ABI (what a C / Rust host calls): one-shot ncclAllGather and the chunked,
+        # in-place overlap (bitnuc_encode_sharded_allgather_overlapped_dev).  It is an EXTRA block with its own RCCL
+        # communicator: it runs in a thread with a bounded wait so that it can never cost the headline line.
+        if on_gpu_collectives and not args.share_gpu and state.get("rc", 0) == 0:
+            extra["c_abi_allgather"] = c_abi_allgather_block(args, ctx, torch, dist, rank, world, seqs[0], n, state)
+        else:
+            extra["c_abi_allgather"] = {"skipped": "needs RCCL and one GPU per rank"}
 
     if not rehearse and (args.probe or (world == 1 and not args.no_extras)):
         # the step's two access shapes WITHOUT arithmetic, in the same sustained rotation as the timed loop: the
@@ -649,16 +667,87 @@ def run_rank(args, real_stdout, traffic):
         except Exception as e:  # noqa: BLE001
             extra["stream_probe_gb_s"] = {"error": repr(e)[:300]}
     emit(make_line(extra))
+    rc = state.get("rc", 0)
+    if state.get("hung_thread"):
+        os._exit(rc)  # the C-ABI extra block never returned: its communicator cannot be torn down in order
     if ctx:
         ctx.close()
-    rc = state.get("rc", 0)
     if use_dist:
         if probe_thread is not None and probe_thread.is_alive():
             os._exit(rc)  # an RCCL probe that never returned still holds the communicator: do not wait for it again
+        wd.arm(max(args.dist_timeout, 300.0), "final barrier")
+        dist.barrier()  # gloo: the ranks leave together, after rank 0 has timed the CPU baseline and printed the line
+        wd.disarm()
         wd.arm(120.0, "destroy_process_group")
         dist.destroy_process_group()
         wd.disarm()
     return rc
+
+
+def xgmi_roofline(args, torch, rank, world, local_rank, rehearse, ag):
+    """roofline block of the all-gather: bound "xgmi", peak = the MEASURED aggregate rate of the links the gather uses."""
+    nominal_link = 153.6  # GB/s per xGMI link (MI355X_MICROARCH.md / SURVEY section 5), 7 links per GPU
+    if rehearse or world < 2:
+        return {"value": None, "reason": "one rank: nothing crosses the fabric"}
+    if rank != 0:
+        return None  # measured and reported by rank 0
+    if args.share_gpu or torch.cuda.device_count() < world:
+        return {"value": None, "reason": f"{torch.cuda.device_count()} device(s) visible to rank 0 for {world} ranks: the link probe needs the peers' devices in one process"}
+    try:
+        from bitnuc_amd import api
+        peers = [d for d in range(world) if d != local_rank]
+        pr = api.peer_link_probe(local_rank, peers, nbytes=256 << 20, reps=3)
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "reason": "link probe failed: " + repr(e)[:200]}
+    peak = pr["gb_s_all"]
+    ach = ag["gb_s_per_gpu"]
+    return {"bound": "xgmi", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 4) if peak else None,
+            "per_link_measured": pr["gb_s_each"], "links_used": len(peers), "nominal": round(nominal_link * len(peers), 1),
+            "frac_of_nominal": round(ach / (nominal_link * len(peers)), 4),
+            "how": "achieved = bytes received per GPU / all-gather time; peak = hipMemcpyPeerAsync from this GPU to all peers at once (outbound; the fabric is symmetric)"}
+
+
+def c_abi_allgather_block(args, ctx, torch, dist, rank, world, seq, n, state):
+    """bitnuc_comm_init_rank + one-shot and chunked in-place all-gather through the C ABI, timed; bounded wait."""
+    import bitnuc_amd
+    res = {}
+
+    def work():
+        try:
+            uid = [bitnuc_amd.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)  # default (gloo) group
+            comm = bitnuc_amd.Comm(ctx, world, rank, uid[0])
+            n32 = n - n % 32
+            cnt = n32 // 32
+            one = torch.empty(world * cnt, dtype=torch.int64, device=seq.device)
+            two = torch.zeros(world * cnt, dtype=torch.int64, device=seq.device)
+            reps = 3
+            for name, fn, buf in (("one_shot", lambda: comm.encode_sharded_allgather_dev(seq, n32, one), one),
+                                  ("overlap8", lambda: comm.encode_sharded_allgather_overlapped_dev(seq, n32, 8, two), two)):
+                fn()
+                ctx.sync()
+                dist.barrier()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                ctx.sync()
+                dist.barrier()
+                res[name + "_ms"] = round((time.perf_counter() - t) / reps * 1e3, 3)
+            res["overlap_equals_one_shot"] = bool(torch.equal(one, two))
+            res["gb_s_per_gpu_one_shot"] = round(cnt * 8 * (world - 1) / (res["one_shot_ms"] * 1e-3) / 1e9, 2) if world > 1 else None
+            comm.close()
+            res["note"] = ("encode of this rank's shard + concatenation through the C ABI: ncclAllGather in place (one_shot) and 8 pieces moved in place by "
+                           "grouped ncclSend / ncclRecv on a second stream while the next piece is encoded (overlap8); includes the host barriers around the loop")
+        except Exception as e:  # noqa: BLE001
+            res["error"] = repr(e)[:300]
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(min(args.dist_timeout, 240.0))
+    if th.is_alive():
+        state["hung_thread"] = True
+        return {"stalled": True, "note": "the C-ABI extra block did not finish within its bounded wait; the headline and the torch.distributed blocks above are unaffected"}
+    return res
 
 
 def timed_median(torch, stream, fn, reps=10):
@@ -827,11 +916,12 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
                                        note="plan = word offsets + one byte offset per 64-word tile + one pad byte per word, from one pass over the offsets table "
                                             "(plan_build_ms: host-synchronous, includes the word-offsets scan); the same plan serves the later decode")
     plan.close()
-    # (b) from the two offset tables alone, nothing kept between calls (tile-record pre-kernel inside every call)
+    # (b) from the two offset tables alone, nothing kept between calls: every call emits the plan (pad bytes, tile bases) into
+    # context scratch with one asynchronous pass over both tables, then runs the plan kernel -- both launches are inside the time
     backs[0].zero_()
     ms_e = timed_sustained(torch, stream, lambda i: ctx.encode_batch_dev(seqs[0], roff, rwo, rcount, rtotal, wsets[i & 1]))
     ms_d = timed_sustained(torch, stream, lambda i: ctx.decode_batch_dev(wsets[i & 1], rwo, roff, rcount, rtotal, bsets[i & 1]))
-    extra["reads_batch_tables"] = batch_block(ms_e, ms_d, "the same batch through encode_batch_dev / decode_batch_dev (offset tables only, no plan: every call runs the tile-record pre-kernel)",
+    extra["reads_batch_tables"] = batch_block(ms_e, ms_d, "the same batch through encode_batch_dev / decode_batch_dev (offset tables only, nothing kept between calls: every call runs plan_emit_kernel + the plan kernel)",
                                               timing="sustained", roundtrip_ok=bool(torch.equal(seqs[0][:rb], backs[0][:rb])),
                                               tables_bytes_per_launch=16 * (rcount + 1),
                                               encode_gb_s_with_tables=round((alg + 16 * (rcount + 1)) / (ms_e * 1e-3) / 1e9, 1),
@@ -937,18 +1027,28 @@ def host_path_block(ctx, torch):
     te, td = [], []
     words = np.zeros((n + 31) // 32, dtype=np.uint64)  # caller-owned and already touched, as in a pipeline that reuses its
     back = np.zeros(n, dtype=np.uint8)                 # buffers (a fresh output would be timed by its page faults)
-    for _ in range(4):
+    ok = True
+    for it in range(4):
+        if it:  # identical iterations over the same buffers would hide a stale chunk -- other data each time, every result checked
+            seq[it * 1000003::7] = seq[5::7][: len(seq[it * 1000003::7])]
+        words.fill(0)
+        back.fill(0)
         t = time.perf_counter()
         ctx.encode_into(seq, words)
         te.append(time.perf_counter() - t)
         t = time.perf_counter()
         ctx.decode_into(words, n, back)
         td.append(time.perf_counter() - t)
+        ok = ok and bool(np.array_equal(seq, back))
     te, td = te[1:], td[1:]
     ctx.set_variant("force_gpu", 1)
+    try:  # how the staging pools were sized, and from what (cores visible vs the cgroup quota, measured copy rates)
+        out["pipe"] = dict(ctx.host_pipe_info(), chunk_mb_env=os.environ.get("BITNUC_PIPE_CHUNK_MB"), host_threads_env=os.environ.get("BITNUC_HOST_THREADS"))
+    except Exception as e:  # noqa: BLE001
+        out["pipe"] = {"error": repr(e)[:200]}
     out.update({"bases": n, "encode_gbases_s": round(n / min(te) / 1e9, 1), "decode_gbases_s": round(n / min(td) / 1e9, 1),
                 "encode_gb_s_moved": round(1.25 * n / min(te) / 1e9, 1), "decode_gb_s_moved": round(1.25 * n / min(td) / 1e9, 1),
-                "roundtrip_ok": bool(np.array_equal(seq, back)),
+                "roundtrip_ok": ok,
                 "encode_frac_of_pinned_h2d": round(n / min(te) / 1e9 / out["pinned_h2d_gb_s"], 3),
                 "decode_frac_of_pinned_d2h": round(n / min(td) / 1e9 / out["pinned_d2h_gb_s"], 3),
                 "note": "bitnuc_encode / bitnuc_decode on pageable host buffers: staged through pinned double buffers, H2D / kernel / D2H overlapped; PCIe-bound, never the reported value"})

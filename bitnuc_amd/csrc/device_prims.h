@@ -89,8 +89,10 @@ __device__ __forceinline__ unsigned wave_in_block() { return (unsigned)__builtin
 // contribution.  Nothing else is communicated between workgroups (no plain data), which is what a fence would be for.
 template <class T> __device__ __forceinline__ void add_performed(T *acc, T v) {
     const T prev = atomicAdd(acc, v); // returning form: the value can only arrive once the add has been performed
-    if constexpr (sizeof(T) == 8) asm volatile("" ::"v"((uint32_t)prev), "v"((uint32_t)(prev >> 32)));
-    else asm volatile("" ::"v"(prev));
+    // consuming the returned value forces the wait for it; the "memory" clobber keeps the compiler from moving any other memory
+    // access (the ticket RMW in particular) across this point
+    if constexpr (sizeof(T) == 8) asm volatile("" ::"v"((uint32_t)prev), "v"((uint32_t)(prev >> 32)) : "memory");
+    else asm volatile("" ::"v"(prev) : "memory");
 }
 __device__ __forceinline__ bool draw_last_ticket(unsigned *ticket) {
     if (atomicAdd(ticket, 1u) != gridDim.x - 1) return false;

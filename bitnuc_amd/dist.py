@@ -56,29 +56,50 @@ def encode_sharded(encode_fn, seq_shard, n_total, group=None):
     return allgather_packed(words, counts, group)
 
 
-def encode_allgather_overlapped(encode_chunk, shard_words, n_chunks, like, group=None):
-    """BASELINE config 4 end to end with chunked overlap (SURVEY 8e iii): the shard is encoded in
-    `n_chunks` pieces; as soon as piece c is enqueued its all-gather is issued asynchronously, so
-    the fabric moves piece c while the GPU encodes piece c+1 (with backend "nccl" torch runs the
-    collective on its own stream, ordered after the encode by an event).
+def encode_allgather_overlapped(encode_chunk, shard_words, n_chunks, like, group=None, out=None):
+    """BASELINE config 4 end to end with chunked overlap (SURVEY 8e iii), IN PLACE: the shard is encoded in `n_chunks`
+    pieces straight into this rank's slot of the output; as soon as piece c is enqueued it is exchanged with every peer
+    by one batch of point-to-point operations (grouped ncclSend / ncclRecv under backend "nccl": every peer's piece lands
+    directly in out[peer * shard_words + w0 ...], no staging tensor, no strided copy -- and on MI355X's full mesh of
+    point-to-point xGMI links all world-1 links of a GPU carry data at once), while the GPU encodes piece c+1.
 
-    encode_chunk(w0, w1) -> 1-D int64 tensor holding words [w0, w1) of this rank's shard (on the
-    GPU: a view of the shard's word buffer after Context.encode_dev of bases [32*w0, 32*w1) on the
-    current stream).  Every rank must have the same `shard_words`.  `like` gives dtype/device.
-    Returns the concatenation [world * shard_words], bit-identical to allgather_packed(words)."""
+    encode_chunk(w0, w1, dst): write words [w0, w1) of this rank's shard into `dst` (a contiguous 1-D view of the output;
+    on the GPU: Context.encode_dev of bases [32*w0, 32*w1) on the current stream).  A two-argument encode_chunk(w0, w1)
+    that returns the words is still accepted (one device copy per piece).  Every rank must have the same `shard_words`.
+    `like` gives dtype / device; `out` (world * shard_words) may be passed to reuse a buffer.
+    Returns the concatenation [world * shard_words], bit-identical to allgather_packed(words).
+    C / Rust hosts have the same thing as bitnuc_encode_sharded_allgather_overlapped_dev (include/bitnuc_hip.h)."""
+    import inspect
     world = dist.get_world_size(group)
-    bounds = [shard_words * c // n_chunks for c in range(n_chunks + 1)]
-    pieces, works = [], []
+    rank = dist.get_rank(group)
+    if out is None:
+        out = torch.empty(world * shard_words, dtype=like.dtype, device=like.device)
+    assert out.numel() == world * shard_words and out.is_contiguous()
+    grid = out.view(world, shard_words)
+    try:
+        into = len(inspect.signature(encode_chunk).parameters) >= 3
+    except (TypeError, ValueError):
+        into = False
+    peers = [dist.get_global_rank(group, s) if group is not None else s for s in range(world)]
+    works = []
     for c in range(n_chunks):
-        w0, w1 = bounds[c], bounds[c + 1]
+        w0, w1 = shard_words * c // n_chunks, shard_words * (c + 1) // n_chunks
         if w1 == w0:
             continue
-        local = encode_chunk(w0, w1)
-        tmp = torch.empty(world * (w1 - w0), dtype=like.dtype, device=like.device)  # [world][w1-w0]
-        works.append(dist.all_gather_into_tensor(tmp, local.contiguous(), group=group, async_op=True))
-        pieces.append((w0, w1, tmp))
-    out = torch.empty(world, shard_words, dtype=like.dtype, device=like.device)
-    for work, (w0, w1, tmp) in zip(works, pieces):
-        work.wait()  # nccl: orders the current stream after the collective; gloo: blocks
-        out[:, w0:w1].copy_(tmp.view(world, w1 - w0))
-    return out.reshape(world * shard_words)
+        dst = grid[rank, w0:w1]
+        if into:
+            encode_chunk(w0, w1, dst)
+        else:
+            local = encode_chunk(w0, w1)
+            if local.data_ptr() != dst.data_ptr():
+                dst.copy_(local)
+        ops = []
+        for s in range(world):
+            if s != rank:
+                ops.append(dist.P2POp(dist.isend, dst, peers[s], group))
+                ops.append(dist.P2POp(dist.irecv, grid[s, w0:w1], peers[s], group))
+        if ops:
+            works.extend(dist.batch_isend_irecv(ops))
+    for work in works:
+        work.wait()  # nccl: orders the current stream after the exchange; gloo: blocks
+    return out

@@ -63,3 +63,31 @@ def test_fails_loudly_without_gpu():
     import bitnuc_amd
     with pytest.raises(bitnuc_amd.BackendError):
         bitnuc_amd.Context(0)
+
+
+def _hip_runtime_choice(env_extra, preimport_torch=False):
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, json; sys.path.insert(0, %r)\n" % ROOT
+            + ("import torch\n" if preimport_torch else "")
+            + "from bitnuc_amd import _lib\n_lib.load()\nprint(json.dumps(_lib.hip_runtime_choice))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("BITNUC_NO_TORCH_HIP_PRELOAD", "BITNUC_LOG")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+
+def test_hip_runtime_preload_is_logged_and_can_be_opted_out():
+    """load() preloads torch's bundled libamdhip64.so so that `import bitnuc_amd; import torch` share ONE HIP
+    runtime; a plain C-ABI consumer opts out with BITNUC_NO_TORCH_HIP_PRELOAD, a process that already imported torch is left
+    alone, and BITNUC_LOG=1 says on stderr which runtime was chosen."""
+    (reason, path), err = _hip_runtime_choice({"BITNUC_NO_TORCH_HIP_PRELOAD": "1", "BITNUC_LOG": "1"})
+    assert "BITNUC_NO_TORCH_HIP_PRELOAD" in reason and path is None
+    assert "bitnuc_amd: HIP runtime: system runtime" in err
+    (reason, path), err = _hip_runtime_choice({}, preimport_torch=True)
+    assert "torch already imported" in reason and path is None and "bitnuc_amd:" not in err
+    (reason, path), err = _hip_runtime_choice({"BITNUC_LOG": "1"})
+    assert ("preloaded torch's bundled runtime" in reason and path and path.endswith("libamdhip64.so")) or "system runtime" in reason
+    assert "bitnuc_amd: HIP runtime:" in err

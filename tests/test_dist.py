@@ -63,7 +63,7 @@ def test_two_rank_sharded_encode_equals_single(n):
     assert res == {0: True, 1: True}
 
 
-def _worker_overlap(rank, world, port, shard_words, n_chunks, q):
+def _worker_overlap(rank, world, port, shard_words, n_chunks, in_place, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -73,28 +73,41 @@ def _worker_overlap(rank, world, port, shard_words, n_chunks, q):
         n = 32 * shard_words
         shard = oracle_py.nucgen(n, 0xB17C0DE, first=rank * n)
         words = torch.zeros(shard_words, dtype=torch.int64)
+        slots = []
 
-        def enc(w0, w1):  # the per-rank encoder is injected: the oracle here, Context.encode_dev on a GPU
+        def enc2(w0, w1):  # legacy form: returns the words (one copy per piece into the output)
             words[w0:w1] = torch.from_numpy(oracle_py.encode(shard[32 * w0:32 * w1]).view(np.int64).copy())
             return words[w0:w1]
-        full = encode_allgather_overlapped(enc, shard_words, n_chunks, words)
+
+        def enc3(w0, w1, dst):  # in-place form: the per-rank encoder writes straight into its slot of the output
+            dst.copy_(torch.from_numpy(oracle_py.encode(shard[32 * w0:32 * w1]).view(np.int64).copy()))
+            words[w0:w1] = dst
+            slots.append(dst.data_ptr())
+        out = torch.full((world * shard_words,), -1, dtype=torch.int64) if in_place else None
+        full = encode_allgather_overlapped(enc3 if in_place else enc2, shard_words, n_chunks, words, out=out)
         expect = oracle_py.encode(oracle_py.nucgen(world * n, 0xB17C0DE))
-        same_as_plain = torch.equal(full, allgather_packed(words))
-        q.put((rank, bool(np.array_equal(full.numpy().view(np.uint64), expect)) and same_as_plain))
+        ok = bool(np.array_equal(full.numpy().view(np.uint64), expect)) and torch.equal(full, allgather_packed(words))
+        if in_place:  # the result IS the caller's buffer and every piece was encoded inside this rank's slot of it
+            lo = out.data_ptr() + 8 * rank * shard_words
+            ok = ok and full.data_ptr() == out.data_ptr() and all(lo <= p < lo + 8 * shard_words for p in slots)
+        q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard_words,n_chunks", [(1000, 8), (7, 8), (64, 1), (1001, 3)])
-def test_two_rank_overlapped_allgather_equals_single(shard_words, n_chunks):
+@pytest.mark.parametrize("world,shard_words,n_chunks,in_place", [(2, 1000, 8, True), (2, 7, 8, False), (2, 64, 1, True), (2, 1001, 3, False),
+                                                                 (3, 1001, 5, True), (4, 500, 8, True)])
+def test_overlapped_allgather_in_place_equals_single(world, shard_words, n_chunks, in_place):
+    """The chunked, in-place exchange (batched point-to-point: what RCCL runs as grouped ncclSend / ncclRecv) over gloo with 2, 3
+    and 4 ranks == the plain all-gather == the oracle's encode of the whole sequence."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() + shard_words) % 2000
-    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, shard_words, n_chunks, q)) for r in range(2)]
+    port = 31500 + (os.getpid() + shard_words + 7 * world) % 2000
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, shard_words, n_chunks, in_place, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    res = dict(q.get(timeout=10) for _ in range(2))
-    assert res == {0: True, 1: True}
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res == {r: True for r in range(world)}
