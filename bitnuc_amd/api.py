@@ -483,13 +483,12 @@ class Context:
     def host_pipe_info(self):
         """Configuration and creation-time measurements of the pipelined host-pointer path (creates it if needed)."""
         names = ["cores_visible", "cores_quota", "cores_usable", "chunk_bases", "depth", "encode_stage_in_threads", "encode_hand_back_threads",
-                 "decode_stage_in_threads", "decode_hand_back_threads", "pinned_h2d_gb_s", "pinned_d2h_gb_s", "stage_in_memcpy_gb_s",
-                 "hand_back_memcpy_gb_s", "heavy_side_thread_cap", "calibrated"]
+                 "decode_stage_in_threads", "decode_hand_back_threads", "heavy_side_thread_cap"]
         out = (C.c_double * len(names))()
         err = L.BitnucErr()
         if self._lib.bitnuc_host_pipe_info(self._h, out, len(names), C.byref(err)) != L.OK:
             _raise(err)
-        return {k: (round(v, 1) if "gb_s" in k else int(v)) for k, v in zip(names, out)}
+        return {k: int(v) for k, v in zip(names, out)}
 
     def stream_probe_dev(self, mode, d_src, d_dst, nbytes):
         self._call_dev(self._lib.bitnuc_stream_probe_dev, int(mode), _dev_ptr(d_src), _dev_ptr(d_dst), int(nbytes))

@@ -355,9 +355,21 @@ __device__ __forceinline__ void zero_bytes(uint8_t *__restrict__ p, unsigned lon
     if (n & 1) p[k] = 0;
 }
 
+// A workgroup owns kScanTile consecutive sequences and with them the contiguous pad bytes P[W0 + 1 .. W1].  When that range fits
+// kEmitLds bytes (reads: 2048 x 5 words = 10 KiB) it is ASSEMBLED IN LDS -- zeroed, the pad bytes and the tile bases scattered
+// into it with LDS stores -- and leaves as coalesced 16-byte stores; a per-thread global scatter of single bytes at a 40-byte
+// stride cost 3 partial-line writes per sequence (first version of this kernel: 33-39 us for 6.67 M reads, now measured in
+// profiles/r03_plan_emit.txt).  Longer ranges (sequences of hundreds of bases and more: far fewer table entries per byte) take
+// the per-thread path below.
+constexpr unsigned kEmitLds = 16 * 1024;
+constexpr unsigned kEmitLdsTiles = kEmitLds / 64 + 2;
+
 __global__ void __launch_bounds__(kBlock)
 plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets, unsigned long long count,
                  uint8_t *__restrict__ P, unsigned long long *__restrict__ tile_base, unsigned long long *__restrict__ bounds) {
+    __shared__ __attribute__((aligned(16))) uint8_t pads[kEmitLds + 16];
+    __shared__ unsigned long long tbs[kEmitLdsTiles];
+    __shared__ unsigned long long range[2];
     const unsigned lane = threadIdx.x & 63;
     const unsigned long long i = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) * kScanPer;
     unsigned long long o[kScanPer + 1], w[kScanPer + 1];
@@ -365,7 +377,33 @@ plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned 
     load_offsets9(offsets, count, ic, o);
     load_offsets9(word_offsets, count, ic, w);
     if (i == 0) { bounds[0] = o[0]; bounds[1] = offsets[count]; }
-    // this thread's pad bytes: P[w[0] + 1 .. w[8]]
+    if (threadIdx.x == 0) range[0] = w[0];
+    if (threadIdx.x == kBlock - 1) range[1] = w[kScanPer];
+    __syncthreads();
+    const unsigned long long W0 = range[0], R = range[1] - W0; // this workgroup's pad bytes: P[W0 + 1 .. W0 + R]
+    if (R <= kEmitLds) { // workgroup-uniform
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (unsigned k = 16u * threadIdx.x; k < (unsigned)R; k += 16u * kBlock) *reinterpret_cast<u32x4 *>(pads + k) = z;
+        __syncthreads();
+        const unsigned long long T0 = (W0 + 63) >> 6; // first tile whose first word lies in [W0, W0 + R)
+#pragma unroll
+        for (int j = 0; j < kScanPer; ++j) {
+            const unsigned long long a = w[j], b = w[j + 1];
+            if (ic + j < count && b > a) {
+                pads[(unsigned)(b - W0 - 1)] = (uint8_t)(32ull * (b - a) - (o[j + 1] - o[j]));
+                for (unsigned long long t = (a + 63) >> 6; t < ((b + 63) >> 6); ++t) tbs[(unsigned)(t - T0)] = o[j] + (((t << 6) - a) << 5);
+            }
+        }
+        __syncthreads();
+        uint8_t *dst = P + W0 + 1;
+        const unsigned body = (unsigned)R & ~15u;
+        for (unsigned k = 16u * threadIdx.x; k < body; k += 16u * kBlock) *reinterpret_cast<u32x4_u *>(dst + k) = *reinterpret_cast<const u32x4 *>(pads + k);
+        if (threadIdx.x < (unsigned)R - body) dst[body + threadIdx.x] = pads[body + threadIdx.x];
+        const unsigned nt = (unsigned)(((W0 + R + 63) >> 6) - T0);
+        for (unsigned k = threadIdx.x; k < nt; k += kBlock) tile_base[T0 + k] = tbs[k];
+        return;
+    }
+    // long ranges: every thread zeroes and fills its own pad bytes P[w[0] + 1 .. w[8]] in global memory
     const unsigned long long len = w[kScanPer] - w[0];
     uint8_t *mine = P + w[0] + 1;
     const bool coop = len > kEmitCoop;
@@ -375,8 +413,8 @@ plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned 
         while (m) {
             const unsigned l = (unsigned)__builtin_ctzll(m);
             m &= m - 1;
-            const unsigned long long W0 = read_lane_u64(w[0], l), L = read_lane_u64(len, l);
-            uint8_t *q = P + W0 + 1;
+            const unsigned long long W = read_lane_u64(w[0], l), L = read_lane_u64(len, l);
+            uint8_t *q = P + W + 1;
             const unsigned long long body = L & ~15ull;
             const u32x4 z = {0u, 0u, 0u, 0u};
             for (unsigned long long k = 16ull * lane; k < body; k += 1024) *reinterpret_cast<u32x4_u *>(q + k) = z;

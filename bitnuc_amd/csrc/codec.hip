@@ -233,16 +233,17 @@ int codec_ballot_variant() { return kEvidenceBuild ? kBallotVariant : -1; }
 // context's stream; a second, asynchronous pool hands chunk c-2 back to the caller meanwhile.  Events order the three
 // streams and guard buffer reuse; the host waits only when a pinned buffer is about to be overwritten.
 //
-// How many threads copy is decided per direction when the pipe is created, from measurements on this host: the pinned
-// H2D / D2H rates of the DMA engines, and the rate of the pool's pageable <-> pinned memcpy at 1, 2, 3, ... threads.  The
-// HEAVY side (stage-in for encode: 1 B per base; hand-back for decode: 1 B per base) gets the smallest thread count whose
-// copy rate exceeds the DMA rate by 30 %; the light side (0.25 B per base) gets 1-2 threads; together they stay inside the
-// CPUs this process may use (affinity mask AND cgroup quota: cores_usable()).  Round 2 sized the hand-back pool as
-// threads/2+1 = 4 workers: on a 16-core quota that moved 40-45 GB/s against a 57 GB/s D2H engine, decode 0.78 of the pinned rate.
+// How many threads copy is decided per direction when the pipe is created.  The HEAVY side (stage-in for encode: 1 B per base;
+// hand-back for decode: 1 B per base) gets 8 threads, the light side (0.25 B per base) 2, both capped by the CPUs this process
+// may use (affinity mask AND cgroup quota: cores_usable() -- a 16-core quota on a 256-thread host shows 256 CPUs in its mask).
+// Measured on the GPU box (tools/host_path_r03.py, profiles/r03_host_path.txt; 10^9 bases, pinned engines 56 GB/s each way and
+// full duplex): 6 / 8 / 11 heavy threads give encode 51.7 / 52.0 / 52.0 and decode 49.3 / 49.5 / 49.9 Gbases/s; round 2's
+// hand-back pool of threads/2+1 = 4 workers gave decode 39-45.  A creation-time calibration (smallest thread count whose memcpy
+// of a 32 MiB probe buffer beats the DMA rate by 30 %) was tried and REMOVED: the probe buffer stays in the host's L3, 2-3
+// threads look sufficient (84-88 GB/s), and the real pipeline, whose sources stream from DRAM, then ran decode at 39 Gbases/s.
 constexpr int kPipeDepth = 3; // buffer sets in flight: the host hands chunk c-2 to the caller while chunk c-1 is on the DMA engines and chunk c is staged
 constexpr size_t kPipeChunkDefault = (size_t)32 << 20; // bases per chunk; BITNUC_PIPE_CHUNK_MB overrides
 constexpr size_t kPipeMin = (size_t)8 << 20;           // inputs below this stay on the simple path (latency, not bandwidth, matters there)
-constexpr int kPipeRates = bitnuc_host::kPoolMaxThreads;
 
 struct HostPipe {
     hipStream_t s_in = nullptr, s_out = nullptr;
@@ -254,66 +255,10 @@ struct HostPipe {
     size_t chunk = kPipeChunkDefault; // bases per chunk (a multiple of 32)
     int enc_in = 1, enc_out = 1, dec_in = 1, dec_out = 1; // copy threads per direction and side
     int cores_visible = 1, cores_quota = 0, cores_usable = 1, heavy_cap = 1;
-    double h2d_gbs = 0, d2h_gbs = 0;                             // pinned hipMemcpyAsync rates measured at creation
-    double in_gbs[kPipeRates + 1] = {}, out_gbs[kPipeRates + 1] = {}; // pool memcpy rates at k threads: pageable -> pinned, pinned -> pageable
-    bool calibrated = false;
     bool ok = false;
 };
 
 namespace {
-
-double wall_s() {
-    struct timespec t;
-    clock_gettime(CLOCK_MONOTONIC, &t);
-    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
-}
-
-// thread counts from measurements (see above).  Leaves the defaults (heavy = min(8, cap), light) when anything fails.
-void pipe_calibrate(bitnuc_ctx *c, HostPipe *p) {
-    const size_t n = p->chunk < ((size_t)32 << 20) ? p->chunk : ((size_t)32 << 20); // bytes per probe copy
-    uint8_t *page = static_cast<uint8_t *>(malloc(n));
-    if (!page) return;
-    memset(page, 'A', n); // touched: the probes time copies, not page faults
-    auto dma = [&](bool h2d) {
-        double best = 0;
-        for (int rep = 0; rep < 3; ++rep) {
-            const double t0 = wall_s();
-            hipError_t rc = h2d ? hipMemcpyAsync(p->dev_a[0], p->pin_a[0], n, hipMemcpyHostToDevice, p->s_in)
-                                : hipMemcpyAsync(p->pin_a[0], p->dev_a[0], n, hipMemcpyDeviceToHost, p->s_out);
-            if (rc == hipSuccess) rc = hipStreamSynchronize(h2d ? p->s_in : p->s_out);
-            if (rc != hipSuccess) return 0.0;
-            const double g = (double)n / (wall_s() - t0) / 1e9;
-            if (rep > 0 && g > best) best = g;
-        }
-        return best;
-    };
-    p->h2d_gbs = dma(true);
-    p->d2h_gbs = dma(false);
-    (void)c;
-    if (p->h2d_gbs <= 0 || p->d2h_gbs <= 0) { free(page); return; }
-    auto pick = [&](bool in, double need) {
-        int best_k = 1;
-        double best = 0;
-        for (int k = 1; k <= p->heavy_cap; ++k) {
-            double g = 0;
-            for (int rep = 0; rep < 2; ++rep) {
-                const double t0 = wall_s();
-                if (in) p->pool->copy(p->pin_a[1], page, n, k);
-                else { p->pool_out->start(page, p->pin_a[1], n, k); p->pool_out->wait(); }
-                const double r = (double)n / (wall_s() - t0) / 1e9;
-                if (r > g) g = r;
-            }
-            (in ? p->in_gbs : p->out_gbs)[k] = g;
-            if (g > best * 1.03) { best = g; best_k = k; } // more threads only for a real gain
-            if (g >= need) return k;
-        }
-        return best_k;
-    };
-    p->enc_in = pick(true, 1.3 * p->h2d_gbs);
-    p->dec_out = pick(false, 1.3 * p->d2h_gbs);
-    p->calibrated = true;
-    free(page);
-}
 
 void pipe_free(HostPipe *p) {
     if (!p) return;
@@ -367,13 +312,12 @@ int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err) {
     const int forced = bitnuc_host::env_threads("BITNUC_HOST_THREADS"); // the heavy side's thread count, as given
     if (forced) cap = forced < bitnuc_host::kPoolMaxThreads ? forced : bitnuc_host::kPoolMaxThreads - 1;
     p->heavy_cap = cap;
-    const int most = cap > light ? cap : light;
+    const int heavy = forced ? cap : (cap < 8 ? cap : 8);
+    const int most = heavy > light ? heavy : light;
     p->pool = new CopyPool(most);         // the caller + most - 1 workers
     p->pool_out = new CopyPool(most + 1); // most workers (the caller's slice index is unused in asynchronous jobs)
-    p->enc_in = p->dec_out = cap < 8 ? cap : 8;
-    p->enc_out = p->dec_in = light;
-    const char *cal = getenv("BITNUC_PIPE_CALIBRATE");
-    if (!forced && !(cal && atoi(cal) == 0)) pipe_calibrate(c, p);
+    p->enc_in = p->dec_out = heavy;
+    p->enc_out = p->dec_in = light < most ? light : most;
     p->ok = true;
     c->pipe = p;
     *out = p;
@@ -515,10 +459,9 @@ int encode_dev_at(bitnuc_ctx *c, const uint8_t *d_seq, size_t len, uint64_t *d_o
 // =====================================================================================
 extern "C" {
 
-// Diagnostic (bench.py's host_path block): how the pipelined host-pointer path of this context is configured and what it
-// measured when it was created.  Creates the pipe if this context has none yet.  out[0..n): cores_visible, cores_quota
-// (0 = none), cores_usable, chunk_bases, depth, enc_in, enc_out, dec_in, dec_out (copy threads), h2d_gbs, d2h_gbs (pinned
-// hipMemcpyAsync), stage-in GB/s at enc_in threads, hand-back GB/s at dec_out threads, heavy_cap, calibrated (0 / 1).
+// Diagnostic (bench.py's host_path block): how the pipelined host-pointer path of this context is configured.  Creates the pipe if
+// this context has none yet.  out[0..n): cores_visible, cores_quota (0 = none), cores_usable, chunk_bases, depth, enc_in, enc_out,
+// dec_in, dec_out (copy threads), heavy_cap.
 int bitnuc_host_pipe_info(bitnuc_ctx *c, double *out, int n, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
@@ -526,10 +469,9 @@ int bitnuc_host_pipe_info(bitnuc_ctx *c, double *out, int n, bitnuc_err *err) {
     DeviceGuard g(c->device);
     HostPipe *p;
     if (int st = pipe_get(c, &p, err)) return st;
-    const double v[15] = {(double)p->cores_visible, (double)p->cores_quota, (double)p->cores_usable, (double)p->chunk, (double)kPipeDepth,
-                          (double)p->enc_in, (double)p->enc_out, (double)p->dec_in, (double)p->dec_out, p->h2d_gbs, p->d2h_gbs,
-                          p->in_gbs[p->enc_in], p->out_gbs[p->dec_out], (double)p->heavy_cap, p->calibrated ? 1.0 : 0.0};
-    for (int i = 0; i < n; ++i) out[i] = i < 15 ? v[i] : 0.0;
+    const double v[10] = {(double)p->cores_visible, (double)p->cores_quota, (double)p->cores_usable, (double)p->chunk, (double)kPipeDepth,
+                          (double)p->enc_in, (double)p->enc_out, (double)p->dec_in, (double)p->dec_out, (double)p->heavy_cap};
+    for (int i = 0; i < n; ++i) out[i] = i < 10 ? v[i] : 0.0;
     return BITNUC_OK;
 }
 
@@ -600,6 +542,21 @@ int bitnuc_stream_probe_dev(bitnuc_ctx *c, int mode, const void *d_src, void *d_
         probe_dec_shape_kernel<2, 256, false, true><<<g4, 256, 0, c->stream>>>(static_cast<const uint32_t *>(d_src), dst, n16);
         break;
     }
+#ifdef BITNUC_SWEEP_VARIANTS
+    case 5: { // the every-window kernel's shape: `bytes` of ASCII-side input, 8 x as many bytes written.  bit 4: nt stores, bit 5: interleaved map, bits 6-7: rounds per trip 1 / 2 / 4
+        if (!d_src || !d_dst || !aligned16(d_src) || !aligned16(d_dst)) return fail(err, BITNUC_UNSUPPORTED);
+        const unsigned long long rounds = (bytes >> 10) & ~3ull;
+        const int U = 1 << ((mode >> 6) & 3);
+        const unsigned g5 = grid_for(c, (rounds + (unsigned long long)U * 4 - 1) / ((unsigned long long)U * 4));
+#define WIN(NS, UU, MP) probe_win_shape_kernel<NS, UU, MP><<<g5, kBlock, 0, c->stream>>>(src, dst, rounds)
+#define WIN_U(NS, MP) do { if (U == 1) WIN(NS, 1, MP); else if (U == 2) WIN(NS, 2, MP); else WIN(NS, 4, MP); } while (0)
+        if (mode & 32) { if (nts) WIN_U(true, 1); else WIN_U(false, 1); }
+        else { if (nts) WIN_U(true, 0); else WIN_U(false, 0); }
+#undef WIN_U
+#undef WIN
+        break;
+    }
+#endif
     default:
         return fail(err, BITNUC_UNSUPPORTED);
     }

@@ -477,4 +477,36 @@ probe_dec_shape_kernel(const uint32_t *__restrict__ src, u32x4 *__restrict__ dst
     }
 }
 
+#ifdef BITNUC_SWEEP_VARIANTS
+// The every-window kernel's access shape with no arithmetic (tools/ab_window_shape.py): a wave reads 1 KiB and writes 8 KiB per
+// round.  MAP 0: the wave's eight 1 KiB stores are consecutive (kmer_slide2_kernel); MAP 1: the four waves of a workgroup
+// interleave their stores KiB by KiB inside the workgroup's 32 KiB block (what probe_fill_kernel does at 4 KiB).
+template <bool NTST, int U, int MAP>
+__global__ void __launch_bounds__(kBlock)
+probe_win_shape_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, unsigned long long rounds) {
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (kBlock / 64) + wv;
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * (kBlock / 64);
+    for (unsigned long long r0 = wave * U; r0 < rounds; r0 += nwaves * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + ((r0 + u < rounds ? r0 + u : rounds - 1) << 6) + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r0 + u >= rounds) break;
+            u32x4 *base;
+            unsigned step;
+            if constexpr (MAP == 0) { base = dst + ((r0 + u) << 9) + lane; step = 64; }                     // 8 consecutive KiB
+            else { base = dst + (((r0 + u) & ~3ull) << 9) + (((r0 + u) & 3ull) << 6) + lane; step = 256; } // KiB (r & 3) + 4 j of the 4-round block
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u32x4 t = v[u];
+                t.x += (uint32_t)i;
+                if constexpr (NTST) __builtin_nontemporal_store(t, base + step * i); else base[step * i] = t;
+            }
+        }
+    }
+}
+#endif
+
 } // namespace bitnuc_dev

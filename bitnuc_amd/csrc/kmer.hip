@@ -42,11 +42,12 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
     if (stride == 1 && done == 0 && c->batch_slide && c->slide_impl == 1 && aligned16(kmers) && aligned16(out) && count - 1 + k >= 1056) {
         // every window of a sequence (src/lib.rs:170-173): line-aligned rounds of 1024 windows, computed where they are stored
         const unsigned long long rounds = (count - 1 + k - 32) >> 10; // round r reads bytes [1024 r, 1024 r + 1056)
-        const int U = c->slide_rounds == 2 || c->slide_rounds == 4 ? c->slide_rounds : 1;
+        const int U = kEvidenceBuild ? c->slide2_rounds : 4; // the shipped form: 4 rounds per trip (profiles/r03_ab_windows.txt)
         const unsigned grid = grid_for(c, (rounds + (unsigned long long)U * (kBlock / 64) - 1) / ((unsigned long long)U * (kBlock / 64)));
         const bool nts = (c->dense_policy & 2) != 0;
 #define SLIDE2(NT, UU) kmer_slide2_kernel<NT, UU><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot)
-        if (U == 1) { if (nts) SLIDE2(true, 1); else SLIDE2(false, 1); }
+        if constexpr (!kEvidenceBuild) { SLIDE2(true, 4); }
+        else if (U == 1) { if (nts) SLIDE2(true, 1); else SLIDE2(false, 1); }
         else if (U == 2) { if (nts) SLIDE2(true, 2); else SLIDE2(false, 2); }
         else { if (nts) SLIDE2(true, 4); else SLIDE2(false, 4); }
 #undef SLIDE2

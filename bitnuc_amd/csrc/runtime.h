@@ -63,6 +63,7 @@ struct bitnuc_ctx {
     int grid_mult = 0;                   // see grid_for()
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int slide_rounds = 1;                // kmer_slide_kernel: consecutive rounds per wave trip (1, 2 or 4)
+    int slide2_rounds = 4;               // kmer_slide2_kernel: consecutive 1 KiB rounds per wave trip (evidence build: 1, 2 or 4; tools/ab_r03.py)
     int slide_impl = 1;                  // stride-1 windows: 1 = line-aligned rounds of 1024 windows (kmer_slide2_kernel), 0 = rounds of 992 (kmer_slide_kernel)
     int batch_slide = 1;                 // stride 1 (every window of a sequence), 2, 4, 8, 16 batches use the sliding kernels
     int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores

@@ -306,7 +306,8 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "plan_enc_abl")) { prev = c->plan_enc_abl; if (value >= 0 && !kEvidenceBuild && value != 0) return -2; if (value >= 0 && value <= 7) c->plan_enc_abl = value; }
     else if (!strcmp(key, "plan_enc_block")) { prev = c->plan_enc_block; if (value == 64 || value == 128 || value == 256) c->plan_enc_block = value; }
     else if (!strcmp(key, "plan_enc_tiles")) { prev = c->plan_enc_tiles; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->plan_enc_tiles = value; }
-    else if (!strcmp(key, "slide_rounds")) { prev = c->slide_rounds; if (value == 8 && !kEvidenceBuild) return -2; if (value == 1 || value == 2 || value == 4 || value == 8) c->slide_rounds = value; }
+    else if (!strcmp(key, "slide_rounds")) { prev = c->slide_rounds; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4 || value == 8) c->slide_rounds = value; }
+    else if (!strcmp(key, "slide2_rounds")) { prev = c->slide2_rounds; if (value >= 0 && !kEvidenceBuild && value != 4) return -2; if (value == 1 || value == 2 || value == 4) c->slide2_rounds = value; }
     else if (!strcmp(key, "slide_impl")) { prev = c->slide_impl; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 0 || value == 1) c->slide_impl = value; }
     else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && !kEvidenceBuild && value != 2) return -2; if (value >= 0 && value <= 2) c->plan_store = value; }
     else if (!strcmp(key, "batch_abl")) {

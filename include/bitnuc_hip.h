@@ -42,9 +42,9 @@
  *   - "host" entry points take host pointers and are synchronous; large encode / decode
  *     calls (>= 8 Mi bases) are pipelined: a worker pool copies the caller's pageable memory
  *     into pinned double buffers while H2D, kernel and D2H of the neighbouring 32 Mi-base
- *     chunks overlap on three streams; how many threads copy is chosen per direction from rates
- *     measured on this host and the CPUs this process may use (affinity AND cgroup quota;
- *     BITNUC_HOST_THREADS fixes the count, bitnuc_host_pipe_info reports it);
+ *     chunks overlap on three streams; 8 threads copy on the side that moves 1 B per base and 2 on
+ *     the other, capped by the CPUs this process may use (affinity AND cgroup quota;
+ *     BITNUC_HOST_THREADS / BITNUC_HOST_THREADS_LIGHT override, bitnuc_host_pipe_info reports);
  *     the other host entry points stage through device scratch in 128 Mbase chunks;
  *     "_dev" entry points take device pointers, are enqueued
  *     on the context's stream and return immediately -- data-dependent errors
@@ -321,10 +321,9 @@ double bitnuc_selftime_small(int op, size_t n, size_t iters);
  * 2 pinned -> pageable; < 0 on failure. */
 double bitnuc_selftime_host_copy(size_t bytes, int threads, int mode);
 
-/* Configuration and creation-time measurements of this context's pipelined host-pointer path (creates it if needed):
- * out[0..n) = cores_visible, cores_quota (0 = none), cores_usable, chunk_bases, depth, encode stage-in / hand-back threads,
- * decode stage-in / hand-back threads, pinned H2D GB/s, pinned D2H GB/s, stage-in memcpy GB/s and hand-back memcpy GB/s at
- * the chosen thread counts, heavy_cap, calibrated. */
+/* Configuration of this context's pipelined host-pointer path (creates it if needed): out[0..n) = cores_visible, cores_quota
+ * (0 = none), cores_usable, chunk_bases, depth, encode stage-in / hand-back threads, decode stage-in / hand-back threads,
+ * heavy_cap (the most threads the heavy side may use here). */
 int bitnuc_host_pipe_info(bitnuc_ctx *ctx, double *out, int n, bitnuc_err *err);
 
 #ifdef __cplusplus

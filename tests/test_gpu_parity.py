@@ -156,7 +156,7 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     assert all(ctx.set_variant("decode", v) == -2 for v in range(47, 56)) and ctx.get("decode") == 22  # decode_x2_kernel: evidence build
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
-                                 ("slide_rounds", 1, (8,)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 1, (0,)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
+                                 ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 1, (0,)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,))):
         assert ctx.get(key) == shipped, key
         assert all(ctx.set_variant(key, v) == -2 for v in others) and ctx.get(key) == shipped, key

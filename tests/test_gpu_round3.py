@@ -355,8 +355,6 @@ def test_host_pipe_budget_respects_the_cpu_quota():
         assert 2 <= total <= max(3, info["cores_usable"]), info
     assert info["encode_stage_in_threads"] >= info["encode_hand_back_threads"]  # 1 B per base in, 0.25 B out
     assert info["decode_hand_back_threads"] >= info["decode_stage_in_threads"]  # 0.25 B per base in, 1 B out
-    if info["calibrated"]:
-        assert info["pinned_h2d_gb_s"] > 1 and info["pinned_d2h_gb_s"] > 1
     c.close()
 
 
@@ -479,13 +477,14 @@ def test_bytes_before_a_batch_never_reach_its_first_word(ctx, oracle):
 
 # ---- every window of a sequence: line-aligned rounds, windows computed where they are stored -------------------------------
 @pytest.mark.parametrize("rounds_per_trip", [1, 2, 4])
-def test_windows_line_aligned_rounds_vs_oracle(ctx, oracle, rounds_per_trip):
+def test_windows_line_aligned_rounds_vs_oracle(ctx, sweep_ctx, oracle, rounds_per_trip):
     """kmer_slide2_kernel (`for w in seq.windows(k) { as_2bit(w) }`, src/lib.rs:170-173): rounds of 1024 windows whose 30-base
     halo comes from the next round's registers or one extra load; sizes around the 1024 / 1056-byte round and trip
     boundaries, every k class (<= 16, 17..31, 32), first invalid byte incl. the halo positions."""
     import bitnuc_amd as bn
-    prev = ctx.set_variant("slide_rounds", rounds_per_trip)
-    assert ctx.get("slide_impl") == 1 and ctx.get("slide_rounds") == rounds_per_trip
+    ctx = ctx if rounds_per_trip == 4 else sweep_ctx  # the product ships 4 rounds per trip; 1 and 2 live in the evidence build
+    prev = ctx.set_variant("slide2_rounds", rounds_per_trip)
+    assert ctx.get("slide_impl") == 1 and ctx.get("slide2_rounds") == rounds_per_trip
     rng = np.random.default_rng(4242 + rounds_per_trip)
     alpha = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
     try:
@@ -510,7 +509,7 @@ def test_windows_line_aligned_rounds_vs_oracle(ctx, oracle, rounds_per_trip):
         t = np.concatenate([s, np.frombuffer(b"N", dtype=np.uint8)])  # a byte past the last window is never examined
         assert np.array_equal(ctx.as_2bit_batch(t, k, 1, n - k + 1), oracle.as_2bit_batch(s, k, 1, n - k + 1))
     finally:
-        ctx.set_variant("slide_rounds", prev)
+        ctx.set_variant("slide2_rounds", prev)
 
 
 def test_windows_both_formulations_agree_at_scale(sweep_ctx, oracle):

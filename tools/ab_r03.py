@@ -97,6 +97,7 @@ if "windows" in what:
             def fn(i, impl=impl, u=u):
                 evid.set_variant("slide_impl", impl)
                 evid.set_variant("slide_rounds", u)
+                evid.set_variant("slide2_rounds", u)
                 evid.as_2bit_batch_dev(seq, k, 1, nwin, outs[i & 1])
             cases[f"{'line-aligned, computed in place' if impl else 'strip kernel (rounds of 992)'}, {u} round(s) per trip"] = fn
     table(f"every {k}-base window of 10^9 bases ({alg / 1e9:.3f} GB algorithmic)", cases, alg)
