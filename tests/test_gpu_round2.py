@@ -218,4 +218,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["rccl_ok"] is None
     assert line["allgather_packed"]["own_slot_ok"] is True and "encode_allgather_end_to_end" in line
+    # round 3: the fabric roofline entry (one shared GPU: null + the reason), the C-ABI block's skip reason, the CPU baseline on an N > 1 line
+    assert line["allgather_packed"]["roofline"]["value"] is None and "device" in line["allgather_packed"]["roofline"]["reason"]
+    assert "skipped" in line["c_abi_allgather"] and line["cpu_baseline"]["value"] > 0
     assert line["roofline"]["kernel"] in ("encode_kernel", "decode_kernel") and "roofline_step" in line

@@ -561,3 +561,25 @@ def test_encode_quad_variants_vs_oracle(sweep_ctx, oracle):
     finally:
         ctx.set_variant("encode", enc0)
     assert ctx.set_variant("encode", 63) == -2
+
+
+def test_bench_force_dist_prints_the_multi_gpu_blocks():
+    """`bench.py --force-dist` on the one GPU every box has: torch.distributed + RCCL at world size 1, so the N>1 line's
+    blocks are all exercised -- allgather_packed with its xGMI roofline entry (null + reason at one rank), the in-place
+    chunked end-to-end form, and the C-ABI block (1-rank RCCL communicator: one-shot == chunked overlap); rc 0, one line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "5", "--warmup", "2", "--bases", str(10**8),
+                        "--no-extras", "--no-traffic", "--cpu-sample", str(10**7), "--cpu-reps", "3"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["rccl_ok"] is True
+    ag = line["allgather_packed"]
+    assert ag["own_slot_ok"] is True and ag["roofline"]["value"] is None and "one rank" in ag["roofline"]["reason"]
+    e2e = line["encode_allgather_end_to_end"]
+    assert e2e["one_shot_ok"] is True and e2e["overlap8_ok"] is True
+    cab = line["c_abi_allgather"]
+    assert cab.get("overlap_equals_one_shot") is True and cab["one_shot_ms"] > 0 and cab["overlap8_ms"] > 0, cab
+    assert "cpu_baseline" in line and line["cpu_baseline"].get("value", 0) > 0
