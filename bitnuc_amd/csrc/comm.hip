@@ -40,7 +40,9 @@ RcclApi &rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        // "librccl.so.1" first: it is the SONAME, so a process that already holds an RCCL (PyTorch bundles its own copy under
+        // that soname) gets THAT instance back instead of a second RCCL runtime beside it; otherwise the system's is loaded
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
             api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (api.handle) break;
         }

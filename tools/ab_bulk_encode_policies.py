@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Bulk encode variants in ENCODE-ONLY sustained bursts (two output buffers): what the store policy and the workgroup size do
 to the kernel by itself, as opposed to inside the encode+decode pair of the timed step (tools/sweep_pairs.py).
-Variant = (UNROLL, BLOCK, nt loads, nt stores, LDS transpose, XCD order): see BITNUC_VARIANTS in bitnuc_hip.hip."""
+Variant = (UNROLL, BLOCK, nt loads, nt stores, LDS transpose, XCD order): see BITNUC_VARIANTS in csrc/codec.hip."""
 import os
 import statistics
 import sys

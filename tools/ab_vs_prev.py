@@ -3,8 +3,9 @@
 rounds, sustained bursts: plan encode / decode, fixed-length encode / decode and the bulk codec on L-base reads.
 Build the other library first, e.g.
   git archive HEAD~1 bitnuc_amd/csrc include | tar -x -C /tmp/prev
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -I/tmp/prev/include \
-        -o bitnuc_amd/libbitnuc_hip_prev.so /tmp/prev/bitnuc_amd/csrc/bitnuc_hip.hip -ldl -lpthread
+  (cd /tmp/prev/bitnuc_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc \
+        -o $REPO/bitnuc_amd/libbitnuc_hip_prev.so runtime.hip codec.hip kmer.hip batch.hip analysis.hip comm.hip -ldl -lpthread)
+  (commits before round 3 have the single unit bitnuc_hip.hip instead)
 usage: ab_vs_prev.py [--prev PATH] [L ...]"""
 import os
 import statistics
