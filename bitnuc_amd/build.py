@@ -35,14 +35,14 @@ def is_stale(lib=LIB):
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build_library(force=False, verbose=True, extra_flags=(), sweep=False, jobs=None):
+def build_library(force=False, verbose=True, extra_flags=(), sweep=False, jobs=None, out=None):
     """sweep=False: the product (libbitnuc_hip.so, the shipped codec variants).  sweep=True: the evidence build
     (libbitnuc_hip_sweep.so, -DBITNUC_SWEEP_VARIANTS) that tools/sweep*.py and the all-variants parity test load.
     The units are compiled side by side (`jobs` at a time, default: the CPUs of this process, at most one per unit) and linked
     into one shared library; objects live in a private temporary directory, the library appears atomically."""
     import concurrent.futures
     import tempfile
-    lib = LIB_SWEEP if sweep else LIB
+    lib = out or (LIB_SWEEP if sweep else LIB)  # out: an experiment's library (tools/ab_*.py), never the product's path
     if not force and not is_stale(lib):
         return lib
     hipcc = hipcc_path()
@@ -69,7 +69,7 @@ def build_library(force=False, verbose=True, extra_flags=(), sweep=False, jobs=N
         finally:
             if os.path.exists(tmp):
                 os.unlink(tmp)
-    if not sweep:
+    if not sweep and not out:
         write_build_info()
     return lib
 

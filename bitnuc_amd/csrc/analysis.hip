@@ -54,10 +54,22 @@ static int hdist_words_launch(bitnuc_ctx *c, bool query_mode, const uint64_t *d_
     if (!d_a || (!query_mode && !d_b) || !d_dist || (reinterpret_cast<uintptr_t>(d_a) & 7) ||
         (!query_mode && (reinterpret_cast<uintptr_t>(d_b) & 7))) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    const unsigned grid = grid_for(c, (count / 4 + kBlock - 1) / kBlock + 1);
     const unsigned long long *a = reinterpret_cast<const unsigned long long *>(d_a), *b = reinterpret_cast<const unsigned long long *>(d_b);
-    if (query_mode) hdist_words_kernel<true><<<grid, kBlock, 0, c->stream>>>(a, nullptr, query, count, (unsigned)len, d_dist);
-    else hdist_words_kernel<false><<<grid, kBlock, 0, c->stream>>>(a, b, 0, count, (unsigned)len, d_dist);
+    size_t done = 0;
+    if (c->hdist_words_impl == 1 && aligned16(d_a) && (query_mode || aligned16(d_b)) && (reinterpret_cast<uintptr_t>(d_dist) & 3) == 0 && count >= 256) {
+        // whole 256-word wave tiles through the coalesced kernel (one tile per wave: the hardware dispatcher walks them)
+        const unsigned long long tiles = count / 256;
+        const unsigned grid = grid_for(c, (tiles + kBlock / 64 - 1) / (kBlock / 64));
+        if (query_mode) hdist_words_coalesced_kernel<true><<<grid, kBlock, 0, c->stream>>>(a, nullptr, query, tiles, (unsigned)len, d_dist);
+        else hdist_words_coalesced_kernel<false><<<grid, kBlock, 0, c->stream>>>(a, b, 0, tiles, (unsigned)len, d_dist);
+        HIPCHK(hipGetLastError());
+        done = (size_t)tiles * 256;
+        if (done == count) return BITNUC_OK;
+    }
+    const size_t rest = count - done;
+    const unsigned grid = grid_for(c, (rest / 4 + kBlock - 1) / kBlock + 1);
+    if (query_mode) hdist_words_kernel<true><<<grid, kBlock, 0, c->stream>>>(a + done, nullptr, query, rest, (unsigned)len, d_dist + done);
+    else hdist_words_kernel<false><<<grid, kBlock, 0, c->stream>>>(a + done, b + done, 0, rest, (unsigned)len, d_dist + done);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }

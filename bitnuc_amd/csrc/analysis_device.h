@@ -9,6 +9,10 @@
 #pragma once
 #include "device_prims.h"
 
+#ifndef BITNUC_COUNTS_UNROLL
+#define BITNUC_COUNTS_UNROLL 4 // 16-byte loads in flight per thread of base_counts_kernel (tools/ab_counts_unroll.py)
+#endif
+
 namespace bitnuc_dev {
 
 // counts[1..3] += C,G,T of one word's bases (A is derived from the length by the host side
@@ -33,7 +37,7 @@ base_counts_kernel(const unsigned long long *__restrict__ words, unsigned long l
     if ((reinterpret_cast<uintptr_t>(words) & 15) == 0) {
         const unsigned long long pairs = full >> 1;
         const u32x4 *w4 = reinterpret_cast<const u32x4 *>(words);
-#pragma unroll 4
+#pragma unroll BITNUC_COUNTS_UNROLL
         for (unsigned long long p = gt; p < pairs; p += nthreads) {
             const u32x4 v = __builtin_nontemporal_load(w4 + p);
             count_word(((unsigned long long)v.y << 32) | v.x, c, g, t);
@@ -70,6 +74,44 @@ base_counts_kernel(const unsigned long long *__restrict__ words, unsigned long l
         counts[1] = cs;
         counts[2] = gs;
         counts[3] = ts;
+    }
+}
+
+// Round 3: the same result with fully coalesced loads.  Above, lane q reads its four words as 32 CONTIGUOUS bytes, so each of its
+// two load instructions covers the wave's 2 KiB with half-filled lines.  Here a wave takes 256 words and lane l loads the 16 bytes
+// at 16 l of the first KiB and of the second KiB (two contiguous KiB per instruction pair), which leaves it with the distances of
+// words 2l, 2l+1 and 128+2l, 128+2l+1; the four bytes a lane STORES (words 4l .. 4l+3) sit in two neighbouring lanes and arrive
+// by two ds_bpermute_b32 (LDS crossbar, no LDS memory).  Only whole 256-word wave tiles; the tail goes through the kernel above.
+template <bool QUERY>
+__global__ void __launch_bounds__(kBlock)
+hdist_words_coalesced_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b, unsigned long long query,
+                             unsigned long long tiles /* of 256 words */, unsigned len, uint8_t *__restrict__ dist) {
+    const unsigned long long mask = len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1); // scalar.rs:26-30
+    const uint32_t mlo = (uint32_t)mask & 0x55555555u, mhi = (uint32_t)(mask >> 32) & 0x55555555u;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * (kBlock / 64);
+    const u32x4 q4 = {(uint32_t)query, (uint32_t)(query >> 32), (uint32_t)query, (uint32_t)(query >> 32)};
+    const int src = (int)(((lane & 31u) << 1) << 2); // byte address of lane 2 (l & 31) for ds_bpermute
+    for (unsigned long long t = wave; t < tiles; t += nwaves) {
+        const u32x4 *pa = reinterpret_cast<const u32x4 *>(a + t * 256);
+        const u32x4 a0 = __builtin_nontemporal_load(pa + lane), a1 = __builtin_nontemporal_load(pa + 64 + lane);
+        u32x4 b0 = q4, b1 = q4;
+        if constexpr (!QUERY) {
+            const u32x4 *pb = reinterpret_cast<const u32x4 *>(b + t * 256);
+            b0 = __builtin_nontemporal_load(pb + lane);
+            b1 = __builtin_nontemporal_load(pb + 64 + lane);
+        }
+        const u32x4 x0 = a0 ^ b0, x1 = a1 ^ b1;
+        const uint32_t d0 = __builtin_popcount((x0.x | (x0.x >> 1)) & mlo) + __builtin_popcount((x0.y | (x0.y >> 1)) & mhi);
+        const uint32_t d1 = __builtin_popcount((x0.z | (x0.z >> 1)) & mlo) + __builtin_popcount((x0.w | (x0.w >> 1)) & mhi);
+        const uint32_t d2 = __builtin_popcount((x1.x | (x1.x >> 1)) & mlo) + __builtin_popcount((x1.y | (x1.y >> 1)) & mhi);
+        const uint32_t d3 = __builtin_popcount((x1.z | (x1.z >> 1)) & mlo) + __builtin_popcount((x1.w | (x1.w >> 1)) & mhi);
+        const uint32_t mine = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24); // low half: words 2l, 2l+1; high half: words 128+2l, 128+2l+1
+        const uint32_t v0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)mine), v1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src + 4, (int)mine);
+        // lanes 0..31 store words 4l..4l+3 (first KiB: low halves), lanes 32..63 words 128 + 4(l-32).. (second KiB: high halves)
+        const uint32_t out = lane < 32 ? ((v0 & 0xFFFFu) | (v1 << 16)) : ((v0 >> 16) | (v1 & 0xFFFF0000u));
+        __builtin_nontemporal_store(out, reinterpret_cast<uint32_t *>(dist + t * 256) + lane);
     }
 }
 

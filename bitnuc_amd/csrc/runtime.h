@@ -83,6 +83,7 @@ struct bitnuc_ctx {
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
     int scan_impl = 1;                     // 1 = line-aligned rounds of 1024 windows (kmer_scan2_kernel), 0 = rounds of 992 windows (kmer_scan_kernel)
+    int hdist_words_impl = 1;              // many-pair / one-query hdist: 1 = coalesced loads + bpermute for whole 256-word tiles, 0 = four contiguous words per lane
     int force_gpu = 0;                     // 1: single-word and below-cutoff calls launch kernels too (GPU parity tests, BITNUC_FORCE_GPU=1)
     size_t host_cutoff = bitnuc_rt::kDefaultHostCutoff; // bulk host-pointer encode / hdist below this many bases run on the host (host_word.h)
     size_t host_cutoff_decode = bitnuc_rt::kDefaultHostCutoffDecode; // ... decode

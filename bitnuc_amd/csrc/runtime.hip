@@ -319,6 +319,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
     else if (!strcmp(key, "scan_impl")) { prev = c->scan_impl; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 0 || value == 1) c->scan_impl = value; }
     else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value >= 0 && !kEvidenceBuild && value != 4) return -2; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
+    else if (!strcmp(key, "hdist_words_impl")) { prev = c->hdist_words_impl; if (value == 0 || value == 1) c->hdist_words_impl = value; }
     else if (!strcmp(key, "reduce_mult")) { prev = (int)(c->reduce_blocks / (unsigned)c->num_cu); if (value >= 1 && value <= 32) c->reduce_blocks = (unsigned)c->num_cu * (unsigned)value; }
     else if (!strcmp(key, "num_variants")) { prev = codec_num_variants(); }
     else if (!strcmp(key, "num_cu")) { prev = c->num_cu; }

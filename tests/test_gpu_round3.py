@@ -583,3 +583,36 @@ def test_bench_force_dist_prints_the_multi_gpu_blocks():
     cab = line["c_abi_allgather"]
     assert cab.get("overlap_equals_one_shot") is True and cab["one_shot_ms"] > 0 and cab["overlap8_ms"] > 0, cab
     assert "cpu_baseline" in line and line["cpu_baseline"].get("value", 0) > 0
+
+
+def test_hdist_words_coalesced_kernel_vs_oracle(ctx, oracle):
+    """Many-pair / one-query hdist_scalar (hamming/scalar.rs:11-48): the coalesced-load kernel (whole 256-word wave tiles, the
+    stored bytes gathered from neighbouring lanes) and the four-contiguous-words kernel give the oracle's distances for
+    counts around the tile size, every len class, 16- and 8-byte aligned inputs."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(808)
+    for impl in (1, 0):
+        prev = ctx.set_variant("hdist_words_impl", impl)
+        try:
+            for count in (1, 255, 256, 257, 511, 512, 1000, 256 * 37 + 3, 100003):
+                for length in (0, 1, 16, 31, 32):
+                    a = rng.integers(0, 1 << 63, size=count + 1, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=count + 1, dtype=np.uint64)
+                    b = a ^ (rng.integers(0, 1 << 63, size=count + 1, dtype=np.uint64) & rng.integers(0, 1 << 63, size=count + 1, dtype=np.uint64))
+                    for shift in (0, 1):  # 16-byte aligned tables, then 8 bytes into them
+                        da = torch.from_numpy(a.view(np.int64)).to(dev)[shift:]
+                        db = torch.from_numpy(b.view(np.int64)).to(dev)[shift:]
+                        n = count + 1 - shift
+                        out = torch.full((n + 8,), 0xEE, dtype=torch.uint8, device=dev)
+                        torch.cuda.synchronize()
+                        ctx.hdist_pairs_dev(da, db, n, length, out)
+                        ctx.sync()
+                        exp = oracle.hdist_pairs(a[shift:], b[shift:], length)
+                        h = out.cpu().numpy()
+                        assert np.array_equal(h[:n], exp) and (h[n:] == 0xEE).all(), (impl, count, length, shift)
+                        q = int(b[0])
+                        ctx.hdist_query_dev(q, da, n, length, out)
+                        ctx.sync()
+                        assert np.array_equal(out.cpu().numpy()[:n], oracle.hdist_pairs(a[shift:], np.full(n, q, dtype=np.uint64), length)), (impl, count, length, shift)
+        finally:
+            ctx.set_variant("hdist_words_impl", prev)
