@@ -61,7 +61,7 @@ int bitnuc_batch_word_offsets_dev(bitnuc_ctx *c, const uint64_t *d_offsets, size
     unsigned long long *wo = reinterpret_cast<unsigned long long *>(d_word_offsets);
     word_offsets_block_sums<<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums);
     word_offsets_scan_sums<<<1, kBlock, 0, c->stream>>>(sums, nblocks, off, count);
-    word_offsets_finish<false><<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums, wo, nullptr, nullptr);
+    word_offsets_finish<<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums, wo);
     HIPCHK(hipGetLastError());
     uint64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, d_word_offsets + count, sizeof total, hipMemcpyDeviceToHost, c->stream));
@@ -82,10 +82,10 @@ static int emit_scratch_plan(bitnuc_ctx *c, const uint64_t *d_offsets, const uin
     *P = c->scratch[6];
     *tile_base = reinterpret_cast<unsigned long long *>(c->scratch[7]);
     *bounds = *tile_base + ntiles + 1;
-    const size_t threads = (count + kScanPer - 1) / kScanPer;
-    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
-    plan_emit_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_offsets),
-                                                      reinterpret_cast<const unsigned long long *>(d_word_offsets), count, *P, *tile_base, *bounds);
+    const unsigned grid = (unsigned)((count + kScanTile - 1) / kScanTile);
+    // word_offsets[i] is by definition the prefix sum of ceil(len / 32): the kernel reads one entry per workgroup and scans the rest
+    plan_emit_kernel<true, false><<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_offsets),
+                                                                   reinterpret_cast<const unsigned long long *>(d_word_offsets), count, *P, *tile_base, *bounds, nullptr);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }
@@ -357,7 +357,7 @@ int bitnuc_batch_plan_build_dev(bitnuc_ctx *c, bitnuc_batch_plan *p, const uint6
     DeviceGuard g(c->device);
     p->built = false;
     if (int st = plan_reserve(&p->d_wo, &p->cap_wo, count + 1, c->stream, err)) return st;
-    // sums -> scan of the sums -> (host learns the total and sizes the plan) -> offsets + pad bytes + tile bases in one pass
+    // sums -> scan of the sums -> (host learns the total and sizes the plan) -> offsets + pad bytes + tile bases + bounds in one pass
     unsigned long long ends[3] = {0, 0, 0}; // total words, offsets[0], offsets[count]
     const size_t nblocks = (count + kScanTile - 1) / kScanTile;
     const unsigned long long *off = reinterpret_cast<const unsigned long long *>(d_offsets);
@@ -379,15 +379,13 @@ int bitnuc_batch_plan_build_dev(bitnuc_ctx *c, bitnuc_batch_plan *p, const uint6
     const size_t ntiles = (total + kBatchTile - 1) / kBatchTile;
     if (int st = plan_reserve(&p->d_base, &p->cap_base, ntiles + 1, c->stream, err)) return st;
     if (int st = plan_reserve(&p->d_P, &p->cap_P, total + 2 + kBatchTile, c->stream, err)) return st;
-    HIPCHK(hipMemsetAsync(p->d_P, 0, total + 2 + kBatchTile, c->stream));
-    if (count) {
-        word_offsets_finish<true><<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, count, sums, p->d_wo, p->d_P, p->d_base);
+    if (int st = plan_reserve(&p->d_bounds, &p->cap_bounds, 2, c->stream, err)) return st;
+    if (count) { // one pass: word offsets + pad bytes + tile bases + buffer bounds (every pad byte is written: no memset)
+        plan_emit_kernel<false, true><<<(unsigned)nblocks, kBlock, 0, c->stream>>>(off, sums, count, p->d_P, p->d_base, p->d_bounds, p->d_wo);
         HIPCHK(hipGetLastError());
     }
     p->seq_begin = ends[1];
     p->seq_end = ends[2];
-    if (int st = plan_reserve(&p->d_bounds, &p->cap_bounds, 2, c->stream, err)) return st;
-    HIPCHK(hipMemcpyAsync(p->d_bounds, &ends[1], 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream)); // the build is synchronous: the plan's tables may be read on any stream afterwards
     p->built = true;
     if (total_words) *total_words = total;

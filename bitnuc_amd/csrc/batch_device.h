@@ -170,9 +170,8 @@ block_owner_kernel(const unsigned long long *__restrict__ offsets, const unsigne
 // owns kScanPer = 8 CONSECUTIVE sequences: their nine offsets are four 16-byte loads plus one 8-byte load (the lanes of a
 // wave read 4 KiB contiguous), the serial part of the scan runs in registers, and the eight results leave as four
 // 16-byte stores.  (Round 1's version staged 16 counts per thread through LDS at a stride of 16 dwords: 10-13 bank-conflict
-// cycles per LDS instruction and 59 us for 6.7 M sequences, profiles/r02_batch_pmc1.txt.)  The last pass also has everything
-// plan_emit_kernel needs -- a sequence's first / one-past-last word and byte -- so the plan's pad bytes and tile bases are
-// written there (EMIT) instead of by a fourth pass that re-reads both tables.
+// cycles per LDS instruction and 59 us for 6.7 M sequences, profiles/r02_batch_pmc1.txt.)  A layout plan's last pass is
+// plan_emit_kernel below, which redoes this pass's workgroup scan and writes the offsets AND the plan.
 constexpr int kScanPer = 8;
 constexpr int kScanTile = kBlock * kScanPer; // sequences per workgroup
 
@@ -252,32 +251,26 @@ word_offsets_scan_sums(unsigned long long *__restrict__ block_sums, unsigned lon
     }
 }
 
-// The plan entries of one sequence: words [a, b), bytes [o, e).  P[b] = what its last word lacks (seen by the word after
-// it); tile_base[t] for every 64-word tile whose first word it owns.  Call from all 64 lanes (wave-uniform control flow):
-// a long sequence hands its tile bases to the whole wave.
-__device__ __forceinline__ void plan_emit_sequence(unsigned long long a, unsigned long long b, unsigned long long o, unsigned long long e, bool valid,
-                                                   uint8_t *__restrict__ P, unsigned long long *__restrict__ tile_base) {
-    const unsigned lane = threadIdx.x & 63;
-    const bool has_words = valid && b > a;
-    if (has_words) P[b] = (uint8_t)(32ull * (b - a) - (e - o));
-    const unsigned long long t0 = (a + 63) >> 6, t1 = has_words ? (b + 63) >> 6 : t0; // tile boundaries 64 t inside [a, b)
-    const bool is_long = t1 - t0 > 8;
-    if (!is_long)
-        for (unsigned long long t = t0; t < t1; ++t) tile_base[t] = o + (((t << 6) - a) << 5);
-    unsigned long long m = __ballot(is_long);
-    while (m) {
-        const unsigned l = (unsigned)__builtin_ctzll(m);
-        m &= m - 1;
-        const unsigned long long A = read_lane_u64(a, l), O = read_lane_u64(o, l), T0 = read_lane_u64(t0, l), T1 = read_lane_u64(t1, l);
-        for (unsigned long long t = T0 + lane; t < T1; t += 64) tile_base[t] = O + (((t << 6) - A) << 5);
+// w[j] -> word_offsets[i + j] for the entries of the table this thread owns (j = 0..7, and the grand total at index `count` by the
+// thread that holds the last sequence): four 16-byte stores when the thread's eight sequences are all inside the table
+__device__ __forceinline__ void store_word_offsets9(unsigned long long *__restrict__ word_offsets, unsigned long long count, unsigned long long i,
+                                                    const unsigned long long (&w)[kScanPer + 1]) {
+    if (i + kScanPer <= count) {
+        u32x4_u *dst = reinterpret_cast<u32x4_u *>(word_offsets + i);
+#pragma unroll
+        for (int q = 0; q < kScanPer / 2; ++q)
+            dst[q] = u32x4{(uint32_t)w[2 * q], (uint32_t)(w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)(w[2 * q + 1] >> 32)};
+        if (i + kScanPer == count) word_offsets[count] = w[kScanPer]; // the grand total, by the thread that holds the last sequence
+    } else {
+#pragma unroll
+        for (int j = 0; j <= kScanPer; ++j)
+            if (i + j <= count) word_offsets[i + j] = w[j]; // j with i + j == count: the grand total
     }
 }
 
-template <bool EMIT>
 __global__ void __launch_bounds__(kBlock)
 word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned long long count,
-                    const unsigned long long *__restrict__ block_sums, unsigned long long *__restrict__ word_offsets,
-                    uint8_t *__restrict__ P /* EMIT: zeroed, total_words + 1 */, unsigned long long *__restrict__ tile_base) {
+                    const unsigned long long *__restrict__ block_sums, unsigned long long *__restrict__ word_offsets) {
     const unsigned long long i = (unsigned long long)blockIdx.x * kScanTile + (unsigned long long)threadIdx.x * kScanPer;
     unsigned long long o[kScanPer + 1], c[kScanPer], s = 0;
     load_offsets9(offsets, count, i, o);
@@ -295,36 +288,27 @@ word_offsets_finish(const unsigned long long *__restrict__ offsets, unsigned lon
         run += c[j];
     }
     w[kScanPer] = run;
-    if (i + kScanPer <= count) {
-        u32x4_u *dst = reinterpret_cast<u32x4_u *>(word_offsets + i);
-#pragma unroll
-        for (int q = 0; q < kScanPer / 2; ++q)
-            dst[q] = u32x4{(uint32_t)w[2 * q], (uint32_t)(w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)(w[2 * q + 1] >> 32)};
-        if (i + kScanPer == count) word_offsets[count] = run; // the grand total, by the thread that holds the last sequence
-    } else {
-#pragma unroll
-        for (int j = 0; j <= kScanPer; ++j)
-            if (i + j <= count) word_offsets[i + j] = w[j]; // j with i + j == count: the grand total
-    }
-    if constexpr (EMIT) {
-#pragma unroll
-        for (int j = 0; j < kScanPer; ++j) plan_emit_sequence(w[j], w[j + 1], o[j], o[j + 1], i + j < count, P, tile_base);
-    }
+    store_word_offsets9(word_offsets, count, i, w);
 }
 
 // ---------------------------------------------------------------------------------
-// layout plan from BOTH tables in one asynchronous pass (the table-driven entry points)
+// the layout plan in one pass over the offsets table
 // ---------------------------------------------------------------------------------
-// bitnuc_encode_batch_dev / bitnuc_decode_batch_dev receive offsets, word offsets and total_words: everything the plan's
-// two arrays depend on is on the device and their sizes are known to the host, so the plan can be emitted into context
-// scratch by ONE launch with no scan, no host synchronisation and no memset -- and the plan kernels run unchanged.  (Round 2's
-// table-driven form searched the owner of every tile in a pre-kernel and rebuilt the per-word lookup inside the main kernels:
-// 0.245 / 0.252 ms against 0.205 / 0.206 for the plan kernels, profiles/r02_batch_kernel_stats.txt.)
-// A thread owns kScanPer consecutive sequences (both tables: four 16-byte loads + one 8-byte load each) and with them the pad
-// bytes P[w0 + 1 .. w8] (w0 / w8 = its first / one-past-last word): it ZEROES that range itself with 16-byte stores (adjacent
-// threads own adjacent ranges: every P byte in 1..total_words is written exactly once, none needs a memset) and then drops
-// each sequence's pad byte on top (same thread, same address: program order).  A range longer than kEmitCoop bytes (long
-// sequences) is zeroed by the whole wave.  bounds[0..1] = offsets[0], offsets[count] for the plan encode's buffer clipping.
+// bitnuc_encode_batch_dev / bitnuc_decode_batch_dev receive offsets, word offsets and total_words: the plan's sizes are known to
+// the host, so the plan can be emitted into context scratch by ONE launch with no host synchronisation and no memset -- and the
+// plan kernels run unchanged.  (Round 2's table-driven form searched the owner of every tile in a pre-kernel and rebuilt the
+// per-word lookup inside the main kernels: 0.245 / 0.252 ms against 0.205 / 0.206 for the plan kernels.)
+// A workgroup owns kScanTile = 2048 consecutive sequences, a thread eight of them.  It needs their word offsets -- and reads
+// only ONE of them from the caller's table: word_offsets[i] is by definition the prefix sum of ceil(len/32), so the workgroup's
+// first entry plus a workgroup-wide exclusive scan of the counts (registers, wave shuffles, one LDS hop) gives all 2048.  The
+// kernel therefore reads 8 bytes per sequence, not 16 (the first form read both tables: 144 MB moved, 24 us; this one 91 MB).
+// FROM_TABLE = false: the workgroup's base comes from the scan's block sums instead and WRITE_WO stores the word offsets too --
+// the last pass of bitnuc_batch_plan_build_dev (it replaces a pass that scattered the plan bytes into global memory: 44.6 us).
+// The workgroup's pad bytes P[W0 + 1 .. W1] are one contiguous run: when it fits kEmitLds bytes (reads: 2048 x 5 words = 10 KiB) it
+// is ASSEMBLED IN LDS -- zeroed, pad bytes and tile bases scattered into it with LDS stores -- and leaves as coalesced 16-byte
+// stores (every P byte in 1..total_words is written exactly once: no memset); longer runs (sequences of hundreds of bases:
+// far fewer table entries per byte) take a per-thread path, ranges above kEmitCoop bytes zeroed by the whole wave.
+// bounds[0..1] = offsets[0], offsets[count] for the plan encode's buffer clipping.
 constexpr unsigned kEmitCoop = 256;
 
 __device__ __forceinline__ void plan_emit_tile_bases(unsigned long long a, unsigned long long b, unsigned long long o, bool valid,
@@ -355,32 +339,32 @@ __device__ __forceinline__ void zero_bytes(uint8_t *__restrict__ p, unsigned lon
     if (n & 1) p[k] = 0;
 }
 
-// A workgroup owns kScanTile consecutive sequences and with them the contiguous pad bytes P[W0 + 1 .. W1].  When that range fits
-// kEmitLds bytes (reads: 2048 x 5 words = 10 KiB) it is ASSEMBLED IN LDS -- zeroed, the pad bytes and the tile bases scattered
-// into it with LDS stores -- and leaves as coalesced 16-byte stores; a per-thread global scatter of single bytes at a 40-byte
-// stride cost 3 partial-line writes per sequence (first version of this kernel: 33-39 us for 6.67 M reads, now measured in
-// profiles/r03_plan_emit.txt).  Longer ranges (sequences of hundreds of bases and more: far fewer table entries per byte) take
-// the per-thread path below.
 constexpr unsigned kEmitLds = 16 * 1024;
 constexpr unsigned kEmitLdsTiles = kEmitLds / 64 + 2;
 
+template <bool FROM_TABLE, bool WRITE_WO>
 __global__ void __launch_bounds__(kBlock)
-plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ word_offsets, unsigned long long count,
-                 uint8_t *__restrict__ P, unsigned long long *__restrict__ tile_base, unsigned long long *__restrict__ bounds) {
+plan_emit_kernel(const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ wbase /* FROM_TABLE: the caller's word offsets; else the exclusive block sums */,
+                 unsigned long long count, uint8_t *__restrict__ P, unsigned long long *__restrict__ tile_base, unsigned long long *__restrict__ bounds,
+                 unsigned long long *__restrict__ wo_out /* WRITE_WO */) {
     __shared__ __attribute__((aligned(16))) uint8_t pads[kEmitLds + 16];
     __shared__ unsigned long long tbs[kEmitLdsTiles];
-    __shared__ unsigned long long range[2];
     const unsigned lane = threadIdx.x & 63;
-    const unsigned long long i = ((unsigned long long)blockIdx.x * kBlock + threadIdx.x) * kScanPer;
-    unsigned long long o[kScanPer + 1], w[kScanPer + 1];
+    const unsigned long long first = (unsigned long long)blockIdx.x * kScanTile; // < count: the grid is ceil(count / kScanTile)
+    const unsigned long long i = first + (unsigned long long)threadIdx.x * kScanPer;
+    unsigned long long o[kScanPer + 1], w[kScanPer + 1], s = 0;
     const unsigned long long ic = i < count ? i : count; // threads past the table hold nine copies of its last entry: nothing to write
     load_offsets9(offsets, count, ic, o);
-    load_offsets9(word_offsets, count, ic, w);
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) s += (o[j + 1] - o[j] + 31) >> 5;
+    unsigned long long R; // words of this workgroup's sequences = its pad bytes P[W0 + 1 .. W0 + R]
+    const unsigned long long excl = block_exclusive_scan(s, &R);
+    const unsigned long long W0 = FROM_TABLE ? wbase[first] : wbase[blockIdx.x]; // wave-uniform: one scalar load
+    w[0] = W0 + excl;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) w[j + 1] = w[j] + ((o[j + 1] - o[j] + 31) >> 5);
     if (i == 0) { bounds[0] = o[0]; bounds[1] = offsets[count]; }
-    if (threadIdx.x == 0) range[0] = w[0];
-    if (threadIdx.x == kBlock - 1) range[1] = w[kScanPer];
-    __syncthreads();
-    const unsigned long long W0 = range[0], R = range[1] - W0; // this workgroup's pad bytes: P[W0 + 1 .. W0 + R]
+    if constexpr (WRITE_WO) if (i <= count) store_word_offsets9(wo_out, count, i, w);
     if (R <= kEmitLds) { // workgroup-uniform
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (unsigned k = 16u * threadIdx.x; k < (unsigned)R; k += 16u * kBlock) *reinterpret_cast<u32x4 *>(pads + k) = z;
@@ -1039,12 +1023,12 @@ decode_batch2_kernel(const unsigned long long *__restrict__ words, const unsigne
 // and often many times.  The plan therefore holds, per layout:
 //   tile_base[t]  byte offset of word 64 t (one u64 per wave tile), and
 //   P[w]          one byte per word: the padding of the sequence that ENDS at word w-1 (0..31; 0 when word w does
-//                 not start a sequence) -- written by the last pass of the word-offsets scan (word_offsets_finish<true>).
+//                 not start a sequence) -- written by plan_emit_kernel.
 // A lane's lookup is then ONE byte load, issued together with the tile's data, and a DPP prefix sum:
 //   n  = P[wb + lane + 1]          what word (wb + lane) lacks to 32 bases,
 //   nb = 32 - n,    first byte = tile_base + 32 lane - (sum of n over the lanes before it).
 // No window, no search, no LDS for the lookup, no dependent global load, no per-call pre-kernel.
-// (The plan is written by word_offsets_finish<true> above: plan_emit_sequence.)
+// (The plan is written by plan_emit_kernel above.)
 
 // One tile of the plan encode.  issue: the tile's 16-byte chunks (2 per lane), one dword of the 129th chunk (an unaligned
 // tile's last <= 15 bytes; lanes 0-3) and the lane's pad byte.  Every load is unconditional with a clamped, in-bounds

@@ -255,6 +255,7 @@ struct HostPipe {
     size_t chunk = kPipeChunkDefault; // bases per chunk (a multiple of 32)
     int enc_in = 1, enc_out = 1, dec_in = 1, dec_out = 1; // copy threads per direction and side
     int cores_visible = 1, cores_quota = 0, cores_usable = 1, heavy_cap = 1;
+    int numa_node = -1, bound_cpus = 0; // the GPU's NUMA node (-1 = unknown) and how many of its CPUs the workers are bound to (0 = not bound)
     bool ok = false;
 };
 
@@ -314,8 +315,27 @@ int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err) {
     p->heavy_cap = cap;
     const int heavy = forced ? cap : (cap < 8 ? cap : 8);
     const int most = heavy > light ? heavy : light;
-    p->pool = new CopyPool(most);         // the caller + most - 1 workers
-    p->pool_out = new CopyPool(most + 1); // most workers (the caller's slice index is unused in asynchronous jobs)
+    // NUMA: the runtime places pinned host memory on the node the GPU hangs off, and a copy thread is fast when it sits on the node
+    // of its SOURCE (local reads, posted remote writes).  The hand-back pool reads pinned memory, so its workers are bound to the
+    // GPU's local CPUs; the stage-in pool reads the CALLER's memory, whose node the library cannot know -- its workers stay free
+    // and the scheduler keeps them near the calling thread that wakes them, which is where the caller's pages usually are.
+    // tools/host_topology.py on a two-socket box, fresh contexts, 10^9 bases: free hand-back workers gave decode 35.9-51.2 Gbases/s
+    // (median 44.7), bound ones 46.2-50.7 (median 49.8); bound STAGE-IN workers cost encode 10 % (44-51 against a steady 51-52).
+    // BITNUC_PIPE_NUMA=0 leaves every worker free.
+    cpu_set_t local;
+    int n_local = 0;
+    const char *numa_env = getenv("BITNUC_PIPE_NUMA");
+    if (!(numa_env && atoi(numa_env) == 0)) {
+        char bdf[32] = {0};
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, c->device) == hipSuccess) {
+            for (char *q = bdf; *q; ++q) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a'); // sysfs names are lower case
+            n_local = bitnuc_host::pci_local_cpus(bdf, &local, &p->numa_node);
+        } else (void)hipGetLastError();
+    }
+    p->bound_cpus = n_local >= most ? n_local : 0; // only when the node offers at least as many CPUs as the pool has threads
+    const cpu_set_t *bind = p->bound_cpus ? &local : nullptr;
+    p->pool = new CopyPool(most);               // the caller + most - 1 workers, free (see above)
+    p->pool_out = new CopyPool(most + 1, bind); // most workers (the caller's slice index is unused in asynchronous jobs)
     p->enc_in = p->dec_out = heavy;
     p->enc_out = p->dec_in = light < most ? light : most;
     p->ok = true;
@@ -461,7 +481,7 @@ extern "C" {
 
 // Diagnostic (bench.py's host_path block): how the pipelined host-pointer path of this context is configured.  Creates the pipe if
 // this context has none yet.  out[0..n): cores_visible, cores_quota (0 = none), cores_usable, chunk_bases, depth, enc_in, enc_out,
-// dec_in, dec_out (copy threads), heavy_cap.
+// dec_in, dec_out (copy threads), heavy_cap, the GPU's NUMA node (-1 = unknown), CPUs of that node the workers are bound to (0 = free).
 int bitnuc_host_pipe_info(bitnuc_ctx *c, double *out, int n, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
@@ -469,9 +489,10 @@ int bitnuc_host_pipe_info(bitnuc_ctx *c, double *out, int n, bitnuc_err *err) {
     DeviceGuard g(c->device);
     HostPipe *p;
     if (int st = pipe_get(c, &p, err)) return st;
-    const double v[10] = {(double)p->cores_visible, (double)p->cores_quota, (double)p->cores_usable, (double)p->chunk, (double)kPipeDepth,
-                          (double)p->enc_in, (double)p->enc_out, (double)p->dec_in, (double)p->dec_out, (double)p->heavy_cap};
-    for (int i = 0; i < n; ++i) out[i] = i < 10 ? v[i] : 0.0;
+    const double v[12] = {(double)p->cores_visible, (double)p->cores_quota, (double)p->cores_usable, (double)p->chunk, (double)kPipeDepth,
+                          (double)p->enc_in, (double)p->enc_out, (double)p->dec_in, (double)p->dec_out, (double)p->heavy_cap,
+                          (double)p->numa_node, (double)p->bound_cpus};
+    for (int i = 0; i < n; ++i) out[i] = i < 12 ? v[i] : 0.0;
     return BITNUC_OK;
 }
 

@@ -5,6 +5,7 @@
 // The reference is single-threaded (src/utils/unpacking/avx.rs:37 holds its only static); these threads exist only to
 // move the caller's pageable bytes to and from pinned memory at PCIe speed, they never touch codec arithmetic.
 #pragma once
+#include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -52,6 +53,42 @@ inline int cores_usable() {
     const int vis = cores_visible(), quota = cores_quota();
     return quota > 0 && quota < vis ? quota : vis;
 }
+// "0-63,128-191" (sysfs cpulist format) -> cpu_set_t; returns the number of CPUs set
+inline int parse_cpulist(const char *text, cpu_set_t *out) {
+    CPU_ZERO(out);
+    const char *p = text;
+    while (*p) {
+        char *end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') { b = strtol(p + 1, &end, 10); if (end == p + 1) break; p = end; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0) CPU_SET((int)c, out);
+        while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+    }
+    return CPU_COUNT(out);
+}
+// the CPUs local to a PCI device ("0000:23:00.0"), intersected with what this process may run on; 0 = unknown
+inline int pci_local_cpus(const char *bdf, cpu_set_t *out, int *numa_node) {
+    char path[256], buf[4096] = {0};
+    CPU_ZERO(out);
+    if (numa_node) *numa_node = -1;
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    const size_t got = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[got] = 0;
+    cpu_set_t local, mine;
+    if (parse_cpulist(buf, &local) == 0 || sched_getaffinity(0, sizeof mine, &mine) != 0) return 0;
+    CPU_AND(out, &local, &mine);
+    if (numa_node) {
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+        if (FILE *g = fopen(path, "r")) { if (fscanf(g, "%d", numa_node) != 1) *numa_node = -1; fclose(g); }
+    }
+    return CPU_COUNT(out);
+}
 inline int env_threads(const char *name) { // 0 = not set / out of range
     if (const char *e = getenv(name)) {
         const int v = atoi(e);
@@ -82,7 +119,10 @@ struct CopyPool {
     bool busy = false; // caller-side only: an asynchronous job has been started and not yet waited for
     int n = 1;         // workers + the calling thread
 
-    explicit CopyPool(int nthreads) : n(nthreads < 1 ? 1 : nthreads) {
+    // `cpus` (optional): the workers are bound to this CPU set -- the pipelined host path passes the CPUs of the NUMA node the
+    // GPU hangs off, where the runtime also puts pinned host memory (the calling thread is the caller's and is left alone)
+    explicit CopyPool(int nthreads, const cpu_set_t *cpus = nullptr) : n(nthreads < 1 ? 1 : nthreads) {
+        if (cpus) { bind = *cpus; bound = CPU_COUNT(&bind) > 0; }
         for (int i = 1; i < n; ++i) threads.emplace_back([this, i] { run(i); });
     }
     ~CopyPool() {
@@ -103,7 +143,10 @@ struct CopyPool {
         const size_t m = bytes - a < slice ? bytes - a : slice;
         memcpy(dst + a, src + a, m);
     }
+    cpu_set_t bind;
+    bool bound = false;
     void run(int i) {
+        if (bound) (void)pthread_setaffinity_np(pthread_self(), sizeof bind, &bind); // best effort
         unsigned seen = 0;
         for (;;) {
             {

@@ -323,7 +323,8 @@ double bitnuc_selftime_host_copy(size_t bytes, int threads, int mode);
 
 /* Configuration of this context's pipelined host-pointer path (creates it if needed): out[0..n) = cores_visible, cores_quota
  * (0 = none), cores_usable, chunk_bases, depth, encode stage-in / hand-back threads, decode stage-in / hand-back threads,
- * heavy_cap (the most threads the heavy side may use here). */
+ * heavy_cap (the most threads the heavy side may use here), the GPU's NUMA node (-1 = unknown), the number of that node's CPUs
+ * the copy workers are bound to (0 = not bound; BITNUC_PIPE_NUMA=0 disables the binding). */
 int bitnuc_host_pipe_info(bitnuc_ctx *ctx, double *out, int n, bitnuc_err *err);
 
 #ifdef __cplusplus

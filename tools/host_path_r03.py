@@ -51,11 +51,12 @@ back = np.zeros(n, dtype=np.uint8)
 print(f"cores visible: {len(os.sched_getaffinity(0))}")
 
 
-def run(label, env):
+def run(label, env, null_stream=False):
     for k in ("BITNUC_HOST_THREADS", "BITNUC_HOST_THREADS_LIGHT", "BITNUC_PIPE_CHUNK_MB", "BITNUC_PIPE_CALIBRATE"):
         os.environ.pop(k, None)
     os.environ.update(env)
-    ctx = bitnuc_amd.Context(0)
+    # null_stream: the context rides on torch's current stream = the legacy NULL stream (what bench.py's main context does)
+    ctx = bitnuc_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream) if null_stream else bitnuc_amd.Context(0)
     info = ctx.host_pipe_info()
     te, td = [], []
     for _ in range(4):
@@ -73,7 +74,10 @@ def run(label, env):
     ctx.close()
 
 
-run("default (calibrated)", {})
+run("default", {})
+run("default, context on the NULL stream", {}, null_stream=True)
+run("default again", {})
+run("NULL stream again", {}, null_stream=True)
 run("heavy 8, light 2", {"BITNUC_HOST_THREADS": "8", "BITNUC_HOST_THREADS_LIGHT": "2"})
 run("heavy 8, light 4", {"BITNUC_HOST_THREADS": "8", "BITNUC_HOST_THREADS_LIGHT": "4"})
 run("heavy 11, light 4", {"BITNUC_HOST_THREADS": "11", "BITNUC_HOST_THREADS_LIGHT": "4"})
