@@ -234,7 +234,7 @@ int codec_ballot_variant() { return kEvidenceBuild ? kBallotVariant : -1; }
 // streams and guard buffer reuse; the host waits only when a pinned buffer is about to be overwritten.
 //
 // How many threads copy is decided per direction when the pipe is created.  The HEAVY side (stage-in for encode: 1 B per base;
-// hand-back for decode: 1 B per base) gets 8 threads, the light side (0.25 B per base) 2, both capped by the CPUs this process
+// hand-back for decode: 1 B per base) gets 8 threads, the light side (0.25 B per base) 4 (2 below a 12-CPU budget), both capped by the CPUs this process
 // may use (affinity mask AND cgroup quota: cores_usable() -- a 16-core quota on a 256-thread host shows 256 CPUs in its mask).
 // Measured on the GPU box (tools/host_path_r03.py, profiles/r03_host_path.txt; 10^9 bases, pinned engines 56 GB/s each way and
 // full duplex): 6 / 8 / 11 heavy threads give encode 51.7 / 52.0 / 52.0 and decode 49.3 / 49.5 / 49.9 Gbases/s; round 2's
@@ -305,7 +305,7 @@ int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err) {
     p->cores_quota = bitnuc_host::cores_quota();
     p->cores_usable = bitnuc_host::cores_usable();
     const int budget = p->cores_usable > 2 ? p->cores_usable - 1 : 2;
-    int light = budget >= 8 ? 2 : 1;
+    int light = budget >= 12 ? 4 : (budget >= 8 ? 2 : 1); // the 0.25 B-per-base side sits on the caller's critical path: it must never become the slow one
     if (const int v = bitnuc_host::env_threads("BITNUC_HOST_THREADS_LIGHT")) light = v;
     int cap = budget - light;
     if (cap > bitnuc_host::kPoolMaxThreads - 1) cap = bitnuc_host::kPoolMaxThreads - 1;

@@ -42,7 +42,7 @@
  *   - "host" entry points take host pointers and are synchronous; large encode / decode
  *     calls (>= 8 Mi bases) are pipelined: a worker pool copies the caller's pageable memory
  *     into pinned double buffers while H2D, kernel and D2H of the neighbouring 32 Mi-base
- *     chunks overlap on three streams; 8 threads copy on the side that moves 1 B per base and 2 on
+ *     chunks overlap on three streams; 8 threads copy on the side that moves 1 B per base and 4 on
  *     the other, capped by the CPUs this process may use (affinity AND cgroup quota;
  *     BITNUC_HOST_THREADS / BITNUC_HOST_THREADS_LIGHT override, bitnuc_host_pipe_info reports);
  *     the other host entry points stage through device scratch in 128 Mbase chunks;
