@@ -221,6 +221,16 @@ int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *c, bitnuc_comm *c
     // the transfer stream must not run ahead of what the caller already queued on the context's stream (d_all's previous readers)
     HIPCHK(hipEventRecord(comm->all_moved, c->stream));
     HIPCHK(hipStreamWaitEvent(comm->xfer, comm->all_moved, 0));
+    // however this call ends -- also on an error half way -- the context's stream waits for what the transfer stream was given, so
+    // that bitnuc_ctx_sync() covers it and the caller may reuse or free d_all after that sync
+    struct Join {
+        bitnuc_ctx *c;
+        bitnuc_comm *comm;
+        ~Join() {
+            if (hipEventRecord(comm->all_moved, comm->xfer) == hipSuccess) (void)hipStreamWaitEvent(c->stream, comm->all_moved, 0);
+            else (void)hipGetLastError();
+        }
+    } join{c, comm};
     for (int p = 0; p < n_chunks; ++p) {
         const size_t w0 = count * (size_t)p / (size_t)n_chunks, w1 = count * (size_t)(p + 1) / (size_t)n_chunks;
         if (w1 == w0) continue;
@@ -242,9 +252,7 @@ int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *c, bitnuc_comm *c
         if (rc) return fail_rccl(err, rc);
         if (rc_end) return fail_rccl(err, rc_end);
     }
-    HIPCHK(hipEventRecord(comm->all_moved, comm->xfer));
-    HIPCHK(hipStreamWaitEvent(c->stream, comm->all_moved, 0));
-    return BITNUC_OK;
+    return BITNUC_OK; // (~Join: the context's stream now waits for the transfer stream)
 }
 
 int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err) {
