@@ -37,11 +37,24 @@ base_counts_kernel(const unsigned long long *__restrict__ words, unsigned long l
     if ((reinterpret_cast<uintptr_t>(words) & 15) == 0) {
         const unsigned long long pairs = full >> 1;
         const u32x4 *w4 = reinterpret_cast<const u32x4 *>(words);
-#pragma unroll BITNUC_COUNTS_UNROLL
-        for (unsigned long long p = gt; p < pairs; p += nthreads) {
-            const u32x4 v = __builtin_nontemporal_load(w4 + p);
-            count_word(((unsigned long long)v.y << 32) | v.x, c, g, t);
-            count_word(((unsigned long long)v.w << 32) | v.z, c, g, t);
+        // U loads are ISSUED before the first is counted (explicit registers: with `#pragma unroll 8` on the plain loop the
+        // compiler kept ONE load in flight -- load, s_waitcnt vmcnt(0), count, load ... -- and the kernel ran at half speed);
+        // a lane past the end re-reads the last pair and counts zeros
+        constexpr int U = BITNUC_COUNTS_UNROLL;
+        for (unsigned long long p0 = gt; p0 < pairs; p0 += nthreads * U) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned long long p = p0 + (unsigned long long)u * nthreads;
+                v[u] = __builtin_nontemporal_load(w4 + (p < pairs ? p : pairs - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = p0 + (unsigned long long)u * nthreads < pairs;
+                const unsigned long long lo = in ? ((unsigned long long)v[u].y << 32) | v[u].x : 0ull, hi = in ? ((unsigned long long)v[u].w << 32) | v[u].z : 0ull;
+                count_word(lo, c, g, t);
+                count_word(hi, c, g, t);
+            }
         }
         done = pairs << 1;
     }
@@ -62,6 +75,10 @@ base_counts_kernel(const unsigned long long *__restrict__ words, unsigned long l
         part[threadIdx.x >> 6][2] = t64;
     }
     __syncthreads();
+#ifdef BITNUC_COUNTS_NO_REDUCE // timing-only experiment (tools/ab_counts_unroll.py): what the kernel costs without its arrival atomics
+    if (threadIdx.x == 0 && part[0][0] == 0x123456789ull) counts[0] = 1;
+    return;
+#endif
     if (threadIdx.x < 3) {
         unsigned long long s = 0;
         for (int i = 0; i < kBlock / 64; ++i) s += part[i][threadIdx.x];
