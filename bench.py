@@ -612,17 +612,24 @@ def run_rank(args, real_stdout, traffic):
                 def one_shot():
                     ctx.encode_dev(seqs[0], n, words[0])
                     return allgather_packed(words[0], group=ctl)
-                e2e = {}
-                for name, fn in (("one_shot", one_shot), ("overlap8", lambda: encode_allgather_overlapped(enc_chunk, nw, 8, words[0], group=ctl))):
+                def timed_e2e(fn):
                     ref_full = fn()
                     fence()
                     t = time.perf_counter()
                     for _ in range(reps):
                         full = fn()
                     fence()
-                    e2e[name + "_ms"] = round((time.perf_counter() - t) / reps * 1e3, 3)
-                    e2e[name + "_ok"] = bool(torch.equal(full, ref_full))
-                    del full, ref_full
+                    return round((time.perf_counter() - t) / reps * 1e3, 3), bool(torch.equal(full, ref_full))
+                e2e = {}
+                e2e["one_shot_ms"], e2e["one_shot_ok"] = timed_e2e(one_shot)
+                # the chunked in-place exchange rides on batched point-to-point operations: newer than the plain all-gather above, so it
+                # is a SOFT block -- a thread with a bounded wait; if it never returns the line says so and the headline stands
+                ov = bounded("encode_allgather_end_to_end.overlap8", lambda: timed_e2e(lambda: encode_allgather_overlapped(enc_chunk, nw, 8, words[0], group=ctl)),
+                             min(args.dist_timeout, 150.0), state, torch, dev)
+                if isinstance(ov, tuple):
+                    e2e["overlap8_ms"], e2e["overlap8_ok"] = ov
+                else:
+                    e2e["overlap8"] = ov
                 e2e["note"] = ("encode of this rank's 10^9-base shard + all-gather of the packed words; fabric-bound, so it cannot scale like the step; "
                                "overlap8 = 8 pieces exchanged in place by grouped point-to-point sends while the next piece is encoded")
                 extra["encode_allgather_end_to_end"] = e2e
@@ -630,9 +637,10 @@ def run_rank(args, real_stdout, traffic):
                 extra["encode_allgather_end_to_end"] = {"skipped": "needs RCCL (backend nccl on every rank)"}
             # the fabric roofline of the gather -- the per-link rate is MEASURED on this node
             # (hipMemcpyPeerAsync from rank 0's device to every other rank's device, one link at a time and all at once)
-            # while the other ranks wait at a host-side barrier; never quoted from the nominal figure alone.
-            wd.arm(args.dist_timeout, "xgmi link probe")
-            extra["allgather_packed"]["roofline"] = xgmi_roofline(args, torch, rank, world, local_rank, rehearse, extra["allgather_packed"])
+            # while the other ranks wait at a host-side barrier; never quoted from the nominal figure alone.  Soft block, as above.
+            wd.arm(max(args.dist_timeout, 240.0), "xgmi link probe")
+            extra["allgather_packed"]["roofline"] = bounded("allgather_packed.roofline", lambda: xgmi_roofline(args, torch, rank, world, local_rank, rehearse, extra["allgather_packed"]),
+                                                            min(args.dist_timeout, 120.0), state, torch, dev)
             dist.barrier()  # the default (gloo) group: host-side, the GPUs of the waiting ranks stay idle during the probe
         except Exception as e:  # noqa: BLE001 -- a failed collective is reported AND fails the run (rc 4): never a silent success
             extra.setdefault("allgather_packed", {})["error"] = repr(e)[:300]
@@ -644,7 +652,7 @@ def run_rank(args, real_stdout, traffic):
         # The same concatenation through the C ABI (what a C / Rust host calls): one-shot ncclAllGather and the chunked,
         # in-place overlap (bitnuc_encode_sharded_allgather_overlapped_dev).  It is an EXTRA block with its own RCCL
         # communicator: it runs in a thread with a bounded wait so that it can never cost the headline line.
-        if on_gpu_collectives and not args.share_gpu and state.get("rc", 0) == 0:
+        if on_gpu_collectives and not args.share_gpu and state.get("rc", 0) == 0 and not state.get("hung_thread"):
             extra["c_abi_allgather"] = c_abi_allgather_block(args, ctx, torch, dist, rank, world, seqs[0], n, state)
         else:
             extra["c_abi_allgather"] = {"skipped": "needs RCCL and one GPU per rank"}
@@ -666,6 +674,8 @@ def run_rank(args, real_stdout, traffic):
             extra["stream_probe_gb_s"] = stream_probes(ctx, torch, stream, seqs, backs, n)
         except Exception as e:  # noqa: BLE001
             extra["stream_probe_gb_s"] = {"error": repr(e)[:300]}
+    if state.get("side_blocks_stalled"):
+        extra["side_blocks_stalled"] = state["side_blocks_stalled"]  # optional blocks that never returned: reported, the measured headline stands
     emit(make_line(extra))
     rc = state.get("rc", 0)
     if state.get("hung_thread"):
@@ -682,6 +692,34 @@ def run_rank(args, real_stdout, traffic):
         dist.destroy_process_group()
         wd.disarm()
     return rc
+
+
+def bounded(name, fn, seconds, state, torch, dev):
+    """Run an OPTIONAL side block in a thread and wait at most `seconds` for it.  A block that never returns is reported
+    ({"stalled": true} in its place, its name in the line's top-level "side_blocks_stalled") and the process later leaves
+    through os._exit; the headline, measured before any of these blocks, is unaffected.  The strict rule -- a stalled
+    collective fails the run -- stays with the measurements the line cannot do without (barrier, max-reduce, allgather_packed)."""
+    box = {}
+
+    def work():
+        try:
+            if dev is not None and getattr(dev, "type", "cpu") == "cuda":
+                torch.cuda.set_device(dev)  # the current device is per-thread state
+            box["value"] = fn()
+        except Exception as e:  # noqa: BLE001
+            box["error"] = repr(e)[:300]
+
+    th = threading.Thread(target=work, daemon=True, name=name)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        state["hung_thread"] = True
+        state.setdefault("side_blocks_stalled", []).append(name)
+        print(f"[bench] side block '{name}' did not return within {seconds:.0f} s: reported in the line, headline unaffected", file=sys.stderr)
+        return {"stalled": True, "waited_s": seconds}
+    if "error" in box:
+        return {"error": box["error"]}
+    return box.get("value")
 
 
 def xgmi_roofline(args, torch, rank, world, local_rank, rehearse, ag):
@@ -741,12 +779,10 @@ def c_abi_allgather_block(args, ctx, torch, dist, rank, world, seq, n, state):
         except Exception as e:  # noqa: BLE001
             res["error"] = repr(e)[:300]
 
-    th = threading.Thread(target=work, daemon=True)
-    th.start()
-    th.join(min(args.dist_timeout, 240.0))
-    if th.is_alive():
-        state["hung_thread"] = True
-        return {"stalled": True, "note": "the C-ABI extra block did not finish within its bounded wait; the headline and the torch.distributed blocks above are unaffected"}
+    out = bounded("c_abi_allgather", work, min(args.dist_timeout, 240.0), state, torch, seq.device)
+    if isinstance(out, dict) and out.get("stalled"):
+        out["note"] = "the C-ABI extra block did not finish within its bounded wait; the headline and the torch.distributed blocks above are unaffected"
+        return out
     return res
 
 
