@@ -61,6 +61,7 @@ struct bitnuc_ctx {
     // ---- knobs (bitnuc_ctx_set_variant) ----
     int enc_variant = bitnuc_rt::kDefaultEnc, dec_variant = bitnuc_rt::kDefaultDec;
     int grid_mult = 0;                   // see grid_for()
+    unsigned dyn_lds = 0;                // evidence build: bytes of unused dynamic LDS per workgroup of the bulk codec launches (an occupancy limiter for tools/ab_occupancy.py)
     int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
     int slide_rounds = 1;                // kmer_slide_kernel: consecutive rounds per wave trip (1, 2 or 4)
     int slide2_rounds = 4;               // kmer_slide2_kernel: consecutive 1 KiB rounds per wave trip (evidence build: 1, 2 or 4; tools/ab_r03.py)

@@ -293,6 +293,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "host_pipeline")) { prev = c->host_pipeline; if (value == 0 || value == 1) c->host_pipeline = value; }
     else if (!strcmp(key, "sweep_build")) { prev = kEvidenceBuild ? 1 : 0; }
     else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }
+    else if (!strcmp(key, "dyn_lds")) { prev = (int)c->dyn_lds; if (value > 0 && !kEvidenceBuild) return -2; if (value >= 0 && value <= 64 * 1024) c->dyn_lds = (unsigned)value; }
     else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
     else if (!strcmp(key, "batch_slide")) { prev = c->batch_slide; if (value >= 0 && value <= 1) c->batch_slide = value; }
     else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && !kEvidenceBuild && value != 3) return -2; if (value >= 0 && value <= 3) c->dense_policy = value; }

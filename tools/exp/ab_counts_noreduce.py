@@ -13,7 +13,10 @@ c0.sync()
 counts = torch.zeros(4, dtype=torch.int64, device=dev)
 res = {}
 for rnd in range(6):
-    for k, c in ctxs.items():
+  for mult in (2, 4, 8, 16):
+    for k0, c in ctxs.items():
+        k = f"{k0} x{mult}"
+        c.set_variant("reduce_mult", mult)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c.base_counts_dev(words[0], n // 32, n, counts)
         a.record(stream)
@@ -21,4 +24,4 @@ for rnd in range(6):
         b.record(stream); torch.cuda.synchronize()
         if rnd: res.setdefault(k, []).append(a.elapsed_time(b) / 8)
 for k, v in res.items():
-    m = statistics.median(v); print(f"{k:14s} {m*1e3:6.1f} us  {0.25*n/m/1e6:6.0f} GB/s")
+    m = statistics.median(v); print(f"{k:18s} {m*1e3:6.1f} us  {0.25*n/m/1e6:6.0f} GB/s")
