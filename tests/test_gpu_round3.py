@@ -616,3 +616,90 @@ def test_hdist_words_coalesced_kernel_vs_oracle(ctx, oracle):
                         assert np.array_equal(out.cpu().numpy()[:n], oracle.hdist_pairs(a[shift:], np.full(n, q, dtype=np.uint64), length)), (impl, count, length, shift)
         finally:
             ctx.set_variant("hdist_words_impl", prev)
+
+
+def test_every_async_entry_point_can_be_captured_and_replayed(oracle):
+    """Launch-bound pipelines capture their inner loop once and replay it: after one warm-up call (scratch growth is an allocation)
+    every asynchronous entry point -- bulk codec, table-driven and planned batches, fixed-length reads, dense k-mers, windows,
+    scan, fused count, bulk hdist, base counts, one-query hdist, split -- is recorded into ONE hipGraph (8 error slots become
+    persistent), replayed on new data three times and compared with direct calls; then a replay on an invalid byte is reported
+    by the next sync with its byte and index, and the replay after it is clean."""
+    import torch
+    import bitnuc_amd as bn
+    dev = torch.device("cuda:0")
+    L, count = 150, 20011
+    n = L * count
+    k = 31
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        c = bn.Context(0, stream=s.cuda_stream)
+        ref_c = bn.Context(0, stream=s.cuda_stream)  # direct calls for comparison
+        seq = torch.empty(n, dtype=torch.uint8, device=dev)
+        off = torch.arange(0, count + 1, dtype=torch.int64, device=dev) * L
+        wo = torch.empty(count + 1, dtype=torch.int64, device=dev)
+        c.nucgen_dev(seq, n, 1)
+        torch.cuda.synchronize()
+        total = c.batch_word_offsets_dev(off, count, wo)
+        plan = bn.BatchPlan(c, off, count)
+        nw = (n + 31) // 32
+        nk = n // k
+
+        def buffers():
+            return dict(words=torch.zeros(nw, dtype=torch.int64, device=dev), back=torch.zeros(n, dtype=torch.uint8, device=dev),
+                        bw=torch.zeros(total, dtype=torch.int64, device=dev), bback=torch.zeros(n, dtype=torch.uint8, device=dev),
+                        pw=torch.zeros(total, dtype=torch.int64, device=dev), fw=torch.zeros(total, dtype=torch.int64, device=dev),
+                        fback=torch.zeros(n, dtype=torch.uint8, device=dev), km=torch.zeros(nk, dtype=torch.int64, device=dev),
+                        win=torch.zeros(n - k + 1, dtype=torch.int64, device=dev), dist=torch.zeros(n - k + 1, dtype=torch.uint8, device=dev),
+                        cnt=torch.zeros(1, dtype=torch.int64, device=dev), hd=torch.zeros(1, dtype=torch.int32, device=dev),
+                        bc=torch.zeros(4, dtype=torch.int64, device=dev), hq=torch.zeros(nw, dtype=torch.uint8, device=dev),
+                        sl=torch.zeros(nw, dtype=torch.int64, device=dev), sr=torch.zeros(nw, dtype=torch.int64, device=dev))
+
+        def step(cx, b, pl):
+            cx.encode_dev(seq, n, b["words"])
+            cx.decode_dev(b["words"], nw, n, b["back"])
+            cx.encode_batch_dev(seq, off, wo, count, total, b["bw"])
+            cx.decode_batch_dev(b["bw"], wo, off, count, total, b["bback"])
+            pl.encode_dev(seq, b["pw"])
+            cx.encode_fixed_dev(seq, L, L, count, b["fw"])
+            cx.decode_fixed_dev(b["fw"], L, L, count, b["fback"])
+            cx.as_2bit_batch_dev(seq, k, k, nk, b["km"])
+            cx.as_2bit_batch_dev(seq, k, 1, n - k + 1, b["win"])
+            cx.kmer_hdist_scan_dev(seq, n, k, 0x0123456789ABCDEF & ((1 << 62) - 1), b["dist"])
+            cx.kmer_hdist_count_dev(seq, n, k, 0x0123456789ABCDEF & ((1 << 62) - 1), 20, b["cnt"])
+            cx.hdist_dev(b["words"], nw, b["pw"], nw, min(n, 32 * min(nw, total)), b["hd"])
+            cx.base_counts_dev(b["words"], nw, n, b["bc"])
+            cx.hdist_query_dev(0x1111222233334444, b["words"], nw, 32, b["hq"])
+            cx.split_packed_dev(b["words"], nw, n, n // 2 + 5, b["sl"], b["sr"], canonical=True)
+
+        got, exp = buffers(), buffers()
+        ref_plan = bn.BatchPlan(ref_c, off, count)
+        step(c, got, plan)  # warm-up: scratch of the table-driven path grows here, outside the capture
+        c.sync()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            step(c, got, plan)
+        assert c.get("captured_slots") == 8  # encode, tables encode, plan encode, fixed encode, dense k-mers, windows (their tail kernels share the call's slot), scan, count
+        for seed in (2, 3, 4):
+            c.nucgen_dev(seq, n, seed)
+            for t in got.values():
+                t.zero_()
+            g.replay()
+            c.sync()
+            step(ref_c, exp, ref_plan)
+            ref_c.sync()
+            for name in got:
+                assert torch.equal(got[name], exp[name]), (seed, name)
+            assert torch.equal(got["back"], seq) and torch.equal(got["bback"], seq) and torch.equal(got["fback"], seq)
+            assert np.array_equal(got["words"][:1000].cpu().numpy().view(np.uint64), oracle.encode(seq[:32000].cpu().numpy()))
+        seq[n - 77] = ord("N")
+        g.replay()
+        with pytest.raises(bn.NucleotideError) as ei:
+            c.sync()
+        assert (ei.value.byte, ei.value.index) == (ord("N"), n - 77)
+        seq[n - 77] = ord("C")
+        g.replay()
+        c.sync()
+        plan.close()
+        ref_plan.close()
+        ref_c.close()
+        c.close()
