@@ -25,6 +25,18 @@ def shard_word_counts(n_bases, world):
     return [(b - a + 31) // 32 for a, b in (shard_range(n_bases, r, world) for r in range(world))]
 
 
+def scan_shard_range(n_bases, k, rank, world):
+    """Shard of the sliding k-mer scan / window packing (BASELINE config 5, SURVEY 8e: "scan needs a 30-base halo per shard").
+    The n_bases - k + 1 windows are split into `world` contiguous runs (32-window aligned like the codec's shards); rank r
+    reads bases [first, first + count + k - 1) -- its windows plus a (k-1)-base halo that overlaps the next shard -- and
+    produces windows [first, first + count).  Concatenating the ranks' outputs in rank order is the single-GPU result; there is
+    no exchange.  Returns (first_window, n_windows, n_bases_to_read); n_windows is 0 for a rank left without work."""
+    n_win = n_bases - k + 1 if n_bases >= k and k > 0 else 0
+    a, b = shard_range(n_win, rank, world)  # window indices
+    count = b - a
+    return a, count, (count + k - 1 if count else 0)
+
+
 def allgather_packed(local_words, counts=None, group=None):
     """All-gather per-rank packed words (1-D int64/uint64-as-int64 tensors) into the
     concatenation every rank holds.  Equal counts are one all_gather_into_tensor straight

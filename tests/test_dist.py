@@ -111,3 +111,27 @@ def test_overlapped_allgather_in_place_equals_single(world, shard_words, n_chunk
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(world))
     assert res == {r: True for r in range(world)}
+
+
+def test_scan_shards_with_halo_concatenate_to_the_single_result():
+    """the sliding scan shards like the codec, each shard reading a (k-1)-base halo; no exchange.  Every rank's
+    windows (computed here by the oracle on exactly the bytes scan_shard_range hands it) concatenate to the unsharded scan."""
+    import oracle_py
+    from bitnuc_amd.dist import scan_shard_range
+    for n, k in [(1000, 31), (31, 31), (30, 31), (100003, 31), (4096, 1), (5000, 32), (64, 17)]:
+        seq = oracle_py.nucgen(n, 0xB17C0DE)
+        q = oracle_py.as_2bit(seq[:k]) if n >= k else 0
+        whole = oracle_py.kmer_hdist_scan(seq, k, q) if n >= k else np.zeros(0, np.uint8)
+        for world in (1, 2, 3, 8):
+            parts, covered = [], 0
+            for r in range(world):
+                first, count, nread = scan_shard_range(n, k, r, world)
+                assert first == covered and (first % 32 == 0 or count == 0)
+                covered += count
+                if count:
+                    assert first + nread <= n
+                    parts.append(oracle_py.kmer_hdist_scan(seq[first:first + nread], k, q))
+                    assert len(parts[-1]) == count
+            assert covered == len(whole)
+            got = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+            assert np.array_equal(got, whole), (n, k, world)
