@@ -1077,6 +1077,28 @@ def host_path_block(ctx, torch):
         td.append(time.perf_counter() - t)
         ok = ok and bool(np.array_equal(seq, back))
     te, td = te[1:], td[1:]
+    # the k-mer host calls ride the same engine (configs 3 and 5 for data in host memory): 10^9 / 31 dense 31-mers and the scan of the same bytes
+    import ctypes as C
+    from bitnuc_amd import _lib as L
+    kerr = L.BitnucErr()
+    kcnt = n // 31
+    kout = np.zeros(kcnt, dtype=np.uint64)
+    kdist = np.zeros(n - 30, dtype=np.uint8)
+    tk, ts = [], []
+    for _ in range(3):
+        t = time.perf_counter()
+        st1 = ctx._lib.bitnuc_as_2bit_batch(ctx._h, C.c_void_p(seq.ctypes.data), 31, 31, kcnt, C.c_void_p(kout.ctypes.data), C.byref(kerr))
+        tk.append(time.perf_counter() - t)
+        t = time.perf_counter()
+        st2 = ctx._lib.bitnuc_kmer_hdist_scan(ctx._h, C.c_void_p(seq.ctypes.data), n, 31, C.c_uint64(int(kout[12345])), C.c_void_p(kdist.ctypes.data), C.byref(kerr))
+        ts.append(time.perf_counter() - t)
+    out["kmer_batch_host"] = {"gkmers_s": round(kcnt / min(tk[1:]) / 1e9, 2), "ms": round(min(tk[1:]) * 1e3, 2), "status": st1,
+                              "frac_of_pinned_h2d": round(31 * kcnt / min(tk[1:]) / 1e9 / out["pinned_h2d_gb_s"], 3),
+                              "workload": f"{kcnt} dense 31-mers from pageable host memory -> u64 in host memory (bitnuc_as_2bit_batch)"}
+    out["kmer_scan_host"] = {"gwindows_s": round((n - 30) / min(ts[1:]) / 1e9, 2), "ms": round(min(ts[1:]) * 1e3, 2), "status": st2, "self_hit_ok": bool(kdist[12345 * 31] == 0),
+                             "frac_of_pinned_d2h": round((n - 30) / min(ts[1:]) / 1e9 / out["pinned_d2h_gb_s"], 3),
+                             "workload": "sliding 31-mer pack + Hamming scan of 10^9 bases, host memory in and out (bitnuc_kmer_hdist_scan): a byte in and a byte out per window, both DMA engines at once"}
+    del kout, kdist
     ctx.set_variant("force_gpu", 1)
     try:  # how the staging pools were sized, and from what (cores visible vs the cgroup quota, measured copy rates)
         out["pipe"] = dict(ctx.host_pipe_info(), chunk_mb_env=os.environ.get("BITNUC_PIPE_CHUNK_MB"), host_threads_env=os.environ.get("BITNUC_HOST_THREADS"))

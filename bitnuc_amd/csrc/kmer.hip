@@ -5,6 +5,7 @@
 #include "runtime.h"
 #include "kmer_device.h"
 #include "host_word.h"
+#include "host_pipe.h"
 
 using namespace bitnuc_dev;
 using namespace bitnuc_rt;
@@ -161,6 +162,84 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
 #undef SCAN_LAUNCH
     return hipGetLastError();
 }
+// ---- host-pointer k-mer calls through the pipelined staging of host_pipe.h ---------------------------------------------------
+// The drop-in forms of configs 3 and 5 for a caller whose data lives in host memory (README.md:52-56's host loop over as_2bit;
+// the window idiom of src/lib.rs:170-173): PCIe-bound, so the point is to keep both DMA engines busy -- round 2's simple path
+// (one pageable hipMemcpyAsync in, kernel, one out, host wait, per 128 MiB chunk) left each idle two thirds of the time.
+// A chunk is as many k-mers as fit BOTH pinned buffers; the side that moves more bytes per k-mer (8 out against `stride` in) gets
+// the large A buffers (chunk + 64), the other the B buffers (chunk / 4 + 64).  Errors: one slot per chunk with the chunk's byte offset as index base, one drain at the end (launch order =
+// sequence order), so the first invalid examined byte of the whole call is reported; `out` past it is unspecified.
+int batch_pipelined(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t stride, size_t count, uint64_t *out, bitnuc_err *err) {
+    HostPipe *p;
+    if (int st = pipe_get(c, &p, err)) return st;
+    PipeAbort guard{c, p};
+    // the side that moves more bytes per k-mer gets the large (A) buffers: 8 bytes out against `stride` bytes in
+    const bool in_heavy = stride >= 8;
+    const size_t in_cap = in_heavy ? p->chunk : p->chunk / 4, out_cap = in_heavy ? p->chunk / 4 : p->chunk;
+    size_t per = out_cap / 8;                                             // words that fit the output buffer
+    const size_t by_bytes = in_cap > k ? (in_cap - k) / stride + 1 : 1;   // k-mers whose bytes fit the input buffer
+    if (by_bytes < per) per = by_bytes;
+    if (per >= 1024) per &= ~(size_t)1023; // whole dense items / window rounds per chunk where the chunk is large enough to care
+    if (per == 0) per = 1;
+    struct Job {
+        bitnuc_ctx *c; const uint8_t *kmers; size_t k, stride, count, per; uint64_t *out;
+        size_t nchunks; int in_kind, out_kind, in_threads, out_threads;
+        size_t items(size_t ci) const { return count - ci * per < per ? count - ci * per : per; }
+        const void *in_src(size_t ci) const { return kmers + ci * per * stride; }
+        size_t in_bytes(size_t ci) const { return (items(ci) - 1) * stride + k; }
+        void *out_dst(size_t ci) const { return out + ci * per; }
+        size_t out_bytes(size_t ci) const { return items(ci) * 8; }
+        int launch(size_t ci, const uint8_t *d_in, uint8_t *d_out, bitnuc_err *err) const {
+            unsigned long long *slot;
+            if (int st = take_slot(c, (unsigned long long)(ci * per) * stride, &slot, err)) return st;
+            HIPCHK(launch_batch(c, d_in, k, stride, items(ci), reinterpret_cast<uint64_t *>(d_out), slot));
+            return BITNUC_OK;
+        }
+    } job{c, kmers, k, stride, count, per, out, (count + per - 1) / per};
+    job.in_kind = in_heavy ? kBufA : kBufB;
+    job.out_kind = in_heavy ? kBufB : kBufA;
+    job.in_threads = in_heavy ? p->enc_in : p->dec_in;
+    job.out_threads = in_heavy ? p->enc_out : p->dec_out;
+    if (int st = pipe_run(c, p, job, err)) return st;
+    bitnuc_err e;
+    const int st = drain(c, &e);
+    if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
+    guard.dismissed = true;
+    if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    return BITNUC_OK;
+}
+
+// windows [off, off + w) of a chunk need bases [off, off + w + k - 1): consecutive chunks overlap by the k - 1 halo bases
+int scan_pipelined(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist, bitnuc_err *err) {
+    HostPipe *p;
+    if (int st = pipe_get(c, &p, err, (1u << kBufA) | (1u << kBufB) | (1u << kBufC))) return st; // input AND output are a byte per base
+    PipeAbort guard{c, p};
+    struct Job {
+        bitnuc_ctx *c; const uint8_t *ref; size_t nwin, k, per; uint64_t query; uint8_t *dist;
+        size_t nchunks; int in_kind = kBufA, out_kind = kBufC, in_threads, out_threads;
+        size_t items(size_t ci) const { return nwin - ci * per < per ? nwin - ci * per : per; }
+        const void *in_src(size_t ci) const { return ref + ci * per; }
+        size_t in_bytes(size_t ci) const { return items(ci) + k - 1; }
+        void *out_dst(size_t ci) const { return dist + ci * per; }
+        size_t out_bytes(size_t ci) const { return items(ci); }
+        int launch(size_t ci, const uint8_t *d_in, uint8_t *d_out, bitnuc_err *err) const {
+            unsigned long long *slot;
+            if (int st = take_slot(c, ci * per, &slot, err)) return st;
+            HIPCHK(launch_scan(c, d_in, in_bytes(ci), k, query, d_out, slot));
+            return BITNUC_OK;
+        }
+    } job{c, ref, n - k + 1, k, p->chunk, query, dist, (n - k + 1 + p->chunk - 1) / p->chunk}; // chunk windows + 31 halo bases fit chunk + 64
+    job.in_threads = p->enc_in;  // a byte in and a byte out per window: both sides are heavy
+    job.out_threads = p->dec_out;
+    if (int st = pipe_run(c, p, job, err)) return st;
+    bitnuc_err e;
+    const int st = drain(c, &e);
+    if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
+    guard.dismissed = true;
+    if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    return BITNUC_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -251,6 +330,7 @@ int bitnuc_as_2bit_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t s
     if (!kmers) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
     if (int st = flush_pending(c, err)) return st;
+    if (c->host_pipeline && (count - 1) * stride + k >= kPipeMin && stride <= ((size_t)1 << 20)) return batch_pipelined(c, kmers, k, stride, count, out, err);
     // chunk by k-mers so a staged chunk stays <= kHostChunk bytes
     size_t per = kHostChunk / stride;
     if (per == 0) per = 1;
@@ -280,6 +360,7 @@ int bitnuc_kmer_hdist_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k
     if (!ref || !dist) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
     if (int st = flush_pending(c, err)) return st;
+    if (c->host_pipeline && n >= kPipeMin) return scan_pipelined(c, ref, n, k, query, dist, err);
     const size_t nwin = n - k + 1;
     const size_t chunk = nwin < kHostChunk ? nwin : kHostChunk; // windows per staged chunk
     if (int st = ensure_scratch(c, 0, chunk + k + 16, err)) return st;

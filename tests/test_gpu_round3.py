@@ -7,7 +7,8 @@
   one process per GPU through init_rank, one-shot and chunked-overlap (in-place) all-gather, both exchange modes; the
   chunked form on a 1-rank communicator against the one-shot form on the one GPU every box has;
 * the pipelined host-pointer path with >= 9 chunks, so that every buffer-reuse guard of the three-stream pipeline runs
-  (BITNUC_PIPE_CHUNK_MB=1), with invalid bytes planted in late chunks;
+  (BITNUC_PIPE_CHUNK_MB=1), with invalid bytes planted in late chunks -- encode / decode and, through the same engine, the
+  host-pointer k-mer batch (dense, every window, strided with gaps) and scan;
 * the pipe's thread budget (bitnuc_host_pipe_info) and the xGMI link probe's argument rule;
 * table-driven ragged batches through the asynchronous plan emission against the explicit plan and the oracle loop.
 """
@@ -326,6 +327,35 @@ for bad in (3 * chunk + 5, 4 * chunk - 1, 7 * chunk, 9 * chunk + 33, 10 * chunk 
         assert (e.kind, e.byte, e.index) == ("InvalidBase", ord("N"), bad), (bad, e.kind, e.byte, e.index)
         assert np.array_equal(e.words, expect[: bad // 32]), bad
     assert np.array_equal(c.encode_array(s), expect)  # the pipe is idle and clean after an error
+# the k-mer host calls ride the same engine (round 3): dense 31-mers, every window, strided with gaps, the scan (input AND output a byte
+# per base: the second A-sized buffer set) -- many 1 Mi chunks each, against the oracle, then the first invalid byte from a late chunk
+k = 31
+cnt = 400_003
+km = oracle.nucgen(cnt * k, SEED + 1, 0, 2)
+assert np.array_equal(c.as_2bit_batch(km, k, k, cnt), oracle.as_2bit_batch(km, k, k, cnt))
+nwin_src = oracle.nucgen(10 * chunk + 777, SEED + 2, 0, 2)
+for kk in (31, 32, 5):
+    cw = len(nwin_src) - kk + 1
+    assert np.array_equal(c.as_2bit_batch(nwin_src, kk, 1, cw), oracle.as_2bit_batch(nwin_src, kk, 1, cw)), kk
+gap = oracle.nucgen(9 * chunk, SEED + 3, 0, 0)
+cg = (len(gap) - 21) // 40 + 1
+assert np.array_equal(c.as_2bit_batch(gap, 21, 40, cg), oracle.as_2bit_batch(gap, 21, 40, cg))
+ref = oracle.nucgen(9 * chunk + 17, SEED + 4, 0, 2)
+for kk in (31, 32, 7):
+    q = oracle.as_2bit(ref[12345:12345 + kk])
+    assert np.array_equal(c.kmer_hdist_scan(ref, kk, q), oracle.kmer_hdist_scan(ref, kk, q)), kk
+for bad in (5 * chunk + 7, 8 * chunk + 31, len(ref) - 1):
+    t = ref.copy()
+    t[bad] = ord("N")
+    if bad + chunk < len(t):
+        t[bad + chunk] = ord("X")
+    for call in (lambda: c.kmer_hdist_scan(t, 31, 0), lambda: c.as_2bit_batch(t, 31, 1, len(t) - 30)):
+        try:
+            call()
+            raise SystemExit("no error for " + str(bad))
+        except bn.NucleotideError as e:
+            assert (e.kind, e.byte, e.index) == ("InvalidBase", ord("N"), bad), (bad, e.kind, e.byte, e.index)
+assert np.array_equal(c.kmer_hdist_scan(ref, 31, 0), oracle.kmer_hdist_scan(ref, 31, 0))  # idle and clean after the errors
 c.close()
 print("pipe child ok", info)
 """
