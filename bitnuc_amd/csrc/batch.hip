@@ -3,6 +3,7 @@
 // sequences, each call padding its own last word (src/utils/mod.rs:22-25,60-62, packing/avx.rs:147-148).  Kernels: batch_device.h.
 #include "runtime.h"
 #include "batch_device.h"
+#include "host_pipe.h"
 
 using namespace bitnuc_dev;
 using namespace bitnuc_rt;
@@ -460,6 +461,49 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
     return BITNUC_OK;
 }
 
+// Host-pointer fixed-length reads through the pipelined staging engine (host_pipe.h): a chunk is as many whole reads as fit both
+// pinned buffers (their bytes in an A buffer, their words in a B buffer; decode the other way round).
+static int fixed_pipelined(bitnuc_ctx *c, bool encode, const uint8_t *seq, const uint64_t *words, size_t read_len, size_t stride, size_t count,
+                           uint64_t *out_words, uint8_t *out_seq, bitnuc_err *err) {
+    HostPipe *p;
+    if (int st = pipe_get(c, &p, err)) return st;
+    PipeAbort guard{c, p};
+    const size_t wpr = words_for(read_len);
+    size_t per = (p->chunk / 4) / (8 * wpr);
+    const size_t by_bytes = p->chunk > read_len ? (p->chunk - read_len) / stride + 1 : 0;
+    if (by_bytes < per) per = by_bytes;
+    if (per == 0) return fail(err, BITNUC_UNSUPPORTED); // a read larger than a chunk: the caller falls back to the simple path
+    struct Job {
+        bitnuc_ctx *c; bool encode; const uint8_t *seq; const uint64_t *words; size_t read_len, stride, count, per, wpr; uint64_t *out_words; uint8_t *out_seq;
+        size_t nchunks; int in_kind, out_kind, in_threads, out_threads;
+        size_t items(size_t ci) const { return count - ci * per < per ? count - ci * per : per; }
+        size_t seq_bytes(size_t ci) const { return (items(ci) - 1) * stride + read_len; }
+        const void *in_src(size_t ci) const { return encode ? static_cast<const void *>(seq + ci * per * stride) : static_cast<const void *>(words + ci * per * wpr); }
+        size_t in_bytes(size_t ci) const { return encode ? seq_bytes(ci) : items(ci) * wpr * 8; }
+        void *out_dst(size_t ci) const { return encode ? static_cast<void *>(out_words + ci * per * wpr) : static_cast<void *>(out_seq + ci * per * stride); }
+        size_t out_bytes(size_t ci) const { return encode ? items(ci) * wpr * 8 : seq_bytes(ci); }
+        int launch(size_t ci, const uint8_t *d_in, uint8_t *d_out, bitnuc_err *err) const {
+            if (encode) {
+                if (int st = bitnuc_encode_fixed_dev(c, d_in, read_len, stride, items(ci), reinterpret_cast<uint64_t *>(d_out), err)) return st;
+                set_last_slot_base(c, (unsigned long long)(ci * per) * stride); // report the index in the caller's buffer
+                return BITNUC_OK;
+            }
+            return bitnuc_decode_fixed_dev(c, reinterpret_cast<const uint64_t *>(d_in), read_len, stride, items(ci), d_out, err);
+        }
+    } job{c, encode, seq, words, read_len, stride, count, per, wpr, out_words, out_seq, (count + per - 1) / per};
+    job.in_kind = encode ? kBufA : kBufB;
+    job.out_kind = encode ? kBufB : kBufA;
+    job.in_threads = encode ? p->enc_in : p->dec_in;
+    job.out_threads = encode ? p->enc_out : p->dec_out;
+    if (int st = pipe_run(c, p, job, err)) return st;
+    bitnuc_err e;
+    const int st = drain(c, &e);
+    if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
+    guard.dismissed = true;
+    if (st != BITNUC_OK) { if (err) *err = e; return st; }
+    return BITNUC_OK;
+}
+
 int bitnuc_encode_fixed(bitnuc_ctx *c, const uint8_t *seq, size_t read_len, size_t stride, size_t count, uint64_t *out, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
@@ -467,6 +511,8 @@ int bitnuc_encode_fixed(bitnuc_ctx *c, const uint8_t *seq, size_t read_len, size
     if (stride < read_len || !seq || !out) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
     if (int st = flush_pending(c, err)) return st;
+    if (c->host_pipeline && (count - 1) * stride + read_len >= kPipeMin && stride < ((size_t)1 << 20))
+        return fixed_pipelined(c, true, seq, nullptr, read_len, stride, count, out, nullptr, err);
     const size_t wpr = words_for(read_len);
     size_t per = kHostChunk / stride; // reads per staged chunk
     if (per == 0) per = 1;
@@ -493,6 +539,11 @@ int bitnuc_decode_fixed(bitnuc_ctx *c, const uint64_t *words, size_t read_len, s
     if (count == 0 || read_len == 0) return BITNUC_OK;
     if (stride < read_len || !words || !out) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
+    // back-to-back reads only: with separators the bytes between reads are the caller's and would have to travel both ways
+    if (c->host_pipeline && stride == read_len && count * read_len >= kPipeMin && read_len < ((size_t)1 << 20)) {
+        if (int st = flush_pending(c, err)) return st;
+        return fixed_pipelined(c, false, nullptr, words, read_len, stride, count, nullptr, out, err);
+    }
     const size_t wpr = words_for(read_len);
     size_t per = kHostChunk / stride;
     if (per == 0) per = 1;

@@ -45,8 +45,9 @@
  *     chunks overlap on three streams; 8 threads copy on the side that moves 1 B per base and 4 on
  *     the other, capped by the CPUs this process may use (affinity AND cgroup quota;
  *     BITNUC_HOST_THREADS / BITNUC_HOST_THREADS_LIGHT override, bitnuc_host_pipe_info reports);
- *     bitnuc_as_2bit_batch and bitnuc_kmer_hdist_scan ride the same engine from 8 MiB of input; the other host entry
- *     points (and smaller inputs) stage through device scratch in 128 Mbase chunks;
+ *     bitnuc_as_2bit_batch, bitnuc_kmer_hdist_scan, bitnuc_encode_fixed and (back-to-back reads) bitnuc_decode_fixed
+ *     ride the same engine from 8 MiB of input; the other host entry points (and smaller inputs) stage through
+ *     device scratch in 128 Mbase chunks;
  *     "_dev" entry points take device pointers, are enqueued
  *     on the context's stream and return immediately -- data-dependent errors
  *     (InvalidBase) are latched on the device and reported by bitnuc_ctx_sync();

@@ -356,6 +356,27 @@ for bad in (5 * chunk + 7, 8 * chunk + 31, len(ref) - 1):
         except bn.NucleotideError as e:
             assert (e.kind, e.byte, e.index) == ("InvalidBase", ord("N"), bad), (bad, e.kind, e.byte, e.index)
 assert np.array_equal(c.kmer_hdist_scan(ref, 31, 0), oracle.kmer_hdist_scan(ref, 31, 0))  # idle and clean after the errors
+# fixed-length reads from host memory: back to back (encode and decode pipelined) and newline-separated (encode pipelined)
+Lr, cr = 150, 70_001
+for stride in (Lr, Lr + 1):
+    fr = oracle.nucgen(cr * stride, SEED + 5, 0, 2)
+    if stride != Lr:
+        fr[Lr::stride] = ord("\n")  # separators are never examined
+    expw = np.concatenate([oracle.encode(fr[i * stride:i * stride + Lr]) for i in range(cr)])
+    got = c.encode_fixed(fr, Lr, stride, cr)  # (count, words per read)
+    assert np.array_equal(got.reshape(-1), expw), stride
+    backr = c.decode_fixed(got, Lr, stride, out=fr.copy() if stride != Lr else None)
+    ref_up = fr & 0xDF if stride == Lr else np.where(fr == ord("\n"), fr, fr & 0xDF)
+    assert np.array_equal(backr[:cr * stride], ref_up), stride
+    bad = 61_234 * stride + 77
+    t = fr.copy()
+    t[bad] = ord("N")
+    t[bad + 5 * stride] = ord("X")
+    try:
+        c.encode_fixed(t, Lr, stride, cr)
+        raise SystemExit("no error")
+    except bn.NucleotideError as e:
+        assert (e.kind, e.byte, e.index) == ("InvalidBase", ord("N"), bad), (stride, e.byte, e.index)
 c.close()
 print("pipe child ok", info)
 """
