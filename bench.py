@@ -1032,11 +1032,27 @@ def stream_probes(ctx, torch, stream, seqs, backs, n):
             torch.cuda.synchronize()
             ms.append(a.elapsed_time(b))
         return round(moved / (statistics.median(ms[2:]) * 1e-3) / 1e9, 1)
+    def sustained(mode, moved, burst=24):
+        # one burst moves burst x ~1 GB: what is still dirty in the 256 MiB Infinity Cache when its last kernel "ends" is ~1 % of it
+        # (an isolated 1 GB fill ends with up to a quarter of its bytes not yet in HBM and reads 4-5 % high)
+        ms = []
+        for rnd in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for i in range(burst):
+                ctx.stream_probe_dev(mode, seqs[i % len(seqs)], backs[(i + 1) % len(backs)], nb)
+            b.record(stream)
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b) / burst)
+        return round(moved / (min(ms[1:]) * 1e-3) / 1e9, 1)
     nb = min(n, min(t.numel() for t in backs))
     return {"read": max(rate(m, nb) for m in (0 | 8, 0 | 8 | 32, 0)),
             "copy": max(rate(m, 2 * nb) for m in (1 | 8 | 16, 1 | 8, 1 | 16, 1)),
             "fill": max(rate(m, nb) for m in (2 | 16, 2)),
-            "note": "isolated launches, best of a few cache-policy variants per shape"}
+            "note": "isolated launches, best of a few cache-policy variants per shape",
+            "sustained": {"read": sustained(0 | 8, nb), "copy": sustained(1 | 8 | 16, 2 * nb), "fill_nt": sustained(2 | 16, nb), "fill_plain": sustained(2, nb),
+                          "note": "bursts of 24 launches over rotating buffers (~24 GB per burst): the two directions of this memory system; a kernel that reads r and "
+                                  "writes w bytes cannot finish before r / read + w / fill (DESIGN section 3)"}}
 
 
 def host_path_block(ctx, torch):
