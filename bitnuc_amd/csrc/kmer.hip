@@ -314,8 +314,10 @@ int bitnuc_hdist_dev(bitnuc_ctx *c, const uint64_t *d_a, size_t na, const uint64
     }
     if (!d_a || !d_b) return fail(err, BITNUC_UNSUPPORTED);
     const unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1;
-    const unsigned grid = (unsigned)(tiles < c->reduce_blocks ? tiles : c->reduce_blocks);
-    hdist_kernel<<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
+    const unsigned grid = (unsigned)(tiles < c->hdist_blocks ? tiles : c->hdist_blocks);
+    if (c->hdist_tiled) hdist_kernel<true><<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
+                                                 reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result, reinterpret_cast<unsigned *>(c->d_acc + 4), c->d_tickets + 1);
+    else hdist_kernel<false><<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
                                                  reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result, reinterpret_cast<unsigned *>(c->d_acc + 4), c->d_tickets + 1);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;

@@ -585,6 +585,9 @@ kmer_slide_any_kernel(const uint8_t *__restrict__ seq, unsigned k, unsigned S, u
 // ---------------------------------------------------------------------------------
 // bulk hdist: sum over words of the per-word mismatch count (u32, wraps like Rust release)
 // ---------------------------------------------------------------------------------
+// TILED (round 3 experiment, tools/ab_hdist_tiled.py): the grid-stride walk at TILE granularity -- a workgroup reads 4 consecutive
+// KiB-per-wave rows (16 KiB of each operand) per trip, like the read probe -- instead of 4 loads that are a whole grid apart.
+template <bool TILED>
 __global__ void __launch_bounds__(kBlock)
 hdist_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
              unsigned long long n_bases, uint32_t *__restrict__ result, unsigned *__restrict__ total /* zero between launches */,
@@ -602,11 +605,35 @@ hdist_kernel(const unsigned long long *__restrict__ a, const unsigned long long 
     if (al) {
         const unsigned long long pairs = full >> 1;
         const u32x4 *a4 = reinterpret_cast<const u32x4 *>(a), *b4 = reinterpret_cast<const u32x4 *>(b);
+        if constexpr (TILED) {
+            constexpr unsigned long long TILE = (unsigned long long)kBlock * 4; // 16-byte pairs per workgroup trip
+            const unsigned long long tiles = pairs / TILE;
+            for (unsigned long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+                u32x4 va[4], vb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    va[u] = __builtin_nontemporal_load(a4 + t * TILE + u * kBlock + threadIdx.x);
+                    vb[u] = __builtin_nontemporal_load(b4 + t * TILE + u * kBlock + threadIdx.x);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const u32x4 x = va[u] ^ vb[u];
+                    acc += __builtin_popcount(mismatch_bits(x.x, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.y, 0x55555555u)) +
+                           __builtin_popcount(mismatch_bits(x.z, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.w, 0x55555555u));
+                }
+            }
+            for (unsigned long long p = tiles * TILE + gt; p < pairs; p += nthreads) { // the pairs past the last whole tile
+                const u32x4 x = __builtin_nontemporal_load(a4 + p) ^ __builtin_nontemporal_load(b4 + p);
+                acc += __builtin_popcount(mismatch_bits(x.x, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.y, 0x55555555u)) +
+                       __builtin_popcount(mismatch_bits(x.z, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.w, 0x55555555u));
+            }
+        } else {
 #pragma unroll 4
-        for (unsigned long long p = gt; p < pairs; p += nthreads) {
-            const u32x4 x = __builtin_nontemporal_load(a4 + p) ^ __builtin_nontemporal_load(b4 + p);
-            acc += __builtin_popcount(mismatch_bits(x.x, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.y, 0x55555555u)) +
-                   __builtin_popcount(mismatch_bits(x.z, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.w, 0x55555555u));
+            for (unsigned long long p = gt; p < pairs; p += nthreads) {
+                const u32x4 x = __builtin_nontemporal_load(a4 + p) ^ __builtin_nontemporal_load(b4 + p);
+                acc += __builtin_popcount(mismatch_bits(x.x, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.y, 0x55555555u)) +
+                       __builtin_popcount(mismatch_bits(x.z, 0x55555555u)) + __builtin_popcount(mismatch_bits(x.w, 0x55555555u));
+            }
         }
         done = pairs << 1;
     }

@@ -57,7 +57,8 @@ struct bitnuc_ctx {
     uint32_t *d_sink = nullptr;
     unsigned long long *d_acc = nullptr; // accumulators of the single-launch reductions, zero between launches: [0..2] base_counts C,G,T; [4] hdist (u32); [5] scan count
     unsigned *d_tickets = nullptr;       // [0] base_counts, [1] hdist, [2] scan count: arrival counters, zero between launches
-    unsigned reduce_blocks = 512;
+    unsigned reduce_blocks = 512;        // base_counts: resident grid (2 workgroups per CU)
+    unsigned hdist_blocks = 256;         // bulk hdist: resident grid (1 workgroup per CU: 8 loads in flight per thread; profiles/r03_ab_hdist_grid.txt)
     // ---- knobs (bitnuc_ctx_set_variant) ----
     int enc_variant = bitnuc_rt::kDefaultEnc, dec_variant = bitnuc_rt::kDefaultDec;
     int grid_mult = 0;                   // see grid_for()
@@ -84,6 +85,7 @@ struct bitnuc_ctx {
     int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
     int scan_impl = 1;                     // 1 = line-aligned rounds of 1024 windows (kmer_scan2_kernel), 0 = rounds of 992 windows (kmer_scan_kernel)
+    int hdist_tiled = 0;                   // bulk hdist: 1 = grid-stride at tile granularity (16 KiB of each operand per workgroup trip), 0 = at thread granularity
     int hdist_words_impl = 1;              // many-pair / one-query hdist: 1 = coalesced loads + bpermute for whole 256-word tiles, 0 = four contiguous words per lane
     int force_gpu = 0;                     // 1: single-word and below-cutoff calls launch kernels too (GPU parity tests, BITNUC_FORCE_GPU=1)
     size_t host_cutoff = bitnuc_rt::kDefaultHostCutoff; // bulk host-pointer encode / hdist below this many bases run on the host (host_word.h)

@@ -210,6 +210,7 @@ int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, 
     if (rc == hipSuccess) rc = hipMemset(c->d_sink, 0, 64);
     if (const char *e = getenv("BITNUC_FORCE_GPU")) c->force_gpu = atoi(e) != 0;
     if (const char *e = getenv("BITNUC_HOST_CUTOFF")) { const long long v = atoll(e); if (v >= 0) c->host_cutoff = c->host_cutoff_decode = (size_t)v; }
+    c->hdist_blocks = (unsigned)c->num_cu;     // 1 per CU: 74.3 us for two 250 MB operands where 2 per CU take 77.2 and 4 per CU 84.4 (profiles/r03_ab_hdist_grid.txt)
     c->reduce_blocks = (unsigned)c->num_cu * 2; // a resident grid of 2 workgroups of 256 threads per CU (profiles/r01_sweep13_reduce_grid.txt: the tail of atomics + ticket grows with the grid)
     if (rc == hipSuccess) rc = hipMalloc(&c->d_acc, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_acc, 0, 64);
@@ -320,8 +321,10 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
     else if (!strcmp(key, "scan_impl")) { prev = c->scan_impl; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 0 || value == 1) c->scan_impl = value; }
     else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value >= 0 && !kEvidenceBuild && value != 4) return -2; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
+    else if (!strcmp(key, "hdist_tiled")) { prev = c->hdist_tiled; if (value == 0 || value == 1) c->hdist_tiled = value; }
     else if (!strcmp(key, "hdist_words_impl")) { prev = c->hdist_words_impl; if (value == 0 || value == 1) c->hdist_words_impl = value; }
     else if (!strcmp(key, "reduce_mult")) { prev = (int)(c->reduce_blocks / (unsigned)c->num_cu); if (value >= 1 && value <= 32) c->reduce_blocks = (unsigned)c->num_cu * (unsigned)value; }
+    else if (!strcmp(key, "hdist_mult")) { prev = (int)(c->hdist_blocks / (unsigned)c->num_cu); if (value >= 1 && value <= 32) c->hdist_blocks = (unsigned)c->num_cu * (unsigned)value; }
     else if (!strcmp(key, "num_variants")) { prev = codec_num_variants(); }
     else if (!strcmp(key, "num_cu")) { prev = c->num_cu; }
     else if (!strcmp(key, "captured_slots")) { prev = c->n_cap; }

@@ -16,6 +16,10 @@ from bitnuc_amd import build as _b
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
 ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=_b.ensure_built(sweep=True))
+ENC = int(sys.argv[1]) if len(sys.argv) > 1 else 39   # evidence-build encode variant (39 = shipped; 15 / 32 = 8 groups in flight per lane)
+DEC = int(sys.argv[2]) if len(sys.argv) > 2 else 22
+ctx.set_variant("encode", ENC)
+ctx.set_variant("decode", DEC)
 n = 10**9
 nw = n // 32
 R = 3
@@ -48,7 +52,8 @@ for rnd in range(4):
 ctx.set_variant("dyn_lds", 0)
 ctx.sync()
 assert torch.equal(seqs[0], backs[0])
-print("dyn LDS per workgroup -> workgroups per CU (encode 128 thr / decode 256 thr)   step ms   encode ms (GB/s)   decode ms (GB/s)")
+print(f"encode variant {ENC}, decode variant {DEC}")
+print("dyn LDS per workgroup -> workgroups per CU at 128 / 256 threads   step ms   encode ms (GB/s)   decode ms (GB/s)")
 for lds in SET:
     v = res[lds]
     tot, enc, dec = (statistics.median(x[k] for x in v) for k in range(3))
