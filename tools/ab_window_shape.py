@@ -45,11 +45,13 @@ for nts in (1, 0):
                 (lambda i, mode=mode: ctx.stream_probe_dev(mode, seq, outs[i & 1], nbytes), 9 * nbytes)
 cases["fill probe (nt), 8 GB"] = (lambda i: ctx.stream_probe_dev(2 | 16, None, outs[i & 1], 8 * nbytes), 8 * nbytes)
 cases["fill probe (plain), 8 GB"] = (lambda i: ctx.stream_probe_dev(2, None, outs[i & 1], 8 * nbytes), 8 * nbytes)
-for u in (1, 2, 4):
-    def real(i, u=u):
-        ctx.set_variant("slide2_rounds", u)
-        ctx.as_2bit_batch_dev(seq, 31, 1, N - 30, outs[i & 1])
-    cases[f"kmer_slide2_kernel, {u} round(s)/trip"] = (real, N + 8 * (N - 30))
+for pol in (3, 1):
+    for u in (1, 2, 4):
+        def real(i, u=u, pol=pol):
+            ctx.set_variant("slide2_rounds", u)
+            ctx.set_variant("dense_policy", pol)
+            ctx.as_2bit_batch_dev(seq, 31, 1, N - 30, outs[i & 1])
+        cases[f"kmer_slide2_kernel, {'nt' if pol & 2 else 'plain'} stores, {u} round(s)/trip"] = (real, N + 8 * (N - 30))
 res = {k: [] for k in cases}
 for rnd in range(ROUNDS + 1):
     for k, (fn, _) in cases.items():
