@@ -1,0 +1,496 @@
+"""Differential fuzzing of the device entry points against the CPU oracle (-m gpu).
+
+Seeded, so a failure reproduces; every case draws its own length / alignment / content:
+  * lengths cluster around the kernels' tile edges (32, 64, 992, 1024, 4096, 16384, 65536 +- a few) besides uniform draws;
+  * device pointers start at arbitrary byte offsets inside a larger allocation (u64 operands at arbitrary multiples of 8);
+  * every output sits between two canary regions that must come back untouched (no out-of-bounds stores, no stores to
+    separator / padding bytes the entry point does not own);
+  * inputs mix lower case in, and a share of the cases plants invalid bytes: the first one in buffer order has to come back
+    as InvalidBase(byte) with its offset, exactly as the oracle reports it (src/utils/packing/naive.rs:10-16); invalid bytes
+    OUTSIDE what an entry point reads (between strided k-mers, around a batch) must not be reported.
+All cases of one entry point run in one test (one process, one context), failures are collected and reported together.
+"""
+import numpy as np
+import pytest
+
+import bitnuc_amd as bn
+
+pytestmark = pytest.mark.gpu
+
+CANARY = 0xA5
+EDGES = (1, 31, 32, 33, 63, 64, 65, 127, 128, 255, 256, 992, 1023, 1024, 1025, 2048, 4095, 4096, 4097, 8192, 16383, 16384, 16385,
+         32768, 65535, 65536, 65537, 262144, 1 << 20)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def draw_len(rng, most, least=0):
+    r = rng.random()
+    if r < 0.45:
+        e = int(EDGES[rng.integers(len(EDGES))]) * int(rng.integers(1, 4)) + int(rng.integers(-3, 4))
+    elif r < 0.75:
+        e = int(rng.integers(least, 5000))
+    else:
+        e = int(rng.integers(least, most + 1))
+    return max(least, min(most, e))
+
+
+def draw_seq(rng, n, lower=0.25):
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+    if lower > 0 and n:
+        m = rng.random(n) < lower
+        s = np.where(m, s | 0x20, s).astype(np.uint8)
+    return s
+
+
+BAD_BYTES = (ord("N"), 0, 0xFF, ord("n"), ord("U"), ord("@"), ord("B"), 0x80 | ord("A"), ord(" "), ord("\n"))
+
+
+def plant(rng, s, lo=0, hi=None, most=3):
+    """Overwrite 1..most positions of s[lo:hi] with invalid bytes; -> sorted positions."""
+    hi = s.size if hi is None else hi
+    if hi <= lo:
+        return []
+    pos = sorted({int(rng.integers(lo, hi)) for _ in range(int(rng.integers(1, most + 1)))})
+    if rng.random() < 0.3:  # tile edges are where a per-tile first-bad reduction goes wrong
+        pos = sorted(set(pos) | {min(hi - 1, max(lo, lo + int(EDGES[rng.integers(len(EDGES))]) - int(rng.integers(0, 2))))})
+    for p in pos:
+        s[p] = BAD_BYTES[rng.integers(len(BAD_BYTES))]
+    return pos
+
+
+class Arena:
+    """A device allocation holding one operand at an arbitrary byte offset, canaries on both sides."""
+
+    def __init__(self, nbytes, offset, fill=None, pad=256):
+        torch = _torch()
+        self.pad, self.n, self.off = pad, int(nbytes), int(offset)
+        self.host = np.full(self.off + pad + self.n + pad + 64, CANARY, dtype=np.uint8)
+        if fill is not None:
+            self.host[self.lo:self.lo + self.n] = np.frombuffer(np.ascontiguousarray(fill).tobytes(), dtype=np.uint8)
+        self.t = torch.from_numpy(self.host.copy()).cuda()
+        assert self.t.data_ptr() % 256 == 0
+
+    @property
+    def lo(self):
+        return self.off + self.pad
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + self.lo
+
+    def back(self):
+        """-> (payload bytes, canaries intact?)"""
+        h = self.t.cpu().numpy()
+        ok = bool((h[:self.lo] == CANARY).all() and (h[self.lo + self.n:] == CANARY).all())
+        return h[self.lo:self.lo + self.n].copy(), ok
+
+
+def expect_error(ctx, oracle_call):
+    """Run the oracle; -> None if it succeeds else (kind, byte, index)."""
+    import oracle_py
+    try:
+        return None, oracle_call()
+    except oracle_py.OracleError as e:
+        return (e.kind, e.byte, e.index), None
+
+
+def sync_error(ctx):
+    try:
+        ctx.sync()
+        return None
+    except bn.NucleotideError as e:
+        return (e.kind, getattr(e, "byte", None), getattr(e, "index", None))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_fuzz_encode_decode_dev(ctx, oracle):
+    rng = np.random.default_rng(0xE1C0DE)
+    fails = []
+    for case in range(400):
+        n = draw_len(rng, 3_000_000, 1)
+        s = draw_seq(rng, n, lower=0.25 if case % 3 else 0.0)
+        bad = plant(rng, s) if rng.random() < 0.3 else []
+        nw = (n + 31) // 32
+        src = Arena(n, int(rng.integers(0, 64)) if case % 4 else 0, s)
+        dst = Arena(8 * nw, 8 * int(rng.integers(0, 8)))
+        ctx.encode_dev(src.ptr, n, dst.ptr)
+        got_err = sync_error(ctx)
+        want_err, want = expect_error(ctx, lambda: oracle.encode(s))
+        words, intact = dst.back()
+        tag = f"encode case {case}: n={n} src+{src.off} dst+{dst.off} bad={bad[:3]}"
+        if not intact:
+            fails.append(tag + ": canary overwritten")
+        if want_err is not None:
+            if got_err != (want_err[0], want_err[1], bad[0]):
+                fails.append(tag + f": error {got_err}, oracle {want_err}")
+            continue
+        if got_err is not None:
+            fails.append(tag + f": unexpected error {got_err}")
+            continue
+        words = words.view(np.uint64)
+        if not np.array_equal(words, want):
+            fails.append(tag + f": first differing word {int(np.flatnonzero(words != want)[0])}")
+            continue
+        # decode what was encoded: n_bases anywhere in the last word's range, sometimes more words than needed
+        nb = n if rng.random() < 0.6 else int(rng.integers(max(1, 32 * (nw - 1) + 1), 32 * nw + 1))
+        extra = int(rng.integers(0, 3))
+        wsrc = Arena(8 * (nw + extra), 8 * int(rng.integers(0, 8)), np.concatenate([want, np.full(extra, 0xFFFFFFFFFFFFFFFF, np.uint64)]))
+        out = Arena(nb, int(rng.integers(0, 64)) if case % 5 else 0)
+        ctx.decode_dev(wsrc.ptr, nw + extra, nb, out.ptr)
+        got_err = sync_error(ctx)
+        text, intact = out.back()
+        tag = f"decode case {case}: n_bases={nb} words={nw}+{extra} src+{wsrc.off} dst+{out.off}"
+        if got_err is not None:
+            fails.append(tag + f": unexpected error {got_err}")
+        elif not intact:
+            fails.append(tag + ": canary overwritten")
+        elif not np.array_equal(text, oracle.decode(want, nb)):
+            fails.append(tag + f": first differing byte {int(np.flatnonzero(text != oracle.decode(want, nb))[0])}")
+    assert not fails, "\n".join(fails[:20]) + f"\n({len(fails)} failing cases)"
+
+
+def test_fuzz_decode_short_buffer(ctx):
+    """n_words < ceil(n_bases / 32) is InvalidLength(n_bases) before anything is launched (src/utils/unpacking/mod.rs:42-45)."""
+    rng = np.random.default_rng(0x5407)
+    for _ in range(20):
+        nb = draw_len(rng, 100_000, 33)
+        need = (nb + 31) // 32
+        have = int(rng.integers(0, need))
+        w = Arena(8 * max(have, 1), 0, np.zeros(max(have, 1), np.uint64))
+        out = Arena(nb, 0)
+        with pytest.raises(bn.NucleotideError) as ei:
+            ctx.decode_dev(w.ptr, have, nb, out.ptr)
+            ctx.sync()
+        assert (ei.value.kind, ei.value.len) == ("InvalidLength", nb)
+        assert out.back()[1] and not (out.back()[0] != CANARY).any()
+
+
+def test_fuzz_kmer_batch_dev(ctx, oracle):
+    rng = np.random.default_rng(0xBA7C4)
+    fails = []
+    for case in range(600):
+        k = int(rng.integers(1, 33)) if case % 3 else (31, 32, 21, 16)[case % 4]
+        r = rng.random()
+        if r < 0.35:
+            stride = k  # dense
+        elif r < 0.6:
+            stride = (1, 2, 4, 8, 16)[rng.integers(5)]  # overlapping windows (the slide kernels for the power-of-two strides)
+        elif r < 0.8:
+            stride = k + int(rng.integers(1, 40))  # records with separators
+        else:
+            stride = int(rng.integers(1, 70))
+        count = draw_len(rng, 200_000, 1)
+        n = (count - 1) * stride + k
+        s = draw_seq(rng, n + 8)[:n]
+        gaps_bad = False
+        if stride > k and rng.random() < 0.5:  # separators are not bases: '\n', '>' ... must never be looked at
+            m = (np.arange(n) % stride) >= k
+            s[m] = np.frombuffer(b"\n>N\x00", dtype=np.uint8)[rng.integers(0, 4, int(m.sum()))]
+            gaps_bad = True
+        bad = []
+        if rng.random() < 0.3:
+            cand = plant(rng, s.copy())  # positions only
+            bad = [p for p in cand if stride <= k or (p % stride) < k]
+            for p in bad:
+                s[p] = BAD_BYTES[rng.integers(len(BAD_BYTES))]
+        src = Arena(n, int(rng.integers(0, 64)) if case % 4 else 0, s)
+        dst = Arena(8 * count, 8 * int(rng.integers(0, 8)))
+        ctx.as_2bit_batch_dev(src.ptr, k, stride, count, dst.ptr)
+        got_err = sync_error(ctx)
+        want_err, want = expect_error(ctx, lambda: oracle.as_2bit_batch(s, k, stride, count))
+        words, intact = dst.back()
+        tag = f"batch case {case}: k={k} stride={stride} count={count} src+{src.off} dst+{dst.off} bad={bad[:3]} gaps_bad={gaps_bad}"
+        if not intact:
+            fails.append(tag + ": canary overwritten")
+        if want_err is not None:
+            if got_err is None or got_err[:2] != want_err[:2] or got_err[2] != want_err[2]:
+                fails.append(tag + f": error {got_err}, oracle {want_err}")
+            continue
+        if got_err is not None:
+            fails.append(tag + f": unexpected error {got_err}")
+        elif not np.array_equal(words.view(np.uint64), want):
+            fails.append(tag + f": first differing k-mer {int(np.flatnonzero(words.view(np.uint64) != want)[0])}")
+    assert not fails, "\n".join(fails[:20]) + f"\n({len(fails)} failing cases)"
+
+
+def test_fuzz_scan_dev(ctx, oracle):
+    torch = _torch()
+    rng = np.random.default_rng(0x5CA4)
+    fails = []
+    for case in range(400):
+        k = int(rng.integers(1, 33)) if case % 3 else 31
+        n = draw_len(rng, 2_000_000, k)
+        s = draw_seq(rng, n)
+        bad = plant(rng, s) if rng.random() < 0.3 else []
+        query = int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 4)) << 62)  # bits above 2k are ignored (scalar.rs:26-31)
+        nwin = n - k + 1
+        src = Arena(n, int(rng.integers(0, 64)) if case % 4 else 0, s)
+        dst = Arena(nwin, int(rng.integers(0, 64)) if case % 5 else 0)
+        ctx.kmer_hdist_scan_dev(src.ptr, n, k, query, dst.ptr)
+        got_err = sync_error(ctx)
+        want_err, want = expect_error(ctx, lambda: oracle.kmer_hdist_scan(s, k, query))
+        dist, intact = dst.back()
+        tag = f"scan case {case}: n={n} k={k} src+{src.off} dst+{dst.off} bad={bad[:3]}"
+        if not intact:
+            fails.append(tag + ": canary overwritten")
+        if want_err is not None:
+            if got_err != (want_err[0], want_err[1], bad[0]):
+                fails.append(tag + f": error {got_err}, oracle {want_err}")
+            continue
+        if got_err is not None:
+            fails.append(tag + f": unexpected error {got_err}")
+            continue
+        if not np.array_equal(dist, want):
+            fails.append(tag + f": first differing window {int(np.flatnonzero(dist != want)[0])}")
+            continue
+        tau = int(rng.integers(0, k + 1))
+        cnt = torch.full((3,), -1, dtype=torch.int64, device="cuda")
+        ctx.kmer_hdist_count_dev(src.ptr, n, k, query, tau, cnt[1:].data_ptr())
+        ctx.sync()
+        c = cnt.cpu().numpy()
+        if (int(c[0]), int(c[1]), int(c[2])) != (-1, int((want <= tau).sum()), -1):
+            fails.append(tag + f": count(d <= {tau}) = {c.tolist()}, oracle {int((want <= tau).sum())}")
+    assert not fails, "\n".join(fails[:20]) + f"\n({len(fails)} failing cases)"
+
+
+def test_fuzz_packed_word_kernels(ctx, oracle):
+    """hdist (bulk), base_counts, hdist_pairs / hdist_query, split_packed on random packed buffers."""
+    torch = _torch()
+    rng = np.random.default_rng(0x9ACCED)
+    fails = []
+    for case in range(300):
+        nb = draw_len(rng, 4_000_000, 1)
+        nw = (nb + 31) // 32
+        ea, eb = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        a = rng.integers(0, 1 << 63, nw + ea, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, nw + ea, dtype=np.uint64)
+        b = a.copy()[:nw]
+        flips = rng.integers(0, nw, max(1, nw // int(rng.integers(1, 50))))
+        b[flips] ^= rng.integers(0, 1 << 63, flips.size, dtype=np.uint64)
+        b = np.concatenate([b, rng.integers(0, 1 << 63, eb, dtype=np.uint64)])
+        A = Arena(8 * a.size, 8 * int(rng.integers(0, 8)), a)
+        B = Arena(8 * b.size, 8 * int(rng.integers(0, 8)), b)
+        tag = f"packed case {case}: n_bases={nb} words={nw}+{ea}/{eb} a+{A.off} b+{B.off}"
+        res = torch.full((3,), 0xDEAD, dtype=torch.int32, device="cuda")
+        ctx.hdist_dev(A.ptr, a.size, B.ptr, b.size, nb, res[1:].data_ptr())
+        ctx.sync()
+        r = res.cpu().numpy()
+        if (int(r[0]), int(r[1]), int(r[2])) != (0xDEAD, oracle.hdist(a, b, nb), 0xDEAD):
+            fails.append(tag + f": hdist {r.tolist()}, oracle {oracle.hdist(a, b, nb)}")
+        cnt = Arena(32, 0)
+        ctx.base_counts_dev(A.ptr, a.size, nb, cnt.ptr)
+        ctx.sync()
+        c, intact = cnt.back()
+        if not intact or [int(x) for x in c.view(np.uint64)] != oracle.base_counts(a, nb):
+            fails.append(tag + f": base_counts {c.view(np.uint64).tolist()}, oracle {oracle.base_counts(a, nb)} canaries {intact}")
+        # many pairs / one query, word length 1..32
+        length = int(rng.integers(1, 33))
+        m = min(a.size, b.size)
+        d = Arena(m, int(rng.integers(0, 64)) if case % 3 else 0)
+        ctx.hdist_pairs_dev(A.ptr, B.ptr, m, length, d.ptr)
+        ctx.sync()
+        got, intact = d.back()
+        if not intact or not np.array_equal(got, oracle.hdist_pairs(a[:m], b[:m], length)):
+            fails.append(tag + f": hdist_pairs len={length} dst+{d.off} differs (canaries {intact})")
+        q = int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))
+        d = Arena(m, int(rng.integers(0, 64)) if case % 3 else 0)
+        ctx.hdist_query_dev(q, A.ptr, m, length, d.ptr)
+        ctx.sync()
+        got, intact = d.back()
+        if not intact or not np.array_equal(got, oracle.hdist_pairs(a[:m], np.full(m, q, np.uint64), length)):
+            fails.append(tag + f": hdist_query len={length} dst+{d.off} differs (canaries {intact})")
+        # split_packed at an arbitrary base index, as the reference leaves its two buffers (functions/split.rs:63-99)
+        idx = int(rng.integers(0, nb + 1)) if case % 4 else (0, nb, min(nb, 32), max(0, nb - 32))[(case // 4) % 4]
+        try:
+            wl, wr = oracle.split_packed(a[:nw], nb, idx)
+        except Exception as e:  # the oracle refuses what the reference refuses
+            wl = wr = None
+            want_kind = getattr(e, "kind", type(e).__name__)
+        if wl is not None:
+            nl, nr = ctx.split_packed_sizes(nw, nb, idx)
+            if (nl, nr) != (wl.size, wr.size):
+                fails.append(tag + f": split sizes {(nl, nr)} oracle {(wl.size, wr.size)} idx={idx}")
+                continue
+            Lb, Rb = Arena(8 * nl, 8 * int(rng.integers(0, 8))), Arena(8 * nr, 8 * int(rng.integers(0, 8)))
+            ctx.split_packed_dev(A.ptr, nw, nb, idx, Lb.ptr, Rb.ptr)
+            ctx.sync()
+            (gl, il), (gr, ir) = Lb.back(), Rb.back()
+            if not (il and ir):
+                fails.append(tag + f": split idx={idx} canary overwritten")
+            elif not (np.array_equal(gl.view(np.uint64), wl) and np.array_equal(gr.view(np.uint64), wr)):
+                fails.append(tag + f": split idx={idx} differs")
+        else:
+            try:
+                ctx.split_packed_sizes(nw, nb, idx)
+                fails.append(tag + f": split idx={idx} accepted, oracle {want_kind}")
+            except bn.NucleotideError:
+                pass
+    assert not fails, "\n".join(fails[:20]) + f"\n({len(fails)} failing cases)"
+
+
+def _ragged_case(rng, case):
+    style = case % 5
+    if style == 0:
+        count = int(rng.integers(1, 40_000))
+        lens = rng.integers(0, 200, count)
+    elif style == 1:
+        count = int(rng.integers(1, 3000))
+        lens = rng.integers(100, 400, count)
+        lens[rng.integers(0, count, max(1, count // 20))] = 0  # empty reads keep a zero-word slot
+    elif style == 2:
+        count = int(rng.integers(1, 200))
+        lens = rng.integers(0, 60_000, count)  # reads longer than a tile
+    elif style == 3:
+        count = int(rng.integers(1, 20_000))
+        lens = np.full(count, (150, 32, 31, 33, 64, 1)[rng.integers(6)])
+    else:
+        count = int(rng.integers(1, 2000))
+        lens = np.where(rng.random(count) < 0.02, rng.integers(10_000, 100_000, count), rng.integers(0, 300, count))
+    off = np.zeros(count + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens.astype(np.uint64))
+    return count, off
+
+
+def test_fuzz_ragged_batch_dev(ctx, oracle):
+    """encode_batch_dev / decode_batch_dev (tables) and the same batch through a layout plan."""
+    torch = _torch()
+    rng = np.random.default_rng(0x4A66ED)
+    fails = []
+    for case in range(200):
+        count, off = _ragged_case(rng, case)
+        pre = int(rng.integers(0, 100)) if case % 3 else 0
+        total = int(off[-1])
+        s = draw_seq(rng, total)
+        buf = np.concatenate([np.full(pre, ord("N"), np.uint8), s, np.full(7, ord("N"), np.uint8)])  # neighbours are not bases
+        off2 = off + np.uint64(pre)
+        bad = []
+        if rng.random() < 0.3 and total:
+            bad = [p + pre for p in plant(rng, s)]
+            buf[pre:pre + total] = s
+        want_wo = np.zeros(count + 1, dtype=np.uint64)
+        want_wo[1:] = np.cumsum((np.diff(off) + np.uint64(31)) // np.uint64(32))
+        tw = int(want_wo[-1])
+        want_err = None
+        try:
+            want = np.concatenate([oracle.encode(s[int(off[i]):int(off[i + 1])]) if off[i + 1] > off[i] else np.zeros(0, np.uint64) for i in range(count)]) if count < 5000 else None
+        except Exception as e:
+            want_err, want = ("InvalidBase", e.byte, None), None
+        if want is None and want_err is None and not bad:  # large counts: the vectorised restatement of the same definition
+            codes = ((s >> 1) & 3).astype(np.uint64)  # A/a 0, C/c 1, T/t 2, G/g 3 -> fix the G/T order below
+            codes = np.where(codes == 2, np.uint64(3), np.where(codes == 3, np.uint64(2), codes))
+            want = np.zeros(tw, dtype=np.uint64)
+            read = np.repeat(np.arange(count), np.diff(off).astype(np.int64))
+            inpos = np.arange(total, dtype=np.int64) - off[read].astype(np.int64)
+            np.bitwise_or.at(want, want_wo[read].astype(np.int64) + inpos // 32, codes << (np.uint64(2) * (inpos % 32).astype(np.uint64)))
+        src_off = int(rng.integers(0, 64)) if case % 4 else 0
+        S = Arena(buf.size, src_off, buf)
+        d_off = torch.from_numpy(off2.view(np.int64)).cuda()
+        d_wo = torch.full((count + 3,), -7, dtype=torch.int64, device="cuda")
+        tag = f"ragged case {case}: count={count} bases={total} pre={pre} src+{src_off} bad={bad[:3]}"
+        got_tw = ctx.batch_word_offsets_dev(d_off, count, d_wo[1:].data_ptr())
+        wo_back = d_wo.cpu().numpy()
+        if got_tw != tw or not np.array_equal(wo_back[1:count + 2].view(np.uint64), want_wo) or wo_back[0] != -7 or wo_back[-1] != -7:
+            fails.append(tag + f": word offsets differ (total {got_tw} vs {tw})")
+            continue
+        plan = bn.BatchPlan(ctx, d_off, count)
+        if plan.total_words != tw:
+            fails.append(tag + f": plan total {plan.total_words} vs {tw}")
+        for via in ("tables", "plan"):
+            W = Arena(8 * tw, 8 * int(rng.integers(0, 8)))
+            if via == "tables":
+                ctx.encode_batch_dev(S.ptr, d_off, d_wo[1:].data_ptr(), count, tw, W.ptr)
+            else:
+                plan.encode_dev(S.ptr, W.ptr)
+            got_err = sync_error(ctx)
+            words, intact = W.back()
+            if not intact:
+                fails.append(tag + f" [{via}]: encode canary overwritten")
+            if bad:
+                if got_err is None or got_err[0] != "InvalidBase" or got_err[2] != bad[0] or got_err[1] != int(buf[bad[0]]):
+                    fails.append(tag + f" [{via}]: error {got_err}, expected InvalidBase({int(buf[bad[0]])}) at {bad[0]}")
+                continue
+            if got_err is not None:
+                fails.append(tag + f" [{via}]: unexpected error {got_err}")
+                continue
+            if want is not None and not np.array_equal(words.view(np.uint64), want):
+                fails.append(tag + f" [{via}]: first differing word {int(np.flatnonzero(words.view(np.uint64) != want)[0])}")
+                continue
+            # decode back into a buffer whose neighbours and (none here) gaps must stay as they were
+            Wsrc = Arena(8 * tw, 8 * int(rng.integers(0, 8)), words.view(np.uint64))
+            out_off = int(rng.integers(0, 64)) if case % 2 else 0
+            # the decode writes [off2[0], off2[-1]) relative to its base pointer: give it the whole buffer extent
+            D = Arena(buf.size, out_off)
+            if via == "tables":
+                ctx.decode_batch_dev(Wsrc.ptr, d_wo[1:].data_ptr(), d_off, count, tw, D.ptr)
+            else:
+                plan.decode_dev(Wsrc.ptr, D.ptr)
+            got_err = sync_error(ctx)
+            text, intact = D.back()
+            if got_err is not None or not intact:
+                fails.append(tag + f" [{via}]: decode error {got_err} canaries {intact}")
+            elif not (np.array_equal(text[pre:pre + total], s & 0xDF) and (text[:pre] == CANARY).all() and (text[pre + total:] == CANARY).all()):
+                fails.append(tag + f" [{via}]: decode differs or wrote outside [offsets[0], offsets[-1])")
+        plan.close()
+    assert not fails, "\n".join(fails[:20]) + f"\n({len(fails)} failing cases)"
+
+
+def test_fuzz_fixed_reads_dev(ctx, oracle):
+    rng = np.random.default_rng(0xF17ED)
+    fails = []
+    for case in range(300):
+        L = int(rng.integers(1, 700)) if case % 3 else (150, 32, 31, 33, 64, 100, 250, 151)[(case // 3) % 8]
+        stride = L if rng.random() < 0.5 else L + int(rng.integers(1, 9))
+        count = draw_len(rng, max(1, 3_000_000 // max(L, 8)), 1)
+        n = (count - 1) * stride + L
+        s = draw_seq(rng, n)
+        if stride > L:
+            s[(np.arange(n) % stride) >= L] = ord("\n")  # separators: never read as bases, never overwritten by the decode
+        bad = []
+        if rng.random() < 0.3:
+            cand = plant(rng, s.copy())
+            bad = [p for p in cand if (p % stride) < L]
+            for p in bad:
+                s[p] = BAD_BYTES[rng.integers(len(BAD_BYTES))]
+        wpr = (L + 31) // 32
+        S = Arena(n, int(rng.integers(0, 64)) if case % 4 else 0, s)
+        W = Arena(8 * wpr * count, 8 * int(rng.integers(0, 8)))
+        ctx.encode_fixed_dev(S.ptr, L, stride, count, W.ptr)
+        got_err = sync_error(ctx)
+        words, intact = W.back()
+        tag = f"fixed case {case}: L={L} stride={stride} count={count} src+{S.off} bad={bad[:3]}"
+        if not intact:
+            fails.append(tag + ": encode canary overwritten")
+        if bad:
+            if got_err is None or got_err[0] != "InvalidBase" or got_err[2] != bad[0] or got_err[1] != int(s[bad[0]]):
+                fails.append(tag + f": error {got_err}, expected InvalidBase({int(s[bad[0]])}) at {bad[0]}")
+            continue
+        if got_err is not None:
+            fails.append(tag + f": unexpected error {got_err}")
+            continue
+        rows = words.view(np.uint64).reshape(count, wpr)
+        if L <= 32:
+            want = oracle.as_2bit_batch(s, L, stride, count).reshape(count, 1)
+        else:
+            pick = sorted({0, count - 1, *[int(x) for x in rng.integers(0, count, 40)]})
+            want = None
+            for r in pick:
+                if not np.array_equal(rows[r], oracle.encode(s[r * stride:r * stride + L])):
+                    fails.append(tag + f": read {r} differs")
+                    break
+        if want is not None and not np.array_equal(rows, want):
+            fails.append(tag + f": first differing read {int(np.flatnonzero((rows != want).any(axis=1))[0])}")
+            continue
+        Wsrc = Arena(8 * wpr * count, 8 * int(rng.integers(0, 8)), words.view(np.uint64))
+        D = Arena(n, int(rng.integers(0, 64)) if case % 2 else 0, np.full(n, ord("#"), np.uint8))
+        ctx.decode_fixed_dev(Wsrc.ptr, L, stride, count, D.ptr)
+        got_err = sync_error(ctx)
+        text, intact = D.back()
+        expect = np.where((np.arange(n) % stride) < L, s & 0xDF, ord("#")).astype(np.uint8)
+        if got_err is not None or not intact:
+            fails.append(tag + f": decode error {got_err} canaries {intact}")
+        elif not np.array_equal(text, expect):
+            fails.append(tag + f": decode differs at byte {int(np.flatnonzero(text != expect)[0])} (separators must stay)")
+    assert not fails, "\n".join(fails[:20]) + f"\n({len(fails)} failing cases)"
