@@ -494,3 +494,206 @@ def test_fuzz_fixed_reads_dev(ctx, oracle):
         elif not np.array_equal(text, expect):
             fails.append(tag + f": decode differs at byte {int(np.flatnonzero(text != expect)[0])} (separators must stay)")
     assert not fails, "\n".join(fails[:20]) + f"\n({len(fails)} failing cases)"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# host-pointer entry points: the three size regimes (host code below the cutoff, one staged launch, the chunked three-stream
+# pipeline) with caller buffers at arbitrary addresses between canaries.  A fresh process, so that BITNUC_PIPE_CHUNK_MB=1
+# makes an 8..14 Mi-base call run 8..14 chunks (every pinned / device buffer reused several times per call).
+_HOST_FUZZ_CHILD = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import bitnuc_amd as bn
+from bitnuc_amd import _lib as L
+import oracle_py as oracle
+from test_gpu_fuzz import draw_seq, plant, CANARY
+
+ctx = bn.Context(0)
+lib = ctx._lib
+rng = np.random.default_rng(0x4057F)
+CUT = (512 << 10, 1 << 20, 8 << 20)
+fails = []
+
+
+def draw_n(least=1):
+    r = rng.random()
+    if r < 0.3:
+        return max(least, int(rng.integers(least, 3000)))
+    if r < 0.75:
+        return max(least, int(CUT[rng.integers(3)]) + int(rng.integers(-70, 70)))
+    if r < 0.9:
+        return int(rng.integers(least, 2 << 20))
+    return int(rng.integers(8 << 20, 14 << 20))
+
+
+class HostBuf:
+    def __init__(self, nbytes, offset, fill=None):
+        self.raw = np.full(nbytes + offset + 256 + 320, CANARY, dtype=np.uint8)
+        base = (-self.raw.ctypes.data) % 64  # offsets are relative to a 64-byte line
+        self.lo, self.n = base + 128 + offset, nbytes
+        if fill is not None:
+            self.raw[self.lo:self.lo + nbytes] = np.frombuffer(np.ascontiguousarray(fill).tobytes(), dtype=np.uint8)
+    @property
+    def ptr(self):
+        return C.c_void_p(self.raw.ctypes.data + self.lo)
+    def back(self):
+        ok = bool((self.raw[:self.lo] == CANARY).all() and (self.raw[self.lo + self.n:] == CANARY).all())
+        return self.raw[self.lo:self.lo + self.n], ok
+
+
+def status(st, err):
+    if st == L.OK:
+        return None
+    return (st, int(err.byte), int(err.index), int(err.value))
+
+
+for case in range(150):
+    n = draw_n()
+    s = draw_seq(rng, n, lower=0.25 if case % 3 else 0.0)
+    bad = plant(rng, s) if rng.random() < 0.3 else []
+    nw = (n + 31) // 32
+    src = HostBuf(n, int(rng.integers(0, 64)) if case % 4 else 0, s)
+    dst = HostBuf(8 * nw, 8 * int(rng.integers(0, 8)))
+    got_nw, err = C.c_size_t(0), L.BitnucErr()
+    st = lib.bitnuc_encode(ctx._h, src.ptr, n, dst.ptr, C.byref(got_nw), C.byref(err))
+    words, intact = dst.back()
+    tag = f"host encode case {case}: n={n} src+{src.lo % 64} dst+{dst.lo % 64} bad={bad[:3]}"
+    if not intact:
+        fails.append(tag + ": canary overwritten")
+    try:
+        want = oracle.encode(s)
+    except oracle.OracleError as e:
+        # the reference's Vec holds the words of the chunks before the failing one (packing/avx.rs:139-141)
+        if st != L.INVALID_BASE or (int(err.byte), int(err.index)) != (e.byte, bad[0]) or got_nw.value != e.words.size \
+                or not np.array_equal(words.view(np.uint64)[:got_nw.value], e.words):
+            fails.append(tag + f": status {status(st, err)} words {got_nw.value}, oracle byte {e.byte} words {e.words.size}")
+        continue
+    if st != L.OK or got_nw.value != nw or not np.array_equal(words.view(np.uint64), want):
+        fails.append(tag + f": status {status(st, err)} words {got_nw.value}/{nw}")
+        continue
+    nb = n if rng.random() < 0.6 else int(rng.integers(max(1, 32 * (nw - 1) + 1), 32 * nw + 1))
+    extra = int(rng.integers(0, 3))
+    wsrc = HostBuf(8 * (nw + extra), 8 * int(rng.integers(0, 8)), np.concatenate([want, np.full(extra, 0xFFFFFFFFFFFFFFFF, np.uint64)]))
+    out = HostBuf(nb, int(rng.integers(0, 64)) if case % 5 else 0)
+    st = lib.bitnuc_decode(ctx._h, wsrc.ptr, nw + extra, nb, out.ptr, C.byref(err))
+    text, intact = out.back()
+    if st != L.OK or not intact or not np.array_equal(text, oracle.decode(want, nb)):
+        fails.append(f"host decode case {case}: n_bases={nb} words={nw}+{extra} dst+{out.lo % 64}: status {status(st, err)} canaries {intact}")
+
+for case in range(120):
+    k = int(rng.integers(1, 33)) if case % 3 else (31, 32, 21, 16)[case % 4]
+    r = rng.random()
+    stride = k if r < 0.35 else ((1, 2, 4, 8, 16)[rng.integers(5)] if r < 0.6 else (k + int(rng.integers(1, 40)) if r < 0.8 else int(rng.integers(1, 70))))
+    n = draw_n(k)
+    count = (n - k) // stride + 1
+    n = (count - 1) * stride + k
+    s = draw_seq(rng, n)
+    if stride > k and rng.random() < 0.5:
+        m = (np.arange(n) % stride) >= k
+        s[m] = np.frombuffer(b"\n>N\x00", dtype=np.uint8)[rng.integers(0, 4, int(m.sum()))]
+    bad = []
+    if rng.random() < 0.3:
+        bad = [p for p in plant(rng, s.copy()) if stride <= k or (p % stride) < k]
+        for p in bad:
+            s[p] = ord("N")
+    src = HostBuf(n, int(rng.integers(0, 64)) if case % 4 else 0, s)
+    dst = HostBuf(8 * count, 8 * int(rng.integers(0, 8)))
+    err = L.BitnucErr()
+    st = lib.bitnuc_as_2bit_batch(ctx._h, src.ptr, k, stride, count, dst.ptr, C.byref(err))
+    words, intact = dst.back()
+    tag = f"host batch case {case}: k={k} stride={stride} count={count} src+{src.lo % 64} bad={bad[:3]}"
+    if not intact:
+        fails.append(tag + ": canary overwritten")
+    try:
+        want = oracle.as_2bit_batch(s, k, stride, count)
+    except oracle.OracleError as e:
+        if st != L.INVALID_BASE or (int(err.byte), int(err.index)) != (e.byte, e.index):
+            fails.append(tag + f": status {status(st, err)}, oracle byte {e.byte} index {e.index}")
+        continue
+    if st != L.OK or not np.array_equal(words.view(np.uint64), want):
+        fails.append(tag + f": status {status(st, err)} or words differ")
+
+for case in range(80):
+    k = int(rng.integers(1, 33)) if case % 3 else 31
+    n = draw_n(k)
+    s = draw_seq(rng, n)
+    bad = plant(rng, s) if rng.random() < 0.3 else []
+    query = int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 4)) << 62)
+    src = HostBuf(n, int(rng.integers(0, 64)) if case % 4 else 0, s)
+    dst = HostBuf(n - k + 1, int(rng.integers(0, 64)) if case % 5 else 0)
+    err = L.BitnucErr()
+    st = lib.bitnuc_kmer_hdist_scan(ctx._h, src.ptr, n, k, C.c_uint64(query), dst.ptr, C.byref(err))
+    dist, intact = dst.back()
+    tag = f"host scan case {case}: n={n} k={k} src+{src.lo % 64} dst+{dst.lo % 64} bad={bad[:3]}"
+    if not intact:
+        fails.append(tag + ": canary overwritten")
+    try:
+        want = oracle.kmer_hdist_scan(s, k, query)
+    except oracle.OracleError as e:
+        if st != L.INVALID_BASE or (int(err.byte), int(err.index)) != (e.byte, bad[0]):
+            fails.append(tag + f": status {status(st, err)}, oracle byte {e.byte}")
+        continue
+    if st != L.OK or not np.array_equal(dist, want):
+        fails.append(tag + f": status {status(st, err)} or distances differ")
+
+for case in range(60):
+    Lr = int(rng.integers(1, 700)) if case % 3 else (150, 32, 31, 33, 64, 100, 250, 151)[(case // 3) % 8]
+    stride = Lr if rng.random() < 0.5 else Lr + int(rng.integers(1, 9))
+    n = draw_n(Lr)
+    count = (n - Lr) // stride + 1
+    n = (count - 1) * stride + Lr
+    s = draw_seq(rng, n)
+    if stride > Lr:
+        s[(np.arange(n) % stride) >= Lr] = ord("\n")
+    wpr = (Lr + 31) // 32
+    src = HostBuf(n, int(rng.integers(0, 64)) if case % 4 else 0, s)
+    W = HostBuf(8 * wpr * count, 8 * int(rng.integers(0, 8)))
+    err = L.BitnucErr()
+    st = lib.bitnuc_encode_fixed(ctx._h, src.ptr, Lr, stride, count, W.ptr, C.byref(err))
+    words, intact = W.back()
+    tag = f"host fixed case {case}: L={Lr} stride={stride} count={count} src+{src.lo % 64}"
+    rows = words.view(np.uint64).reshape(count, wpr)
+    pick = sorted({0, count - 1, *[int(x) for x in rng.integers(0, count, 60)]})
+    if st != L.OK or not intact or any(not np.array_equal(rows[r], oracle.encode(s[r * stride:r * stride + Lr])) for r in pick):
+        fails.append(tag + f": encode status {status(st, err)} canaries {intact} or reads differ")
+        continue
+    D = HostBuf(n, int(rng.integers(0, 64)) if case % 2 else 0, np.full(n, ord("#"), np.uint8))
+    Wc = HostBuf(8 * wpr * count, 8 * int(rng.integers(0, 8)), words.view(np.uint64))
+    st = lib.bitnuc_decode_fixed(ctx._h, Wc.ptr, Lr, stride, count, D.ptr, C.byref(err))
+    text, intact = D.back()
+    expect = np.where((np.arange(n) % stride) < Lr, s & 0xDF, ord("#")).astype(np.uint8)
+    if st != L.OK or not intact or not np.array_equal(text, expect):
+        fails.append(tag + f": decode status {status(st, err)} canaries {intact} or bytes differ (separators must stay)")
+
+for case in range(60):
+    nb = draw_n()
+    nw = (nb + 31) // 32
+    a = rng.integers(0, 1 << 63, nw, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, nw, dtype=np.uint64)
+    b = a.copy()
+    flips = rng.integers(0, nw, max(1, nw // int(rng.integers(1, 50))))
+    b[flips] ^= rng.integers(0, 1 << 63, flips.size, dtype=np.uint64)
+    if ctx.hdist(a, b, nb) != oracle.hdist(a, b, nb):
+        fails.append(f"host hdist case {case}: n_bases={nb}")
+    if ctx.base_counts(a, nb) != oracle.base_counts(a, nb):
+        fails.append(f"host base_counts case {case}: n_bases={nb}")
+    length = int(rng.integers(1, 33))
+    if not np.array_equal(ctx.hdist_pairs(a, b, length), oracle.hdist_pairs(a, b, length)):
+        fails.append(f"host hdist_pairs case {case}: words={nw} len={length}")
+
+print("\n".join(fails[:30]))
+print(f"host fuzz: {len(fails)} failing cases")
+sys.exit(1 if fails else 0)
+"""
+
+
+def test_fuzz_host_pointer_calls():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BITNUC_PIPE_CHUNK_MB="1")
+    env.pop("BITNUC_FORCE_GPU", None)
+    env.pop("BITNUC_HOST_CUTOFF", None)
+    r = subprocess.run([sys.executable, "-c", _HOST_FUZZ_CHILD, root], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0 and "host fuzz: 0 failing cases" in r.stdout, (r.stdout[-6000:], r.stderr[-3000:])
