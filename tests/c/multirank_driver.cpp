@@ -1,0 +1,163 @@
+// multirank_driver.cpp -- TEST: config 4 through the C ABI with P ranks on ONE GPU (threads of this process, one bitnuc_ctx and
+// one communicator each), against tests/c/mock_rccl.cpp standing in for librccl.so.1 (see that file for what this can and cannot
+// show).  For every scenario the gathered buffer of EVERY rank must equal a single-GPU bitnuc_encode_dev of the concatenated
+// input ("bit-identical to a single-GPU encode of the concatenated input"); that single-GPU encode is what the
+// parity tests pin to the oracle.
+//
+//   multirank_driver P shard_len n_chunks mode rounds [bad_rank bad_offset]
+//     mode: oneshot | overlap           (overlap + BITNUC_GATHER_MODE=bcast in the environment = the broadcast exchange)
+//     rounds: calls back to back on the SAME buffers with new data each round (in-place reuse: the transfer stream of round r+1
+//             must not run ahead of round r's readers)
+//     bad_rank / bad_offset: plant an invalid byte in that rank's shard in the last round: that rank's sync must report
+//             InvalidBase('N') with the shard-relative offset, every other rank's must succeed
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bitnuc_hip.h"
+
+namespace {
+
+struct Barrier { // C++17: no std::barrier
+    std::mutex mu;
+    std::condition_variable cv;
+    int n, waiting = 0;
+    unsigned gen = 0;
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> g(mu);
+        const unsigned my = gen;
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); return; }
+        cv.wait(g, [&] { return gen != my; });
+    }
+};
+
+std::atomic<int> g_fail{0};
+std::mutex g_print;
+void complain(int rank, const std::string &what) {
+    std::lock_guard<std::mutex> g(g_print);
+    fprintf(stderr, "rank %d: %s\n", rank, what.c_str());
+    ++g_fail;
+}
+// a rank that cannot go on ends the process: the others would wait for it at the next barrier or receive
+#define HIPOK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { complain(rank, std::string(#call) + ": " + hipGetErrorString(e_)); _exit(1); } } while (0)
+#define BNOK(call) do { int st_ = (call); if (st_ != BITNUC_OK) { complain(rank, std::string(#call) + ": status " + std::to_string(st_) + " backend " + std::to_string(err.backend_code)); _exit(1); } } while (0)
+
+constexpr uint64_t kSeed = 0xB17C0DE;
+
+} // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 6) { fprintf(stderr, "usage: %s P shard_len n_chunks oneshot|overlap rounds [bad_rank bad_offset]\n", argv[0]); return 2; }
+    const int P = atoi(argv[1]);
+    const size_t shard_len = strtoull(argv[2], nullptr, 10);
+    const int n_chunks = atoi(argv[3]);
+    const bool overlap = !strcmp(argv[4], "overlap");
+    const int rounds = atoi(argv[5]);
+    const int bad_rank = argc > 7 ? atoi(argv[6]) : -1;
+    const size_t bad_offset = argc > 7 ? strtoull(argv[7], nullptr, 10) : 0;
+    if (P < 1 || P > 16 || shard_len % 32 || rounds < 1) return 2;
+    const size_t count = shard_len / 32, total_words = count * (size_t)P;
+
+    uint8_t id[BITNUC_UNIQUE_ID_BYTES];
+    bitnuc_err err;
+    if (bitnuc_comm_get_unique_id(id, &err) != BITNUC_OK) { fprintf(stderr, "no unique id (backend %d)\n", err.backend_code); return 3; }
+    auto totals = reinterpret_cast<void (*)(uint64_t *, uint64_t *)>(dlsym(RTLD_DEFAULT, "mock_rccl_totals"));
+    if (!totals) { fprintf(stderr, "this driver must run against tests/c/mock_rccl.cpp (LD_LIBRARY_PATH), not a real RCCL\n"); return 3; }
+
+    // expected words per round: one context encodes the concatenation of all shards
+    std::vector<std::vector<uint64_t>> expect((size_t)rounds, std::vector<uint64_t>(total_words));
+    {
+        bitnuc_ctx *c = nullptr;
+        if (bitnuc_ctx_create(0, &c, &err) != BITNUC_OK) return 3;
+        uint8_t *d_seq = nullptr;
+        uint64_t *d_words = nullptr;
+        if (hipMalloc(&d_seq, shard_len * P) != hipSuccess || hipMalloc(&d_words, total_words * 8) != hipSuccess) return 3;
+        for (int r = 0; r < rounds; ++r) {
+            if (bitnuc_nucgen_dev(c, d_seq, shard_len * P, kSeed + (uint64_t)r, 0, 0, &err) != BITNUC_OK) return 3;
+            if (bitnuc_encode_dev(c, d_seq, shard_len * P, d_words, &err) != BITNUC_OK || bitnuc_ctx_sync(c, &err) != BITNUC_OK) return 3;
+            if (hipMemcpy(expect[(size_t)r].data(), d_words, total_words * 8, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+        }
+        (void)hipFree(d_seq);
+        (void)hipFree(d_words);
+        bitnuc_ctx_destroy(c);
+    }
+
+    Barrier bar(P);
+    std::vector<std::thread> threads;
+    for (int rank = 0; rank < P; ++rank)
+        threads.emplace_back([&, rank] {
+            bitnuc_err err;
+            memset(&err, 0, sizeof err);
+            bitnuc_ctx *c = nullptr;
+            bitnuc_comm *comm = nullptr;
+            BNOK(bitnuc_ctx_create(0, &c, &err));
+            BNOK(bitnuc_comm_init_rank(c, P, rank, id, &comm, &err));
+            if (bitnuc_comm_nranks(comm) != P || bitnuc_comm_rank(comm) != rank) complain(rank, "communicator reports the wrong rank / size");
+            uint8_t *d_seq = nullptr;
+            uint64_t *d_all = nullptr;
+            HIPOK(hipMalloc(&d_seq, shard_len));
+            HIPOK(hipMalloc(&d_all, total_words * 8 + 64));
+            HIPOK(hipMemset(d_all, 0xEE, total_words * 8 + 64));
+            std::vector<uint64_t> got(total_words + 8);
+            for (int r = 0; r < rounds; ++r) {
+                // rank-disjoint slice of the round's stream, generated in place (asynchronous on the context's stream)
+                BNOK(bitnuc_nucgen_dev(c, d_seq, shard_len, kSeed + (uint64_t)r, (uint64_t)rank * shard_len, 0, &err));
+                const bool plant = r == rounds - 1 && rank == bad_rank;
+                if (plant) { BNOK(bitnuc_ctx_sync(c, &err)); HIPOK(hipMemset(d_seq + bad_offset, 'N', 1)); HIPOK(hipDeviceSynchronize()); }
+                if (overlap) BNOK(bitnuc_encode_sharded_allgather_overlapped_dev(c, comm, d_seq, shard_len, n_chunks, d_all, &err));
+                else BNOK(bitnuc_encode_sharded_allgather_dev(c, comm, d_seq, shard_len, d_all, &err));
+                // no host wait between rounds except where the result is checked: rounds 0..rounds-2 are checked only when rounds <= 2
+                const bool check = r == rounds - 1 || rounds <= 2;
+                if (!check) continue;
+                const int st = bitnuc_ctx_sync(c, &err);
+                if (plant) {
+                    if (st != BITNUC_INVALID_BASE || err.byte != 'N' || err.index != bad_offset)
+                        complain(rank, "planted byte: status " + std::to_string(st) + " byte " + std::to_string(err.byte) + " index " + std::to_string(err.index));
+                } else if (st != BITNUC_OK) complain(rank, "sync: status " + std::to_string(st) + " backend " + std::to_string(err.backend_code));
+                HIPOK(hipMemcpy(got.data(), d_all, total_words * 8 + 64, hipMemcpyDeviceToHost));
+                for (size_t s = 0; s < (size_t)P; ++s) {
+                    if ((int)s == bad_rank && r == rounds - 1) continue; // the failing shard's words are unspecified
+                    if (memcmp(got.data() + s * count, expect[(size_t)r].data() + s * count, count * 8) != 0) {
+                        size_t w = 0;
+                        while (got[s * count + w] == expect[(size_t)r][s * count + w]) ++w;
+                        complain(rank, "round " + std::to_string(r) + ": slot of rank " + std::to_string(s) + " differs from the single-GPU encode at word " + std::to_string(w) + " of " + std::to_string(count));
+                        break;
+                    }
+                }
+                for (size_t i = 0; i < 8; ++i)
+                    if (got[total_words + i] != 0xEEEEEEEEEEEEEEEEull) { complain(rank, "wrote past the gathered buffer"); break; }
+                bar.wait(); // peers read this rank's slot straight out of d_all: nobody starts the next round's encode into it, or frees it, before all have checked
+            }
+            bar.wait();
+            bitnuc_comm_destroy(comm);
+            (void)hipFree(d_seq);
+            (void)hipFree(d_all);
+            bitnuc_ctx_destroy(c);
+        });
+    for (auto &t : threads) t.join();
+    uint64_t sends = 0, recvs = 0;
+    totals(&sends, &recvs);
+    // one message per ordered pair of ranks per non-empty piece (or per call for the one-shot form), each matched exactly once
+    size_t pieces = 1;
+    if (overlap) {
+        pieces = 0;
+        for (int p = 0; p < n_chunks; ++p) pieces += count * (size_t)(p + 1) / (size_t)n_chunks > count * (size_t)p / (size_t)n_chunks;
+    }
+    const uint64_t want = (uint64_t)rounds * pieces * (uint64_t)P * (uint64_t)(P - 1);
+    if (sends != want || recvs != want) { fprintf(stderr, "schedule: %llu sends / %llu receives, expected %llu each\n", (unsigned long long)sends, (unsigned long long)recvs, (unsigned long long)want); ++g_fail; }
+    if (g_fail.load()) { fprintf(stderr, "FAILED: %d complaint(s)\n", g_fail.load()); return 1; }
+    printf("ok P=%d shard_len=%zu chunks=%d mode=%s rounds=%d messages=%llu\n", P, shard_len, n_chunks, argv[4], rounds, (unsigned long long)sends);
+    return 0;
+}

@@ -1,0 +1,93 @@
+"""Config 4 through the C ABI with 2..8 ranks on ONE GPU (-m gpu).
+
+No box this project can reach has more than one GPU, so the multi-rank code of bitnuc_amd/csrc/comm.hip never met a second rank
+on real hardware.  Here it does, against a stand-in for RCCL: tests/c/mock_rccl.cpp is built as `librccl.so.1` into a scratch
+directory that goes first on the child's LD_LIBRARY_PATH (comm.hip binds RCCL by dlopen of that soname), and
+tests/c/multirank_driver.cpp runs P ranks as threads, one bitnuc_ctx + communicator each, all on device 0.  Checked for every
+scenario: every rank's gathered buffer == a single-GPU encode of the concatenated input, nothing written past it, the number
+of point-to-point messages == rounds x pieces x P x (P - 1), errors reported by the rank that owns the invalid byte only.
+What this cannot show is RCCL itself and the xGMI fabric: tests/test_gpu_round3.py holds those tests (skipped below 2 GPUs).
+"""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "c", "_build")
+
+
+@pytest.fixture(scope="module")
+def driver():
+    from bitnuc_amd import build
+    lib = build.ensure_built()
+    os.makedirs(BUILD, exist_ok=True)
+    mock, exe = os.path.join(BUILD, "librccl.so.1"), os.path.join(BUILD, "multirank_driver")
+    subprocess.run(["hipcc", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wl,-soname,librccl.so.1", "-o", mock,
+                    os.path.join(ROOT, "tests", "c", "mock_rccl.cpp")], check=True, capture_output=True, timeout=600)
+    subprocess.run(["hipcc", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "c", "multirank_driver.cpp"), "-L" + os.path.dirname(lib), "-lbitnuc_hip",
+                    "-Wl,-rpath," + os.path.dirname(lib), "-ldl", "-lpthread"], check=True, capture_output=True, timeout=600)
+
+    def run(*args, **env_extra):
+        env = dict(os.environ, LD_LIBRARY_PATH=BUILD + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), **env_extra)
+        r = subprocess.run([exe, *[str(a) for a in args]], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and r.stdout.startswith("ok "), (args, env_extra, r.stdout[-2000:], r.stderr[-4000:])
+        return r.stdout
+    return run
+
+
+ODD = 32 * 100_003  # 100 003 words per shard: no piece boundary falls on a round number
+
+
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+def test_one_shot_gather(driver, P):
+    driver(P, ODD, 1, "oneshot", 2)
+
+
+@pytest.mark.parametrize("P,chunks", [(2, 1), (2, 3), (2, 8), (3, 5), (4, 8), (5, 7), (8, 8), (8, 13)])
+def test_chunked_in_place_gather(driver, P, chunks):
+    out = driver(P, ODD, chunks, "overlap", 2)
+    assert f"messages={2 * chunks * P * (P - 1)}" in out
+
+
+@pytest.mark.parametrize("P,chunks", [(2, 4), (4, 8), (8, 8)])
+def test_chunked_gather_broadcast_exchange(driver, P, chunks):
+    driver(P, ODD, chunks, "overlap", 2, BITNUC_GATHER_MODE="bcast")
+
+
+@pytest.mark.parametrize("P,shard,chunks,mode,rounds", [(8, ODD, 8, "overlap", 2), (2, 32 * 4_000_003, 4, "overlap", 2), (4, ODD, 6, "overlap", 5),
+                                                        (4, ODD, 1, "oneshot", 3), (4, ODD, 4, "bcast", 2)])
+def test_slow_fabric(driver, P, shard, chunks, mode, rounds):
+    """The mock's transfers take 2 ms each (host function in the receiving stream): they finish long after the encode that feeds
+    them, as on xGMI where the gather costs ~8x the encode.  A missing wait between the context's stream and the transfer stream
+    (bitnuc_ctx_sync returning before the exchange is done, a transfer starting before its piece is encoded) then shows as stale
+    words -- tools/multirank_mutation_check.py removes each wait in turn and shows these scenarios fail
+    (profiles/r03_multirank_mock_mutations.txt)."""
+    extra = {"BITNUC_GATHER_MODE": "bcast"} if mode == "bcast" else {}
+    driver(P, shard, chunks, "overlap" if mode == "bcast" else mode, rounds, MOCK_RCCL_DELAY_US="2000", **extra)
+
+
+@pytest.mark.parametrize("mode", ["oneshot", "overlap"])
+def test_back_to_back_rounds_reuse_the_buffer_in_stream_order(driver, mode):
+    """Five calls on the same buffers with new data each time and NO host wait in between: the transfer stream of call r+1 must
+    not overwrite what a peer is still reading from call r (the all_moved handshake), and the last result must be call 4's."""
+    driver(4, ODD, 6, mode, 5)
+    driver(8, 32 * 20_001, 4, mode, 5)
+
+
+def test_fewer_words_than_pieces(driver):
+    """3 words per shard in 8 pieces: five pieces are empty and must be skipped identically by every rank."""
+    out = driver(4, 96, 8, "overlap", 2)
+    assert "messages=%d" % (2 * 3 * 4 * 3) in out
+    driver(2, 32, 4, "overlap", 1)
+
+
+@pytest.mark.parametrize("mode", ["oneshot", "overlap"])
+def test_invalid_byte_is_reported_by_its_rank_only(driver, mode):
+    """InvalidBase with the shard-relative offset on the rank that owns the byte (piece 5 of 8); every other rank succeeds and
+    holds the other shards' words."""
+    driver(4, ODD, 8, mode, 2, 2, 5 * (ODD // 8) + 12345)
+    driver(8, ODD, 8, mode, 1, 7, ODD - 1)

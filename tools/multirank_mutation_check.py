@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Does tests/test_gpu_multirank_mock.py notice a broken comm.hip?  (run on the GPU box; writes nothing into the sources)
+
+Copies bitnuc_amd/csrc to a scratch directory, applies ONE deliberate defect at a time to comm.hip's chunked all-gather,
+builds a library from each copy and runs tests/c/multirank_driver.cpp against it and tests/c/mock_rccl.cpp, with the mock's
+fabric fast (MOCK_RCCL_DELAY_US=0) and slow (2000).  A defect counts as noticed when at least one scenario fails.
+  A  the transfer stream does not wait for the piece's encode        (hipStreamWaitEvent(xfer, piece_done[p]) removed)
+  B  the context's stream does not wait for the transfer stream      (~Join's wait removed: bitnuc_ctx_sync returns early)
+  C  the transfer stream does not wait for earlier work at call start (removed; REDUNDANT by construction: piece_done[p] is
+     recorded later on the same stream, so this one is expected to go unnoticed -- it is listed to show the check is not
+     simply failing everything)
+  D  one receive lands one word too far                               (addressing)
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bitnuc_amd import build as B
+
+MUT = {
+    "A": ("        HIPCHK(hipStreamWaitEvent(comm->xfer, comm->piece_done[(size_t)p], 0));\n", ""),
+    "B": ("            if (hipEventRecord(comm->all_moved, comm->xfer) == hipSuccess) (void)hipStreamWaitEvent(c->stream, comm->all_moved, 0);", "            if (false) {}"),
+    "C": ("    HIPCHK(hipStreamWaitEvent(comm->xfer, comm->all_moved, 0));\n", ""),
+    "D": ("uint64_t *theirs = d_all + (size_t)s * count + w0;", "uint64_t *theirs = d_all + (size_t)s * count + w0 + (s == 1 && p == 2 ? 1 : 0);"),
+}
+ODD, BIG = 32 * 100_003, 32 * 4_000_003
+SCENARIOS = [(4, ODD, 6, "overlap", 5), (8, ODD, 8, "overlap", 2), (4, BIG, 8, "overlap", 3), (2, BIG, 4, "overlap", 2)]
+
+
+def main():
+    hipcc = B.hipcc_path()
+    work = tempfile.mkdtemp(prefix="bitnuc_mut_")
+    src = os.path.join(work, "a", "csrc")  # runtime.h includes ../../include/bitnuc_hip.h
+    shutil.copytree(B.CSRC, src)
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(work, "include"))
+    flags = B.CXXFLAGS
+
+    def cc(unit, name=None):
+        obj = os.path.join(work, (name or unit) + ".o")
+        subprocess.run([hipcc, *flags, "-c", os.path.join(src, (name or unit) + ".hip"), "-o", obj], check=True, cwd=src, capture_output=True)
+        return obj
+    orig = open(os.path.join(src, "comm.hip")).read()
+    for m, (old, new) in MUT.items():
+        assert old in orig, m
+        open(os.path.join(src, f"comm{m}.hip"), "w").write(orig.replace(old, new))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        common = list(ex.map(cc, [u for u in B.UNITS if u != "comm"]))
+        comms = dict(zip(["product", *MUT], ex.map(lambda n: cc("comm", n), ["comm"] + [f"comm{m}" for m in MUT])))
+    libs = {}
+    for name, obj in comms.items():
+        d = os.path.join(work, name)
+        os.makedirs(d)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-fno-gpu-rdc", "-o", os.path.join(d, "libbitnuc_hip.so"), *common, obj, "-ldl", "-lpthread"], check=True, capture_output=True)
+        libs[name] = d
+    mock = os.path.join(work, "mock")
+    os.makedirs(mock)
+    subprocess.run([hipcc, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wl,-soname,librccl.so.1", "-o", os.path.join(mock, "librccl.so.1"), os.path.join(ROOT, "tests", "c", "mock_rccl.cpp")], check=True, capture_output=True)
+    exe = os.path.join(work, "multirank_driver")
+    subprocess.run([hipcc, "-O1", "-g", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "c", "multirank_driver.cpp"),
+                    "-L" + libs["product"], "-lbitnuc_hip", "-ldl", "-lpthread"], check=True, capture_output=True)
+    noticed = {}
+    for name, d in libs.items():
+        for delay in (0, 2000):
+            for sc in SCENARIOS:
+                env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([d, mock, os.environ.get("LD_LIBRARY_PATH", "")]), MOCK_RCCL_DELAY_US=str(delay))
+                r = subprocess.run([exe, *map(str, sc)], capture_output=True, text=True, timeout=300, env=env)
+                first = (r.stderr.strip().splitlines() or [""])[0][:110]
+                print(f"{name:8s} fabric delay {delay:4d} us  P={sc[0]} shard={sc[1]:>9d} pieces={sc[2]} rounds={sc[4]}: {'ok' if r.returncode == 0 else 'FAILS  ' + first}", flush=True)
+                noticed[name] = noticed.get(name, 0) + (r.returncode != 0)
+    print()
+    for name, k in noticed.items():
+        print(f"{name:8s}: {k} of {2 * len(SCENARIOS)} runs fail")
+    shutil.rmtree(work, ignore_errors=True)
+    ok = noticed["product"] == 0 and all(noticed[m] > 0 for m in "ABD")
+    print("verdict:", "the product passes every run; defects A, B and D are noticed" if ok else "UNEXPECTED")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
