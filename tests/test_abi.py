@@ -91,3 +91,115 @@ def test_hip_runtime_preload_is_logged_and_can_be_opted_out():
     (reason, path), err = _hip_runtime_choice({"BITNUC_LOG": "1"})
     assert ("preloaded torch's bundled runtime" in reason and path and path.endswith("libamdhip64.so")) or "system runtime" in reason
     assert "bitnuc_amd: HIP runtime:" in err
+
+
+# ---- one ABI, three declarations: the C header, the ctypes table (bitnuc_amd/_lib.py) and the Rust shim (rust/src/ffi.rs) --------
+# The Rust shim cannot be compiled in this image (no toolchain), so nothing but this test keeps its `extern "C"` block in step with
+# the header: every exported function must be declared in all three places with the same number of arguments and the same
+# argument classes (pointer / size / 64-bit integer / int), and the error struct and status codes must agree.
+def _strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def _c_class(t):
+    t = t.strip()
+    if "*" in t or "[" in t:
+        return "ptr"
+    base = re.sub(r"\b(const|unsigned)\b", "", t).split()
+    name = base[0] if base else ""
+    if t.replace("const", "").strip() in ("unsigned", "unsigned int"):
+        return "int"
+    return {"size_t": "size", "uint64_t": "u64", "int": "int", "double": "f64", "void": "void"}.get(name, name)
+
+
+def _header_prototypes():
+    text = _strip_comments(open(os.path.join(ROOT, "include", "bitnuc_hip.h")).read())
+    protos = {}
+    for ret, name, args in re.findall(r"(?m)^\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\**)\s*(bitnuc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text):
+        args = " ".join(args.split())
+        alist = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        # drop the parameter name: the class only needs the type part
+        classes = []
+        for a in alist:
+            m = re.match(r"(.*?)([A-Za-z_][A-Za-z0-9_]*)?(\[[^\]]*\])?$", a)
+            classes.append(_c_class((m.group(1) or "") + (m.group(3) or "")))
+        protos[name] = (_c_class(ret), classes)
+    return protos
+
+
+def _rust_class(t):
+    t = t.strip()
+    if t.startswith("*"):
+        return "ptr"
+    return {"usize": "size", "u64": "u64", "c_int": "int", "c_uint": "int", "f64": "f64", "i32": "int"}.get(t, t)
+
+
+def _rust_prototypes():
+    text = re.sub(r"//[^\n]*", " ", open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read())
+    protos = {}
+    for name, args, ret in re.findall(r"pub fn (bitnuc_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", text):
+        alist = [a.strip() for a in " ".join(args.split()).split(",") if a.strip()]
+        protos[name] = (_rust_class(ret) if ret.strip() else "void", [_rust_class(a.split(":", 1)[1]) for a in alist])
+    return protos
+
+
+def _ctypes_prototypes():
+    import ctypes as C
+    from bitnuc_amd import _lib as L
+
+    def cls(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_size_t: "size", C.c_uint64: "u64", C.c_int: "int", C.c_uint: "int", C.c_double: "f64"}.get(t, getattr(t, "__name__", str(t)))
+    table = next(v for k, v in vars(L).items() if isinstance(v, dict) and "bitnuc_encode" in v)
+    return {name: (cls(ret), [cls(a) for a in args]) for name, (ret, args) in table.items()}
+
+
+def test_header_ctypes_and_rust_declare_the_same_functions():
+    header, rust, py = _header_prototypes(), _rust_prototypes(), _ctypes_prototypes()
+    assert len(header) >= 60 and "bitnuc_encode_sharded_allgather_overlapped_dev" in header
+    # on this platform size_t and uint64_t are both 64-bit integers: the classes may differ in name only where the header says so
+    problems = []
+    for name, (ret, args) in sorted(header.items()):
+        for other, table in (("rust/src/ffi.rs", rust), ("bitnuc_amd/_lib.py", py)):
+            if name not in table:
+                problems.append(f"{name}: not declared in {other}")
+                continue
+            oret, oargs = table[name]
+            if other.endswith("_lib.py"):  # ctypes.c_size_t IS ctypes.c_uint64 on this platform: one class there
+                args_cmp = ["u64" if a == "size" else a for a in args]
+            else:
+                args_cmp = args
+            if len(oargs) != len(args):
+                problems.append(f"{name}: {len(args)} arguments in the header, {len(oargs)} in {other}")
+            elif oargs != args_cmp:
+                problems.append(f"{name}: argument classes {args} in the header, {oargs} in {other}")
+            ret_cmp = "u64" if (other.endswith("_lib.py") and ret == "size") else ret
+            if ret_cmp != oret:
+                problems.append(f"{name}: returns {ret} in the header, {oret} in {other}")
+    for other, table in (("rust/src/ffi.rs", rust), ("bitnuc_amd/_lib.py", py)):
+        for name in sorted(set(table) - set(header)):
+            problems.append(f"{name}: declared in {other} but not in the header")
+    assert not problems, "\n".join(problems)
+
+
+def test_rust_error_struct_and_status_codes_match_the_header():
+    header = _strip_comments(open(os.path.join(ROOT, "include", "bitnuc_hip.h")).read())
+    rust = open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read()
+    c_consts = {k: int(v) for k, v in re.findall(r"\b(BITNUC_[A-Z_]+)\s*=\s*(\d+)", header)}
+    c_consts.update({k: int(v) for k, v in re.findall(r"#define\s+(BITNUC_[A-Z_]+)\s+(\d+)", header)})
+    r_consts = {k: int(v) for k, v in re.findall(r"pub const (BITNUC_[A-Z_]+)\s*:\s*\w+\s*=\s*(\d+)", rust)}
+    assert c_consts and set(r_consts) <= set(c_consts) and all(c_consts[k] == v for k, v in r_consts.items()), (c_consts, r_consts)
+    for must in ("BITNUC_OK", "BITNUC_INVALID_BASE", "BITNUC_SEQUENCE_TOO_LONG", "BITNUC_INVALID_LENGTH", "BITNUC_BACKEND_ERROR", "BITNUC_UNIQUE_ID_BYTES"):
+        assert must in r_consts, must
+    c_fields = re.search(r"typedef struct bitnuc_err\s*\{(.*?)\}", header, flags=re.S).group(1)
+    c_fields = [(t.strip(), n) for t, n in re.findall(r"([A-Za-z0-9_ ]+?)\s+([a-z_]+)\s*(?:\[\d+\])?\s*;", c_fields)]
+    r_fields = re.search(r"pub struct bitnuc_err\s*\{(.*?)\}", rust, flags=re.S).group(1)
+    r_fields = [(n, t.strip()) for n, t in re.findall(r"pub ([a-z_]+)\s*:\s*([^,]+),", r_fields)]
+    width = {"int32_t": "i32", "int": "i32", "uint64_t": "u64", "uint8_t": "u8"}
+    want = [(n, width[t]) for t, n in c_fields if not n.startswith("_") and n != "pad"]
+    got = [(n, t) for n, t in r_fields if not n.startswith("_")]
+    assert want == got, (want, got)
