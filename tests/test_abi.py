@@ -203,3 +203,33 @@ def test_rust_error_struct_and_status_codes_match_the_header():
     want = [(n, width[t]) for t, n in c_fields if not n.startswith("_") and n != "pad"]
     got = [(n, t) for n, t in r_fields if not n.startswith("_")]
     assert want == got, (want, got)
+
+
+def test_header_is_plain_c_and_the_example_links():
+    """include/bitnuc_hip.h is a C header (the boundary is a C ABI): examples/roundtrip.c compiles as strict C11 with gcc and links
+    against the library (no C++ runtime, no HIP headers needed by the caller)."""
+    import subprocess
+    import tempfile
+    from bitnuc_amd import build
+    lib = build.ensure_built()
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "roundtrip")
+        r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", "roundtrip.c"), "-L" + os.path.dirname(lib), "-lbitnuc_hip",
+                            "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_c_example_runs():
+    import subprocess
+    import tempfile
+    from bitnuc_amd import build
+    lib = build.ensure_built()
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "roundtrip")
+        subprocess.run(["gcc", "-std=c11", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "roundtrip.c"),
+                        "-L" + os.path.dirname(lib), "-lbitnuc_hip", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True, capture_output=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "36 bases -> 2 words" in r.stdout and "round trip ok" in r.stdout and "InvalidBase('N') at index 3" in r.stdout, r.stdout
