@@ -2,7 +2,7 @@
 
 No box this project can reach has more than one GPU, so the multi-rank code of bitnuc_amd/csrc/comm.hip never met a second rank
 on real hardware.  Here it does, against a stand-in for RCCL: tests/c/mock_rccl.cpp is built as `librccl.so.1` into a scratch
-directory that goes first on the child's LD_LIBRARY_PATH (comm.hip binds RCCL by dlopen of that soname), and
+directory that goes first on the child's LD_LIBRARY_PATH (a pytest temporary directory) (comm.hip binds RCCL by dlopen of that soname), and
 tests/c/multirank_driver.cpp runs P ranks as threads, one bitnuc_ctx + communicator each, all on device 0.  Checked for every
 scenario: every rank's gathered buffer == a single-GPU encode of the concatenated input, nothing written past it, the number
 of point-to-point messages == rounds x pieces x P x (P - 1), errors reported by the rank that owns the invalid byte only.
@@ -16,14 +16,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "tests", "c", "_build")
 
 
 @pytest.fixture(scope="module")
-def driver():
+def driver(tmp_path_factory):
     from bitnuc_amd import build
     lib = build.ensure_built()
-    os.makedirs(BUILD, exist_ok=True)
+    BUILD = str(tmp_path_factory.mktemp("mock_rccl"))  # outside the repository: no file named like RCCL ever sits in the tree
     mock, exe = os.path.join(BUILD, "librccl.so.1"), os.path.join(BUILD, "multirank_driver")
     subprocess.run(["hipcc", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wl,-soname,librccl.so.1", "-o", mock,
                     os.path.join(ROOT, "tests", "c", "mock_rccl.cpp")], check=True, capture_output=True, timeout=600)
