@@ -1116,7 +1116,7 @@ def host_path_block(ctx, torch):
                              "workload": "sliding 31-mer pack + Hamming scan of 10^9 bases, host memory in and out (bitnuc_kmer_hdist_scan): a byte in and a byte out per window, both DMA engines at once"}
     del kout, kdist
     ctx.set_variant("force_gpu", 1)
-    try:  # how the staging pools were sized, and from what (cores visible vs the cgroup quota, measured copy rates)
+    try:  # which engine ran, and how the staged engine's pools would be sized (cores visible vs the cgroup quota)
         out["pipe"] = dict(ctx.host_pipe_info(), chunk_mb_env=os.environ.get("BITNUC_PIPE_CHUNK_MB"), host_threads_env=os.environ.get("BITNUC_HOST_THREADS"))
     except Exception as e:  # noqa: BLE001
         out["pipe"] = {"error": repr(e)[:200]}
@@ -1125,7 +1125,7 @@ def host_path_block(ctx, torch):
                 "roundtrip_ok": ok,
                 "encode_frac_of_pinned_h2d": round(n / min(te) / 1e9 / out["pinned_h2d_gb_s"], 3),
                 "decode_frac_of_pinned_d2h": round(n / min(td) / 1e9 / out["pinned_d2h_gb_s"], 3),
-                "note": "bitnuc_encode / bitnuc_decode on pageable host buffers: staged through pinned double buffers, H2D / kernel / D2H overlapped; PCIe-bound, never the reported value"})
+                "note": "bitnuc_encode / bitnuc_decode on pageable host buffers, H2D / kernel / D2H overlapped chunk by chunk (pipe.direct_engine 1: pageable copies issued by the calling thread and one mover thread; 0: staged through the library's pinned buffers by copy threads); PCIe-bound, never the reported value"})
     return out
 
 

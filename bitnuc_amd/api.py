@@ -483,7 +483,7 @@ class Context:
     def host_pipe_info(self):
         """Configuration and creation-time measurements of the pipelined host-pointer path (creates it if needed)."""
         names = ["cores_visible", "cores_quota", "cores_usable", "chunk_bases", "depth", "encode_stage_in_threads", "encode_hand_back_threads",
-                 "decode_stage_in_threads", "decode_hand_back_threads", "heavy_side_thread_cap", "gpu_numa_node", "workers_bound_to_cpus"]
+                 "decode_stage_in_threads", "decode_hand_back_threads", "heavy_side_thread_cap", "gpu_numa_node", "workers_bound_to_cpus", "direct_engine"]
         out = (C.c_double * len(names))()
         err = L.BitnucErr()
         if self._lib.bitnuc_host_pipe_info(self._h, out, len(names), C.byref(err)) != L.OK:

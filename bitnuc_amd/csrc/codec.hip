@@ -327,10 +327,10 @@ int bitnuc_host_pipe_info(bitnuc_ctx *c, double *out, int n, bitnuc_err *err) {
     DeviceGuard g(c->device);
     HostPipe *p;
     if (int st = pipe_get(c, &p, err)) return st;
-    const double v[12] = {(double)p->cores_visible, (double)p->cores_quota, (double)p->cores_usable, (double)p->chunk, (double)kPipeDepth,
+    const double v[13] = {(double)p->cores_visible, (double)p->cores_quota, (double)p->cores_usable, (double)p->chunk, (double)kPipeDepth,
                           (double)p->enc_in, (double)p->enc_out, (double)p->dec_in, (double)p->dec_out, (double)p->heavy_cap,
-                          (double)p->numa_node, (double)p->bound_cpus};
-    for (int i = 0; i < n; ++i) out[i] = i < 12 ? v[i] : 0.0;
+                          (double)p->numa_node, (double)p->bound_cpus, (double)c->pipe_impl};
+    for (int i = 0; i < n; ++i) out[i] = i < 13 ? v[i] : 0.0;
     return BITNUC_OK;
 }
 

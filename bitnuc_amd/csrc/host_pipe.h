@@ -6,6 +6,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 // ---- pipelined host-pointer path --------------------------------------------------------------------
 // A caller's buffers are pageable.  Handing them to hipMemcpyAsync makes the runtime stage them through its own
 // pinned bounce buffers on the calling thread, serialising copy-in, kernel and copy-out.  Here the library owns the
@@ -36,9 +38,12 @@ struct HostPipe {
     uint8_t *pin[3][kPipeDepth] = {}, *dev[3][kPipeDepth] = {};
     bitnuc_host::CopyPool *pool = nullptr;     // stage-in: blocking, the calling thread takes a slice
     bitnuc_host::CopyPool *pool_out = nullptr; // hand-back to the caller: asynchronous, overlaps the next chunk's stage-in
+    bitnuc_host::TaskThread *mover = nullptr;  // the direct engine's second mover (created on first use)
     size_t chunk = kPipeChunkDefault; // bases per chunk (a multiple of 32)
     int enc_in = 1, enc_out = 1, dec_in = 1, dec_out = 1; // copy threads per direction and side
     int cores_visible = 1, cores_quota = 0, cores_usable = 1, heavy_cap = 1;
+    cpu_set_t local_cpus;
+    int pool_threads = 1;
     int numa_node = -1, bound_cpus = 0; // the GPU's NUMA node (-1 = unknown) and how many of its CPUs the workers are bound to (0 = not bound)
     bool ok = false;
     size_t buf_bytes(int kind) const { return kind == kBufB ? chunk / 4 + 64 : chunk + 64; }
@@ -48,6 +53,7 @@ namespace bitnuc_rt {
 
 inline void pipe_free(HostPipe *p) {
     if (!p) return;
+    delete p->mover;    // runs what is still queued, then joins
     delete p->pool_out; // joins its workers (waits for an outstanding hand-back) before the pinned buffers go
     delete p->pool;
     for (int kind = 0; kind < 3; ++kind)
@@ -65,10 +71,11 @@ inline void pipe_free(HostPipe *p) {
     delete p;
 }
 
-inline hipError_t pipe_alloc_kind(HostPipe *p, int kind) {
+// device buffers of a kind; `pinned`: also the staged engine's pinned host buffers (the direct engine has none)
+inline hipError_t pipe_alloc_kind(HostPipe *p, int kind, bool pinned) {
     hipError_t rc = hipSuccess;
     for (int i = 0; i < kPipeDepth && rc == hipSuccess; ++i) {
-        if (!p->pin[kind][i]) rc = hipHostMalloc(reinterpret_cast<void **>(&p->pin[kind][i]), p->buf_bytes(kind), hipHostMallocDefault);
+        if (pinned && !p->pin[kind][i]) rc = hipHostMalloc(reinterpret_cast<void **>(&p->pin[kind][i]), p->buf_bytes(kind), hipHostMallocDefault);
         if (rc == hipSuccess && !p->dev[kind][i]) rc = hipMalloc(&p->dev[kind][i], p->buf_bytes(kind));
     }
     return rc;
@@ -77,8 +84,8 @@ inline hipError_t pipe_alloc_kind(HostPipe *p, int kind) {
 // kinds: bit mask of the buffer sets the caller needs (1 << kBufA | ...); A and B are allocated with the pipe, C on first use
 inline int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err, unsigned kinds = (1u << kBufA) | (1u << kBufB)) {
     if (c->pipe && c->pipe->ok) {
-        if ((kinds & (1u << kBufC)) && !c->pipe->pin[kBufC][kPipeDepth - 1]) {
-            const hipError_t rcC = pipe_alloc_kind(c->pipe, kBufC);
+        if ((kinds & (1u << kBufC)) && !c->pipe->dev[kBufC][kPipeDepth - 1]) {
+            const hipError_t rcC = pipe_alloc_kind(c->pipe, kBufC, false);
             if (rcC != hipSuccess) return fail_hip(err, rcC);
         }
         *out = c->pipe;
@@ -97,9 +104,9 @@ inline int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err, unsigned kin
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&p->ev_k[i], hipEventDisableTiming);
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&p->ev_out[i], hipEventDisableTiming);
     }
-    if (rc == hipSuccess) rc = pipe_alloc_kind(p, kBufA);
-    if (rc == hipSuccess) rc = pipe_alloc_kind(p, kBufB);
-    if (rc == hipSuccess && (kinds & (1u << kBufC))) rc = pipe_alloc_kind(p, kBufC);
+    if (rc == hipSuccess) rc = pipe_alloc_kind(p, kBufA, false);
+    if (rc == hipSuccess) rc = pipe_alloc_kind(p, kBufB, false);
+    if (rc == hipSuccess && (kinds & (1u << kBufC))) rc = pipe_alloc_kind(p, kBufC, false);
     if (rc != hipSuccess) { pipe_free(p); return fail_hip(err, rc); }
     // CPU budget: what the affinity mask AND the cgroup quota allow, minus one for the HIP runtime's own threads
     p->cores_visible = bitnuc_host::cores_visible();
@@ -134,9 +141,8 @@ inline int pipe_get(bitnuc_ctx *c, HostPipe **out, bitnuc_err *err, unsigned kin
         } else (void)hipGetLastError();
     }
     p->bound_cpus = n_local >= most ? n_local : 0; // only when the node offers at least as many CPUs as the pool has threads
-    const cpu_set_t *bind = p->bound_cpus ? &local : nullptr;
-    p->pool = new bitnuc_host::CopyPool(most);               // the caller + most - 1 workers, free (see above)
-    p->pool_out = new bitnuc_host::CopyPool(most + 1, bind); // most workers (the caller's slice index is unused in asynchronous jobs)
+    if (p->bound_cpus) p->local_cpus = local;
+    p->pool_threads = most; // the staged engine creates its pools on first use (pipe_staged_prepare)
     p->enc_in = p->dec_out = heavy;
     p->enc_out = p->dec_in = light < most ? light : most;
     p->ok = true;
@@ -153,7 +159,8 @@ struct PipeAbort {
     HostPipe *p;
     bool dismissed = false;
     ~PipeAbort() {
-        p->pool_out->wait(); // no return leaves workers writing into the caller's buffer
+        if (p->pool_out) p->pool_out->wait(); // no return leaves workers writing into the caller's buffer
+        if (p->mover) p->mover->drain();
         if (dismissed) return;
         (void)hipStreamSynchronize(p->s_in);
         (void)hipStreamSynchronize(p->s_out);
@@ -172,8 +179,70 @@ struct PipeAbort {
 //   const void *in_src(size_t ci); size_t in_bytes(size_t ci);  void *out_dst(size_t ci); size_t out_bytes(size_t ci);
 //   int launch(size_t ci, const uint8_t *d_in, uint8_t *d_out, bitnuc_err *err);   // enqueue on c->stream (takes its own error slot)
 // Returns after the last hand-back; the kernels' error slots are the caller's to drain (one drain: launch order = sequence order).
+// The DIRECT engine (pipe_impl 1).  On this platform the runtime pins a pageable buffer in place and a pageable hipMemcpyAsync
+// runs at the pinned rate (56 GB/s either way, profiles/r03_pageable_copy_rates.txt) -- but it blocks its caller until the copy is
+// done, so one thread gets one direction at a time.  Two threads then do what the staged engine needs 8 + 4 copy threads and
+// three sets of pinned buffers for: the CALLING thread copies chunk c straight from the caller's memory to device buffer
+// c % depth and launches on it, the MOVER thread (host_pool.h: TaskThread) waits for kernel c's event and copies its output straight
+// into the caller's memory.  A device buffer pair is reused once the mover has finished the chunk that used it (a host-side
+// ticket: by then the kernel has read its input and the copy has left its output), so no other guard is needed.
+template <class Job>
+int pipe_run_direct(bitnuc_ctx *c, HostPipe *p, Job &job, bitnuc_err *err) {
+    constexpr int D = kPipeDepth;
+    if (!p->mover) {
+        p->mover = new bitnuc_host::TaskThread();
+        const int dev = c->device;
+        p->mover->post([dev] { (void)hipSetDevice(dev); });
+    }
+    bitnuc_host::TaskThread &w = *p->mover;
+    std::atomic<int> mover_rc{0}; // (declared before the guard: the tasks it waits for write here)
+    struct Drain { // however the loop ends, nothing is still being written into the caller's memory when this call returns
+        bitnuc_host::TaskThread &w;
+        ~Drain() { w.drain(); }
+    } drain_guard{w};
+    const uint64_t base = w.tickets(); // all finished: the previous call drained
+    for (size_t ci = 0; ci < job.nchunks; ++ci) {
+        const int b = (int)(ci % D);
+        if (ci >= (size_t)D) w.wait_done(base + ci - D + 1); // chunk ci-D is with the caller: device buffers b are free
+        if (const int rc = mover_rc.load()) return fail_hip(err, (hipError_t)rc);
+        const size_t nin = job.in_bytes(ci), nout = job.out_bytes(ci);
+        uint8_t *dev_in = p->dev[job.in_kind][b], *dev_out = p->dev[job.out_kind][b];
+        HIPCHK(hipMemcpyAsync(dev_in, job.in_src(ci), nin, hipMemcpyHostToDevice, p->s_in)); // pageable source: back when the copy is done
+        HIPCHK(hipEventRecord(p->ev_in[b], p->s_in));
+        HIPCHK(hipStreamWaitEvent(c->stream, p->ev_in[b], 0)); // (a caller that passes pinned memory gets a truly asynchronous copy)
+        if (int st = job.launch(ci, dev_in, dev_out, err)) return st;
+        HIPCHK(hipEventRecord(p->ev_k[b], c->stream));
+        void *dst = job.out_dst(ci);
+        hipStream_t s_out = p->s_out;
+        hipEvent_t ev_k = p->ev_k[b];
+        w.post([=, &mover_rc] {
+            hipError_t e = hipStreamWaitEvent(s_out, ev_k, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(dst, dev_out, nout, hipMemcpyDeviceToHost, s_out);
+            if (e == hipSuccess) e = hipStreamSynchronize(s_out);
+            if (e != hipSuccess) mover_rc.store((int)e);
+        });
+    }
+    w.drain();
+    if (const int rc = mover_rc.load()) return fail_hip(err, (hipError_t)rc);
+    return BITNUC_OK;
+}
+
+// what only the staged engine needs: pinned buffers of the two kinds a job uses and the two copy pools
+inline int pipe_staged_prepare(HostPipe *p, int in_kind, int out_kind, bitnuc_err *err) {
+    for (int kind : {in_kind, out_kind}) {
+        if (p->pin[kind][kPipeDepth - 1]) continue;
+        const hipError_t rc = pipe_alloc_kind(p, kind, true);
+        if (rc != hipSuccess) return fail_hip(err, rc);
+    }
+    if (!p->pool) p->pool = new bitnuc_host::CopyPool(p->pool_threads); // the caller + pool_threads - 1 workers, free (see pipe_get)
+    if (!p->pool_out) p->pool_out = new bitnuc_host::CopyPool(p->pool_threads + 1, p->bound_cpus ? &p->local_cpus : nullptr); // pool_threads workers (the caller's slice index is unused in asynchronous jobs)
+    return BITNUC_OK;
+}
+
 template <class Job>
 int pipe_run(bitnuc_ctx *c, HostPipe *p, Job &job, bitnuc_err *err) {
+    if (c->pipe_impl == 1) return pipe_run_direct(c, p, job, err);
+    if (int st = pipe_staged_prepare(p, job.in_kind, job.out_kind, err)) return st;
     constexpr int D = kPipeDepth, LAG = kPipeDepth - 1;
     for (size_t ci = 0; ci < job.nchunks + LAG; ++ci) {
         const int b = (int)(ci % D);

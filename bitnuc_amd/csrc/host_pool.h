@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -204,6 +206,72 @@ struct CopyPool {
         copy_slice(0);
         std::unique_lock<std::mutex> g(mu);
         cv_done.wait(g, [&] { return pending == 0; });
+    }
+};
+
+// One helper thread that runs posted tasks in order (the "direct" host pipeline's second mover: while the calling thread copies
+// chunk c+1 towards the device, this thread copies chunk c-1 back into the caller's memory).  post() returns a ticket = the
+// number of tasks posted so far; wait_done(t) returns when t tasks have finished; drain() when all posted ones have.  One poster
+// thread (the context's single-thread contract).  Tasks still queued when the object is destroyed are run first.
+struct TaskThread {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<std::function<void()>> q;
+    uint64_t posted = 0, done = 0;
+    bool stop = false;
+    std::thread t;
+
+    TaskThread() : t([this] { run(); }) {}
+    ~TaskThread() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        t.join();
+    }
+    TaskThread(const TaskThread &) = delete;
+    TaskThread &operator=(const TaskThread &) = delete;
+
+    void run() {
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv_work.wait(g, [&] { return stop || !q.empty(); });
+                if (q.empty()) return; // stop, and nothing left to run
+                fn = std::move(q.front());
+                q.pop_front();
+            }
+            fn();
+            {
+                std::lock_guard<std::mutex> g(mu);
+                ++done;
+            }
+            cv_done.notify_all();
+        }
+    }
+    uint64_t post(std::function<void()> fn) {
+        uint64_t ticket;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            q.push_back(std::move(fn));
+            ticket = ++posted;
+        }
+        cv_work.notify_one();
+        return ticket;
+    }
+    uint64_t tickets() {
+        std::lock_guard<std::mutex> g(mu);
+        return posted;
+    }
+    void wait_done(uint64_t ticket) {
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return done >= ticket; });
+    }
+    void drain() {
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return done >= posted; });
     }
 };
 

@@ -91,6 +91,8 @@ struct bitnuc_ctx {
     size_t host_cutoff = bitnuc_rt::kDefaultHostCutoff; // bulk host-pointer encode / hdist below this many bases run on the host (host_word.h)
     size_t host_cutoff_decode = bitnuc_rt::kDefaultHostCutoffDecode; // ... decode
     int host_pipeline = 1;                 // large host-pointer encode / decode: pinned buffers + overlapped H2D / kernel / D2H
+    int pipe_impl = 1;                     // host-pointer pipeline: 1 = direct engine (pageable copies from the calling thread + one mover thread: ships -- faster on four of four
+                                           // boxes, profiles/r03_ab_pipe_impl.txt), 0 = staged engine (own pinned buffers + copy threads); BITNUC_PIPE_IMPL=direct|staged (csrc/host_pipe.h)
     HostPipe *pipe = nullptr;              // created on the first large host-pointer call (codec.hip)
 };
 

@@ -209,6 +209,7 @@ int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, 
     if (rc == hipSuccess) rc = hipMalloc(&c->d_sink, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_sink, 0, 64);
     if (const char *e = getenv("BITNUC_FORCE_GPU")) c->force_gpu = atoi(e) != 0;
+    if (const char *e = getenv("BITNUC_PIPE_IMPL")) { if (!strcmp(e, "direct")) c->pipe_impl = 1; else if (!strcmp(e, "staged")) c->pipe_impl = 0; }
     if (const char *e = getenv("BITNUC_HOST_CUTOFF")) { const long long v = atoll(e); if (v >= 0) c->host_cutoff = c->host_cutoff_decode = (size_t)v; }
     c->hdist_blocks = (unsigned)c->num_cu;     // 1 per CU: 74.3 us for two 250 MB operands where 2 per CU take 77.2 and 4 per CU 84.4 (profiles/r03_ab_hdist_grid.txt)
     c->reduce_blocks = (unsigned)c->num_cu * 2; // a resident grid of 2 workgroups of 256 threads per CU (profiles/r01_sweep13_reduce_grid.txt: the tail of atomics + ticket grows with the grid)
@@ -291,6 +292,7 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "force_gpu")) { prev = c->force_gpu; if (value == 0 || value == 1) c->force_gpu = value; }
     else if (!strcmp(key, "host_cutoff")) { prev = (int)(c->host_cutoff > 0x7FFFFFFF ? 0x7FFFFFFF : c->host_cutoff); if (value >= 0) c->host_cutoff = c->host_cutoff_decode = (size_t)value; } // sets both
     else if (!strcmp(key, "host_cutoff_decode")) { prev = (int)(c->host_cutoff_decode > 0x7FFFFFFF ? 0x7FFFFFFF : c->host_cutoff_decode); if (value >= 0) c->host_cutoff_decode = (size_t)value; }
+    else if (!strcmp(key, "pipe_impl")) { prev = c->pipe_impl; if (value == 0 || value == 1) c->pipe_impl = value; }
     else if (!strcmp(key, "host_pipeline")) { prev = c->host_pipeline; if (value == 0 || value == 1) c->host_pipeline = value; }
     else if (!strcmp(key, "sweep_build")) { prev = kEvidenceBuild ? 1 : 0; }
     else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }

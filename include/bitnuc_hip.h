@@ -40,11 +40,13 @@
  *   - plain pointers + sizes, no torch / C++ types in signatures;
  *   - return value == err->status (err may be NULL);
  *   - "host" entry points take host pointers and are synchronous; large encode / decode
- *     calls (>= 8 Mi bases) are pipelined: a worker pool copies the caller's pageable memory
- *     into pinned double buffers while H2D, kernel and D2H of the neighbouring 32 Mi-base
- *     chunks overlap on three streams; 8 threads copy on the side that moves 1 B per base and 4 on
- *     the other, capped by the CPUs this process may use (affinity AND cgroup quota;
- *     BITNUC_HOST_THREADS / BITNUC_HOST_THREADS_LIGHT override, bitnuc_host_pipe_info reports);
+ *     calls (>= 8 Mi bases) are pipelined in 32 Mi-base chunks: the calling thread copies chunk c from the
+ *     caller's memory to the device and launches on it while ONE helper thread of the context copies chunk
+ *     c-1's output into the caller's memory (the runtime pins pageable buffers in place: both copies run at
+ *     the DMA rate, each blocks only the thread that issued it).  BITNUC_PIPE_IMPL=staged selects the earlier
+ *     engine instead (the library's own pinned buffers, filled and emptied by 8 + 4 copy threads, capped by the
+ *     CPUs this process may use -- affinity AND cgroup quota; BITNUC_HOST_THREADS / BITNUC_HOST_THREADS_LIGHT
+ *     override); bitnuc_host_pipe_info reports the engine and that budget;
  *     bitnuc_as_2bit_batch, bitnuc_kmer_hdist_scan, bitnuc_encode_fixed and (back-to-back reads) bitnuc_decode_fixed
  *     ride the same engine from 8 MiB of input; the other host entry points (and smaller inputs) stage through
  *     device scratch in 128 Mbase chunks;
@@ -326,7 +328,8 @@ double bitnuc_selftime_host_copy(size_t bytes, int threads, int mode);
 /* Configuration of this context's pipelined host-pointer path (creates it if needed): out[0..n) = cores_visible, cores_quota
  * (0 = none), cores_usable, chunk_bases, depth, encode stage-in / hand-back threads, decode stage-in / hand-back threads,
  * heavy_cap (the most threads the heavy side may use here), the GPU's NUMA node (-1 = unknown), the number of that node's CPUs
- * the copy workers are bound to (0 = not bound; BITNUC_PIPE_NUMA=0 disables the binding). */
+ * the staged engine's copy workers are bound to (0 = not bound; BITNUC_PIPE_NUMA=0 disables the binding), the engine in use
+ * (1 = direct, 0 = staged). */
 int bitnuc_host_pipe_info(bitnuc_ctx *ctx, double *out, int n, bitnuc_err *err);
 
 #ifdef __cplusplus

@@ -11,6 +11,7 @@
 #include "../../bitnuc_amd/csrc/host_word.h"
 #include "../../oracle/bitnuc_oracle.h"
 
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -121,8 +122,48 @@ static void pool_checks(int threads_in, int threads_out) {
     free(a); free(b2);
 }
 
+// the call pattern of pipe_run_direct (csrc/host_pipe.h): the poster fills device-buffer stand-in b = ci % depth itself ("H2D"), posts the
+// chunk's hand-back to the mover, and before it refills b waits for the ticket of the chunk that used b; an error code travels
+// back through an atomic the tasks write; leaving early drains; destruction runs what is still queued.
+static void task_thread_checks() {
+    using bitnuc_host::TaskThread;
+    const size_t sizes[] = {0, 1, 4097, (1u << 20) + 1, (3u << 20) + 5};
+    TaskThread w;
+    for (size_t n : sizes) {
+        const int depth = 3, nchunks = 11;
+        uint8_t *src = static_cast<uint8_t *>(malloc(n * nchunks + 1)), *dst = static_cast<uint8_t *>(malloc(n * nchunks + 1));
+        for (size_t i = 0; i < n * nchunks; ++i) src[i] = (uint8_t)(i * 29 + (i >> 7));
+        memset(dst, 0, n * nchunks + 1);
+        uint8_t *devbuf[3];
+        for (int b = 0; b < depth; ++b) devbuf[b] = static_cast<uint8_t *>(malloc(n + 1));
+        std::atomic<int> rc{0};
+        const uint64_t base = w.tickets();
+        for (int ci = 0; ci < nchunks; ++ci) {
+            const int b = ci % depth;
+            if (ci >= depth) w.wait_done(base + (uint64_t)(ci - depth) + 1);
+            memcpy(devbuf[b], src + (size_t)ci * n, n);
+            uint8_t *from = devbuf[b], *to = dst + (size_t)ci * n;
+            const uint64_t t = w.post([=, &rc] { memcpy(to, from, n); if (ci == 7) rc.store(7); });
+            CHECK(t == base + (uint64_t)ci + 1);
+        }
+        w.drain();
+        CHECK(rc.load() == 7 && memcmp(src, dst, n * nchunks) == 0);
+        for (int b = 0; b < depth; ++b) free(devbuf[b]);
+        free(src); free(dst);
+    }
+    w.drain(); // nothing outstanding: returns at once
+    std::atomic<int> ran{0};
+    {
+        TaskThread tmp;
+        for (int i = 0; i < 50; ++i) tmp.post([&ran] { ++ran; });
+    } // ~TaskThread runs what is queued, then joins
+    CHECK(ran.load() == 50);
+    { TaskThread idle; } // never used
+}
+
 int main() {
     host_word_checks();
+    task_thread_checks();
     for (int t = 1; t <= 9; t += 2) pool_checks(t, t);
     pool_checks(8, 3);
     pool_checks(2, 9);

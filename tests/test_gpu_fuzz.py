@@ -687,12 +687,13 @@ sys.exit(1 if fails else 0)
 """
 
 
-def test_fuzz_host_pointer_calls():
+@pytest.mark.parametrize("engine", ["staged", "direct"])
+def test_fuzz_host_pointer_calls(engine):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BITNUC_PIPE_CHUNK_MB="1")
+    env = dict(os.environ, BITNUC_PIPE_CHUNK_MB="1", BITNUC_PIPE_IMPL=engine)  # both engines of csrc/host_pipe.h
     env.pop("BITNUC_FORCE_GPU", None)
     env.pop("BITNUC_HOST_CUTOFF", None)
     r = subprocess.run([sys.executable, "-c", _HOST_FUZZ_CHILD, root], capture_output=True, text=True, timeout=1200, env=env)

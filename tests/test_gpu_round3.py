@@ -382,12 +382,13 @@ print("pipe child ok", info)
 """
 
 
-def test_pipelined_host_path_reuses_every_buffer(oracle):
+@pytest.mark.parametrize("engine", ["staged", "direct"])
+def test_pipelined_host_path_reuses_every_buffer(oracle, engine):
     """with 32 Mi-base chunks no test input reached the `ci >= depth` guards of the three-stream
     pipeline.  A fresh process with BITNUC_PIPE_CHUNK_MB=1 runs 9-12 chunks per call: every pinned / device buffer is reused
     3-4 times, encode and decode are checked against the oracle, two passes with different data over the same caller
     buffers, and invalid bytes sit in chunks >= 3 with a later invalid byte that must not win."""
-    env = dict(os.environ, BITNUC_PIPE_CHUNK_MB="1", BITNUC_HOST_CUTOFF="0")
+    env = dict(os.environ, BITNUC_PIPE_CHUNK_MB="1", BITNUC_HOST_CUTOFF="0", BITNUC_PIPE_IMPL=engine)  # both engines of csrc/host_pipe.h
     r = subprocess.run([sys.executable, "-c", _PIPE_CHILD, ROOT], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "pipe child ok" in r.stdout
