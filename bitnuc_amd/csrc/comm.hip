@@ -218,7 +218,9 @@ int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *c, bitnuc_comm *c
     const size_t count = shard_len / 32;
     const int P = comm->nranks, me = comm->rank;
     uint64_t *mine = d_all + (size_t)me * count;
-    // the transfer stream must not run ahead of what the caller already queued on the context's stream (d_all's previous readers)
+    // the transfer stream must not run ahead of what the caller already queued on the context's stream (d_all's previous readers).
+    // (Implied by the first piece_done wait below, which is recorded later on the same stream -- tools/multirank_mutation_check.py,
+    // defect C, shows no scenario needs it; kept so that the rule does not depend on the loop's first iteration.)
     HIPCHK(hipEventRecord(comm->all_moved, c->stream));
     HIPCHK(hipStreamWaitEvent(comm->xfer, comm->all_moved, 0));
     // however this call ends -- also on an error half way -- the context's stream waits for what the transfer stream was given, so

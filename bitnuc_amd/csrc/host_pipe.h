@@ -9,6 +9,11 @@
 #include <atomic>
 
 // ---- pipelined host-pointer path --------------------------------------------------------------------
+// Two engines run the same jobs (pipe_run dispatches on bitnuc_ctx::pipe_impl): the DIRECT engine ships (pipe_run_direct below: the
+// calling thread and one mover thread issue pageable copies, no pinned buffers), the STAGED engine described next is kept behind
+// BITNUC_PIPE_IMPL=staged for platforms whose runtime copies pageable memory through bounce buffers of its own.
+//
+// The staged engine:
 // A caller's buffers are pageable.  Handing them to hipMemcpyAsync makes the runtime stage them through its own
 // pinned bounce buffers on the calling thread, serialising copy-in, kernel and copy-out.  Here the library owns the
 // staging: a worker pool (host_pool.h) copies chunk c+1 from the caller's memory into one of three pinned input buffers
