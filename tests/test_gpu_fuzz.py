@@ -698,3 +698,35 @@ def test_fuzz_host_pointer_calls(engine):
     env.pop("BITNUC_HOST_CUTOFF", None)
     r = subprocess.run([sys.executable, "-c", _HOST_FUZZ_CHILD, root], capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0 and "host fuzz: 0 failing cases" in r.stdout, (r.stdout[-6000:], r.stderr[-3000:])
+
+
+def test_plan_accessors_and_host_copy_diagnostic(ctx, oracle):
+    """The small entry points nothing else calls: a plan's count / total words / device word-offset table, and the staged engine's
+    copy-rate diagnostic (argument rule + a positive rate for each of its three modes)."""
+    torch = _torch()
+    lens = np.array([0, 1, 31, 32, 33, 150, 0, 64, 1000], dtype=np.uint64)
+    off = np.zeros(lens.size + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    d_off = torch.from_numpy(off.view(np.int64)).cuda()
+    plan = bn.BatchPlan(ctx, d_off, lens.size)
+    lib = ctx._lib
+    want_wo = np.zeros(lens.size + 1, dtype=np.uint64)
+    want_wo[1:] = np.cumsum((lens + np.uint64(31)) // np.uint64(32))
+    assert lib.bitnuc_batch_plan_count(plan._h) == lens.size
+    assert lib.bitnuc_batch_plan_total_words(plan._h) == plan.total_words == int(want_wo[-1])
+    # the device table of the plan, used as the caller-provided word offsets of the table-driven encode: right words <=> right table
+    ptr = plan.word_offsets_ptr
+    assert ptr and ptr % 8 == 0
+    rng = np.random.default_rng(5)
+    s_host = draw_seq(rng, int(off[-1]))
+    d_seq = torch.from_numpy(s_host).cuda()
+    out = torch.full((int(want_wo[-1]) + 1,), -1, dtype=torch.int64, device="cuda")
+    ctx.encode_batch_dev(d_seq, d_off, ptr, lens.size, int(want_wo[-1]), out)
+    ctx.sync()
+    want = np.concatenate([oracle.encode(s_host[int(off[i]):int(off[i + 1])]) for i in range(lens.size) if lens[i]])
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:-1].view(np.uint64), want) and got[-1] == -1
+    plan.close()
+    assert lib.bitnuc_selftime_host_copy(100, 2, 0) < 0 and lib.bitnuc_selftime_host_copy(1 << 22, 0, 0) < 0 and lib.bitnuc_selftime_host_copy(1 << 22, 2, 3) < 0
+    for mode in (0, 1, 2):
+        assert lib.bitnuc_selftime_host_copy(8 << 20, 3, mode) > 0.1
