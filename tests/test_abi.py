@@ -233,3 +233,22 @@ def test_c_example_runs():
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "36 bases -> 2 words" in r.stdout and "round trip ok" in r.stdout and "InvalidBase('N') at index 3" in r.stdout, r.stdout
+
+
+def test_every_declared_symbol_is_reached_by_some_test():
+    """A symbol counts as reached when a test source (Python, C, C++), bench.py, __graft_entry__.py or the tested C++ mirror names it,
+    or when an api.py / dist.py / sequence.py method that calls it is called from one of those."""
+    import glob
+    srcs = glob.glob(os.path.join(ROOT, "tests", "*.py")) + glob.glob(os.path.join(ROOT, "tests", "c", "*.c*")) + glob.glob(os.path.join(ROOT, "tests", "cpp", "*.cpp"))
+    srcs += [os.path.join(ROOT, f) for f in ("bench.py", "__graft_entry__.py", os.path.join("include", "bitnuc.hpp"))]
+    tests = "".join(open(f).read() for f in srcs)
+    api = "".join(open(os.path.join(ROOT, "bitnuc_amd", f)).read() for f in ("api.py", "dist.py", "sequence.py"))
+    methods = re.findall(r"def (\w+)\(self[^)]*\):(.*?)(?=\n    def |\n    @|\nclass |\Z)", api, flags=re.S)
+    unreached = []
+    for sym in declared_symbols():
+        if sym in tests:
+            continue
+        callers = [m for m, body in methods if re.search(r"\b" + sym + r"\b", body)]
+        if not any(re.search(r"\." + m + r"\b", tests) for m in callers):
+            unreached.append((sym, callers))
+    assert not unreached, unreached
