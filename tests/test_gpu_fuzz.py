@@ -730,3 +730,40 @@ def test_plan_accessors_and_host_copy_diagnostic(ctx, oracle):
     assert lib.bitnuc_selftime_host_copy(100, 2, 0) < 0 and lib.bitnuc_selftime_host_copy(1 << 22, 0, 0) < 0 and lib.bitnuc_selftime_host_copy(1 << 22, 2, 3) < 0
     for mode in (0, 1, 2):
         assert lib.bitnuc_selftime_host_copy(8 << 20, 3, mode) > 0.1
+
+
+def test_host_pipeline_with_pinned_caller_memory(oracle):
+    """A caller that hands PINNED buffers to the host-pointer calls gets truly asynchronous copies from the runtime (a pageable copy
+    blocks its issuer, a pinned one does not): the direct engine's ordering must then rest on its events and tickets alone.
+    150 M bases = 5 chunks of 32 Mi (every device buffer reused), encode and decode, both engines, checked against the oracle on
+    slices and as a round trip."""
+    import torch
+    import bitnuc_amd
+    n = 150_000_001
+    nw = (n + 31) // 32
+    seq_t = torch.empty(n, dtype=torch.uint8).pin_memory()
+    words_t = torch.empty(nw, dtype=torch.int64).pin_memory()
+    back_t = torch.empty(n, dtype=torch.uint8).pin_memory()
+    seq, words, back = seq_t.numpy(), words_t.numpy().view(np.uint64), back_t.numpy()
+    rng = np.random.default_rng(77)
+    seq[:] = np.frombuffer(b"ACGTacgt", dtype=np.uint8)[rng.integers(0, 8, n)]
+    c = bitnuc_amd.Context(0)
+    for engine in (1, 0):
+        c.set_variant("pipe_impl", engine)
+        words[:] = 0
+        back[:] = 0
+        assert c.encode_into(seq, words) == nw
+        for lo in (0, 32 * 1_048_576 - 64, 32 * 3_000_000, n - 1000 - (n - 1000) % 32):
+            assert np.array_equal(words[lo // 32:(lo + 992) // 32], oracle.encode(seq[lo:lo + 992])), (engine, lo)
+        assert np.array_equal(words[-1:], oracle.encode(seq[32 * (nw - 1):]))
+        c.decode_into(words, n, back)
+        assert np.array_equal(back, seq & 0xDF), engine
+        # an invalid byte in the fourth chunk, a later one that must not win
+        seq[3 * 33_554_432 + 17] = ord("N")
+        seq[4 * 33_554_432 + 5] = ord("X")
+        with pytest.raises(bitnuc_amd.NucleotideError) as ei:
+            c.encode_into(seq, words)
+        assert (ei.value.kind, ei.value.byte, ei.value.index) == ("InvalidBase", ord("N"), 3 * 33_554_432 + 17)
+        seq[3 * 33_554_432 + 17] = ord("A")
+        seq[4 * 33_554_432 + 5] = ord("C")
+    c.close()
