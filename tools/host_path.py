@@ -3,6 +3,8 @@
 bitnuc_encode / bitnuc_decode (fresh context per setting), next to the box's pinned hipMemcpyAsync rate and the simple
 (unpipelined, runtime-staged) path."""
 import os
+
+os.environ.setdefault("BITNUC_PIPE_IMPL", "staged")  # this tool studies the STAGED engine's thread budget / placement (the direct engine ships: tools/ab_pipe_impl.py)
 import sys
 import time
 

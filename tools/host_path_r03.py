@@ -3,6 +3,8 @@
 out per base, decode the reverse: is the "pinned rate" of ONE direction the right denominator?), how the staging pools were
 sized (bitnuc_host_pipe_info), and encode / decode of 10^9 bases under a few forced settings."""
 import os
+
+os.environ.setdefault("BITNUC_PIPE_IMPL", "staged")  # this tool studies the STAGED engine's thread budget / placement (the direct engine ships: tools/ab_pipe_impl.py)
 import sys
 import time
 

@@ -3,6 +3,8 @@
 context to the next (thread and page placement lottery)?"""
 import glob
 import os
+
+os.environ.setdefault("BITNUC_PIPE_IMPL", "staged")  # this tool studies the STAGED engine's thread budget / placement (the direct engine ships: tools/ab_pipe_impl.py)
 import subprocess
 import sys
 import time
