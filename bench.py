@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--bases", type=int, default=10**9, help="bases per GPU per step (BASELINE configs[1]: 1e9)")
+    ap.add_argument("--event-every", type=int, default=10, help="record the per-kernel HIP events on every k-th timed step (1 = every step, the method of rounds 1-2: three event records per step cost 2.5 %% of the step, profiles/r03_ab_event_every.txt); never fewer than 4 sampled steps")
     ap.add_argument("--rotate", type=int, default=3, help="buffer sets rotated so the 256 MiB Infinity Cache cannot serve a step (>= 2)")
     ap.add_argument("--evidence-build", action="store_true", help="load libbitnuc_hip_sweep.so (every kernel variant) instead of the product library: for --enc-variant / --dec-variant studies only")
     ap.add_argument("--enc-variant", type=int, default=-1)
@@ -483,7 +484,8 @@ def run_rank(args, real_stdout, traffic):
         step(i)
     if ctx:
         ctx.sync()
-    events = None if rehearse else [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    ev_every = max(1, min(args.event_every, args.steps // 4))  # at least 4 sampled steps (every step when K < 8)
+    events = None if rehearse else [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if i % ev_every == 0 else None for i in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -502,8 +504,8 @@ def run_rank(args, real_stdout, traffic):
     wd.disarm()
     sec_per_step = float(elapsed.item()) / args.steps
     if events:
-        enc_ms = [e[0].elapsed_time(e[1]) for e in events]
-        dec_ms = [e[1].elapsed_time(e[2]) for e in events]
+        enc_ms = [e[0].elapsed_time(e[1]) for e in events if e]
+        dec_ms = [e[1].elapsed_time(e[2]) for e in events if e]
         enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
     else:
         enc_avg = dec_avg = None
@@ -533,6 +535,8 @@ def run_rank(args, real_stdout, traffic):
             "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident, bit-exact vs CPU oracle",
                        "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
                        "seed": hex(SEED), "rotating_buffer_sets": R,
+                       "hip_events": (f"per-kernel HIP events recorded on every {ev_every}th timed step ({len([e for e in (events or []) if e])} of {args.steps} steps): recording them on every step "
+                                      "inserts three markers per step and costs 2.5 % of it") if ev_every > 1 else "per-kernel HIP events recorded on every timed step",
                        "decode_input": "words encoded in the same step (Infinity-Cache warm)" if args.warm_decode else f"words encoded {R - 1} steps earlier (HBM resident, cache cold)",
                        "parallelism": f"shard{world}" if world > 1 else "single",
                        "control_backend": control_backend, "devices": identities,
@@ -1009,6 +1013,15 @@ def sustained_shape_probes(args, ctx, torch, stream, seqs, words, backs, n, R):
     torch.cuda.synchronize()
     e_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
     d_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+    # the same pairs with NO events in between (what the timed loop's `ms_per_step` is to be compared with: per-launch event records
+    # cost about 2.5 % of a step, profiles/r03_ab_event_every.txt)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for i in range(steps):
+        pstep(i)
+    b.record(stream)
+    torch.cuda.synchronize()
+    pair_free_ms = a.elapsed_time(b) / steps
     for r in range(R):  # the probes overwrote the packed words: restore them for what follows
         ctx.encode_dev(seqs[r], n, words[r])
     ctx.sync()
@@ -1016,6 +1029,7 @@ def sustained_shape_probes(args, ctx, torch, stream, seqs, words, backs, n, R):
     return {"encode_shape_ms": round(e_ms, 4), "decode_shape_ms": round(d_ms, 4), "ms_per_pair": round(e_ms + d_ms, 4),
             "encode_shape_gb_s": round(alg / (e_ms * 1e-3) / 1e9, 1), "decode_shape_gb_s": round(alg / (d_ms * 1e-3) / 1e9, 1),
             "pair_gb_s": round(2 * alg / ((e_ms + d_ms) * 1e-3) / 1e9, 1), "steps": steps,
+            "ms_per_pair_without_events": round(pair_free_ms, 4), "pair_gb_s_without_events": round(2 * alg / (pair_free_ms * 1e-3) / 1e9, 1),
             "note": "same bytes, same instructions shapes, same rotation as the timed step, no arithmetic between load and store"}
 
 
