@@ -13,6 +13,8 @@ concatenating all-gather of config 4 is timed separately, outside the step).
 value = bases pushed through the codec per second, whole job:
         N_gpus * (10^9 encoded + 10^9 decoded) / step time / 1e9   [Gbases/s]
         (x 1.25 algorithmic bytes per base = aggregate algorithmic GB/s).
+The two kernels of a step are timed live by HIP events on the launch stream, on every 10th timed step (--event-every; on every step
+the three markers cost 2.5 % of the step itself, profiles/r03_ab_event_every.txt); `config.hip_events` in the line says what was done.
 
 Process model
   python bench.py --gpus N            (no launcher)  the parent touches no GPU: it starts
