@@ -113,14 +113,19 @@ def self_launch(args, argv):
 # roofline.traffic: HBM bytes per launch from PMC counters, measured for THIS run's kernels
 # ---------------------------------------------------------------------------------------------
 def csrc_sha16():
-    """Identity of the kernel sources: a stored traffic figure is only valid for the same sources."""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "bitnuc_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()[:16]
+    """Identity of the kernel sources (bitnuc_amd.build.csrc_sha16: csrc/ + include/bitnuc_hip.h).  The library carries the same
+    hash (compiled in, bitnuc_version()); a stored traffic figure is only valid for the same sources."""
+    from bitnuc_amd import build as bn_build
+    return bn_build.csrc_sha16()
+
+
+def library_identity():
+    """What was timed: the hash the loaded product library reports for itself next to the hash of the sources on disk (equal, or
+    bitnuc_amd refuses to load it), and whether this run had to rebuild it."""
+    from bitnuc_amd import _lib, build as bn_build
+    ver = _lib.load().bitnuc_version().decode()
+    return {"csrc_sha16": bn_build.csrc_sha16(), "library_csrc_sha16": ver.split("csrc:")[-1].split()[0] if "csrc:" in ver else None,
+            "library": bn_build.LAST_ACTION.get(bn_build.LIB, "as shipped"), "version": ver}
 
 
 def git_head():
@@ -336,13 +341,14 @@ def run_rank(args, real_stdout, traffic):
         import bitnuc_amd
         from bitnuc_amd import build as bn_build
         # a fresh checkout has no libbitnuc_hip.so (git-ignored): local rank 0 compiles it, the others wait for the file
+        # ... and a library that travelled with the tree but was built from other sources is rebuilt the same way (the line says so)
         if local_rank == 0:
             bn_build.ensure_built()
         else:
             t_wait = time.time()
-            while not os.path.exists(bn_build.LIB):
+            while bn_build.is_stale(bn_build.LIB):
                 if time.time() - t_wait > 600:
-                    raise RuntimeError(f"{bn_build.LIB} did not appear: there is no CPU fallback")
+                    raise RuntimeError(f"{bn_build.LIB} (csrc:{bn_build.csrc_sha16()}) did not appear: there is no CPU fallback")
                 time.sleep(1.0)
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -551,6 +557,7 @@ def run_rank(args, real_stdout, traffic):
             line.update(extra)
             return line
         line["config"].update({"encode_variant": ctx.get("encode"), "decode_variant": ctx.get("decode"), "grid_mult": ctx.get("grid_mult")})
+        line["config"].update({k: v for k, v in library_identity().items() if k != "csrc_sha16"})  # the binary that was timed, held against the sources
         # the same measurement, three readings (value is the first): bases through the codec per
         # second (encoded + decoded), and the per-kernel rates from the HIP events of rank 0
         line.update({"codec_gbases_s": round(total_bases / sec_per_step / 1e9, 2),
@@ -1179,6 +1186,8 @@ def main():
     traffic = None
     if not args.rehearse_cpu:
         if args.gpus == 1 and not in_rank and not args.no_traffic:
+            from bitnuc_amd import build as bn_build
+            bn_build.ensure_built()  # before any child runs under rocprofv3: a profiled process must not start the compiler
             traffic = measure_traffic_live(args.bases)  # child processes under rocprofv3; this process has not touched the GPU yet
             if "error" in traffic:
                 print(f"[bench] live PMC pass unavailable: {traffic['error']}", file=sys.stderr)

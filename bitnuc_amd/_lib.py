@@ -81,13 +81,16 @@ SIGNATURES = {
     "bitnuc_comm_get_unique_id": (C.c_int, [_P, _ERR]),
     "bitnuc_comm_init_rank": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(_P), _ERR]),
     "bitnuc_comm_init_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), _ERR]),
+    "bitnuc_comm_init_all_devices": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _ERR]),
     "bitnuc_comm_destroy": (None, [_P]),
     "bitnuc_comm_nranks": (C.c_int, [_P]),
     "bitnuc_comm_rank": (C.c_int, [_P]),
+    "bitnuc_comm_single_process": (C.c_int, [_P]),
     "bitnuc_allgather_words_dev": (C.c_int, [_P, _P, _P, _SZ, _P, _ERR]),
     "bitnuc_encode_sharded_allgather_dev": (C.c_int, [_P, _P, _P, _SZ, _P, _ERR]),
     "bitnuc_encode_sharded_allgather_overlapped_dev": (C.c_int, [_P, _P, _P, _SZ, C.c_int, _P, _ERR]),
     "bitnuc_encode_sharded_allgather_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, C.POINTER(_P), _ERR]),
+    "bitnuc_encode_sharded_allgather_overlapped_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, C.c_int, C.POINTER(_P), _ERR]),
     "bitnuc_nucgen_dev": (C.c_int, [_P, _P, _SZ, _U64, _U64, C.c_int, _ERR]),
     "bitnuc_stream_probe_dev": (C.c_int, [_P, C.c_int, _P, _P, _SZ, _ERR]),
     "bitnuc_selftime_small": (C.c_double, [C.c_int, _SZ, _SZ]),
@@ -147,6 +150,13 @@ def load(path=None):
         raise RuntimeError(
             f"{path} is missing: build it with `python -m bitnuc_amd.build` "
             "(hipcc, gfx950). bitnuc_amd has no CPU fallback.")
+    if os.path.isdir(os.path.join(HERE, "csrc")) and not os.environ.get("BITNUC_ALLOW_STALE_LIB"):
+        # the sources are beside the binary (a checkout, not an installed package): refuse a binary that was not built from them
+        from . import build
+        have, want = build.library_sha16(path), build.csrc_sha16()
+        if have != want:
+            raise RuntimeError(f"{path} was built from other sources (library csrc:{have}, sources csrc:{want}): rebuild with "
+                               "`python -m bitnuc_amd.build` (bitnuc_amd.build.ensure_built() does it) or set BITNUC_ALLOW_STALE_LIB=1")
     _share_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():

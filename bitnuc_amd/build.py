@@ -28,11 +28,38 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: libbitnuc_hip.so cannot be built (there is no CPU fallback)")
 
 
+def csrc_sha16():
+    """Identity of the sources the library is compiled from (csrc/*.h, csrc/*.hip, include/bitnuc_hip.h): compiled into every
+    build as -DBITNUC_CSRC_SHA and returned by bitnuc_version(), so that a binary can be held against the sources beside it."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+_SHA_MARK = b" gfx950 csrc:"  # runtime.hip: bitnuc_version() == "bitnuc_hip <ver> gfx950 csrc:<16 hex digits>[ sweep]"
+
+
+def library_sha16(lib=LIB):
+    """The csrc_sha16 a built library carries, read from the file (no dlopen: a stale library must not enter the process that
+    is about to replace it).  None for a missing file or a library from before the identity was compiled in."""
+    try:
+        data = open(lib, "rb").read()
+    except OSError:
+        return None
+    i = data.find(_SHA_MARK)
+    if i < 0:
+        return None
+    sha = data[i + len(_SHA_MARK): i + len(_SHA_MARK) + 16]
+    return sha.decode() if len(sha) == 16 and all(c in b"0123456789abcdef" for c in sha) else None
+
+
 def is_stale(lib=LIB):
-    if not os.path.exists(lib):
-        return True
-    t = os.path.getmtime(lib)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    """True when `lib` is missing or was not compiled from the sources on disk (by content, not by file time: times do not
+    survive every copy of a tree)."""
+    return library_sha16(lib) != csrc_sha16()
 
 
 def build_library(force=False, verbose=True, extra_flags=(), sweep=False, jobs=None, out=None):
@@ -46,7 +73,7 @@ def build_library(force=False, verbose=True, extra_flags=(), sweep=False, jobs=N
     if not force and not is_stale(lib):
         return lib
     hipcc = hipcc_path()
-    flags = CXXFLAGS + list(extra_flags) + (["-DBITNUC_SWEEP_VARIANTS"] if sweep else [])
+    flags = CXXFLAGS + list(extra_flags) + (["-DBITNUC_SWEEP_VARIANTS"] if sweep else []) + [f'-DBITNUC_CSRC_SHA="{csrc_sha16()}"']
     if jobs is None:
         jobs = max(1, min(len(UNITS), len(os.sched_getaffinity(0))))
     tmp = f"{lib}.tmp.{os.getpid()}"  # other processes (bench ranks) only ever see a complete library
@@ -94,12 +121,35 @@ def write_build_info():
         json.dump({"commit": head, "csrc_dirty": dirty, "built": datetime.datetime.now().isoformat(timespec="seconds")}, f)
 
 
-def ensure_built(sweep=False):
-    """Build the library only if it is missing (a fresh checkout: the .so is git-ignored).  An existing
-    library is used as is -- file times do not survive every copy, so staleness is `build_library`'s business."""
-    lib = LIB_SWEEP if sweep else LIB
-    if not os.path.exists(lib):
-        build_library(force=True, sweep=sweep)
+def under_profiler():
+    """True in a process started under rocprofv3 (its tool library is preloaded and initialises the GPU before the program
+    starts): such a process must not start a compiler chain -- every exec in it is the exec-after-GPU-init this pool forbids."""
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return True
+    return any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ)
+
+
+LAST_ACTION = {}  # library path -> "as shipped" | "rebuilt on this box" (what ensure_built did in this process; bench.py reports it)
+
+
+def ensure_built(sweep=False, build=True, lib=None):
+    """The library for the sources on disk.  A library that is missing (a fresh checkout: the .so is git-ignored) or that carries
+    another csrc_sha16 than the sources beside it (it was built before an edit and travelled with the tree) is REBUILT in place
+    when `build` is true; with build=False -- processes started under rocprofv3, whose children must not be a compiler chain --
+    that is an error telling the caller to build first.  Never silently uses a binary that is not the sources'."""
+    lib = lib or (LIB_SWEEP if sweep else LIB)
+    if not is_stale(lib):
+        LAST_ACTION.setdefault(lib, "as shipped")
+        return lib
+    have = library_sha16(lib)
+    what = f"{lib} is missing" if not os.path.exists(lib) else f"{lib} was built from other sources (library csrc:{have}, sources csrc:{csrc_sha16()})"
+    if not build or under_profiler() or os.environ.get("BITNUC_NO_BUILD"):
+        raise RuntimeError(what + ": run `python3 -m bitnuc_amd.build" + (" --sweep" if sweep else "") + "` first (this process may not start a compiler: it runs under a profiler or BITNUC_NO_BUILD is set)")
+    print(f"[bitnuc_amd.build] {what}: rebuilding", file=sys.stderr)
+    build_library(force=True, sweep=sweep, verbose=False, out=None if lib in (LIB, LIB_SWEEP) else lib)
+    if is_stale(lib):
+        raise RuntimeError(f"{lib}: still not the sources' library after a rebuild")
+    LAST_ACTION[lib] = "rebuilt on this box"
     return lib
 
 

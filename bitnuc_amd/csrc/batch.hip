@@ -463,16 +463,19 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
 
 // Host-pointer fixed-length reads through the pipelined staging engine (host_pipe.h): a chunk is as many whole reads as fit both
 // pinned buffers (their bytes in an A buffer, their words in a B buffer; decode the other way round).
+constexpr int kNotPipelined = -1; // not a bitnuc_status: "this shape does not fit the engine, use the staged loop"
 static int fixed_pipelined(bitnuc_ctx *c, bool encode, const uint8_t *seq, const uint64_t *words, size_t read_len, size_t stride, size_t count,
                            uint64_t *out_words, uint8_t *out_seq, bitnuc_err *err) {
     HostPipe *p;
     if (int st = pipe_get(c, &p, err)) return st;
-    PipeAbort guard{c, p};
     const size_t wpr = words_for(read_len);
     size_t per = (p->chunk / 4) / (8 * wpr);
     const size_t by_bytes = p->chunk > read_len ? (p->chunk - read_len) / stride + 1 : 0;
     if (by_bytes < per) per = by_bytes;
-    if (per == 0) return fail(err, BITNUC_UNSUPPORTED); // a read larger than a chunk: the caller falls back to the simple path
+    // a read larger than a chunk (today unreachable: the callers admit read_len, stride < 1 Mi and a chunk is at least 1 MiB): nothing
+    // has been started, the pipe is intact, the caller goes on to its staged-scratch loop
+    if (per == 0) return kNotPipelined;
+    PipeAbort guard{c, p};
     struct Job {
         bitnuc_ctx *c; bool encode; const uint8_t *seq; const uint64_t *words; size_t read_len, stride, count, per, wpr; uint64_t *out_words; uint8_t *out_seq;
         size_t nchunks; int in_kind, out_kind, in_threads, out_threads;
@@ -511,8 +514,10 @@ int bitnuc_encode_fixed(bitnuc_ctx *c, const uint8_t *seq, size_t read_len, size
     if (stride < read_len || !seq || !out) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
     if (int st = flush_pending(c, err)) return st;
-    if (c->host_pipeline && (count - 1) * stride + read_len >= kPipeMin && stride < ((size_t)1 << 20))
-        return fixed_pipelined(c, true, seq, nullptr, read_len, stride, count, out, nullptr, err);
+    if (c->host_pipeline && (count - 1) * stride + read_len >= kPipeMin && stride < ((size_t)1 << 20)) {
+        const int st = fixed_pipelined(c, true, seq, nullptr, read_len, stride, count, out, nullptr, err);
+        if (st != kNotPipelined) return st;
+    }
     const size_t wpr = words_for(read_len);
     size_t per = kHostChunk / stride; // reads per staged chunk
     if (per == 0) per = 1;
@@ -542,7 +547,8 @@ int bitnuc_decode_fixed(bitnuc_ctx *c, const uint64_t *words, size_t read_len, s
     // back-to-back reads only: with separators the bytes between reads are the caller's and would have to travel both ways
     if (c->host_pipeline && stride == read_len && count * read_len >= kPipeMin && read_len < ((size_t)1 << 20)) {
         if (int st = flush_pending(c, err)) return st;
-        return fixed_pipelined(c, false, nullptr, words, read_len, stride, count, nullptr, out, err);
+        const int st = fixed_pipelined(c, false, nullptr, words, read_len, stride, count, nullptr, out, err);
+        if (st != kNotPipelined) return st;
     }
     const size_t wpr = words_for(read_len);
     size_t per = kHostChunk / stride;

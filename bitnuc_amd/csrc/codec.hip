@@ -479,6 +479,9 @@ int bitnuc_decode(bitnuc_ctx *c, const uint64_t *ebuf, size_t n_words, size_t n_
     }
     if (int st = check_ctx(c, err)) return st;
     DeviceGuard g(c->device);
+    // like every host-pointer call: an InvalidBase latched by earlier asynchronous launches stays for the next bitnuc_ctx_sync
+    // (decode itself latches nothing, but the pipeline's abort path drains the ring and would drop it)
+    if (int st = flush_pending(c, err)) return st;
     if (c->host_pipeline && n_bases >= kPipeMin) return decode_pipelined(c, ebuf, n_bases, out, err);
     const size_t chunk = n_bases < kHostChunk ? n_bases : kHostChunk;
     if (int st = ensure_scratch(c, 0, chunk + 16, err)) return st;

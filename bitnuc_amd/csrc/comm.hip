@@ -78,6 +78,10 @@ double now_s() {
 struct bitnuc_comm {
     void *nccl = nullptr; // ncclComm_t
     int nranks = 0, rank = 0, device = 0;
+    // created by bitnuc_comm_init_all[_devices]: ONE host thread holds every rank of the communicator, so an exchange must be issued
+    // for all ranks inside one ncclGroupStart / ncclGroupEnd (the _all entry points).  A per-rank call from that thread would block in
+    // its group's end waiting for peers that the same thread has not yet been able to issue: the per-rank entry points refuse it.
+    bool single_process = false;
     hipStream_t xfer = nullptr;        // the second stream of the chunked overlap (created on first use)
     std::vector<hipEvent_t> piece_done; // piece c encoded (recorded on the context's stream)
     hipEvent_t all_moved = nullptr;     // every piece exchanged (recorded on xfer)
@@ -94,6 +98,43 @@ int comm_overlap_resources(bitnuc_comm *comm, int n_chunks, bitnuc_err *err) {
         comm->piece_done.push_back(e);
     }
     return BITNUC_OK;
+}
+
+// see bitnuc_comm::single_process (a communicator of one rank has no peer to wait for)
+bool per_rank_call_would_block(const bitnuc_comm *comm) { return comm->single_process && comm->nranks > 1; }
+
+bool gather_by_broadcast() {
+    static const bool bcast = [] { const char *e = getenv("BITNUC_GATHER_MODE"); return e && !strcmp(e, "bcast"); }();
+    return bcast;
+}
+
+// the arguments every _all entry point shares: n_gpus contexts + the communicators bitnuc_comm_init_all made for them, in rank order
+int check_all_args(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err) {
+    if (n_gpus < 1 || n_gpus > 64 || !ctxs || !comms || !d_seq_shards || !d_alls) return fail(err, BITNUC_UNSUPPORTED);
+    for (int i = 0; i < n_gpus; ++i) {
+        if (!ctxs[i] || !comms[i]) return fail(err, BITNUC_UNSUPPORTED);
+        if (!comms[i]->single_process || comms[i]->nranks != n_gpus || comms[i]->rank != i || comms[i]->device != ctxs[i]->device) return fail(err, BITNUC_UNSUPPORTED);
+    }
+    if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
+    if (shard_len)
+        for (int i = 0; i < n_gpus; ++i)
+            if (!d_seq_shards[i] || !d_alls[i] || (reinterpret_cast<uintptr_t>(d_alls[i]) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    return BITNUC_OK;
+}
+
+// Wait for every rank's stream; the first data error in rank order is the call's (err.value = that rank, err.index relative to its shard).
+int sync_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_err *err) {
+    int st_first = BITNUC_OK;
+    for (int i = 0; i < n_gpus; ++i) {
+        bitnuc_err e;
+        const int st = bitnuc_ctx_sync(ctxs[i], &e);
+        if (st != BITNUC_OK && st_first == BITNUC_OK) {
+            st_first = st;
+            if (st == BITNUC_INVALID_BASE) e.value = (uint64_t)i;
+            if (err) *err = e;
+        }
+    }
+    return st_first;
 }
 
 } // namespace
@@ -130,30 +171,33 @@ int bitnuc_comm_init_rank(bitnuc_ctx *c, int nranks, int rank, const uint8_t id[
     return BITNUC_OK;
 }
 
-int bitnuc_comm_init_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, bitnuc_err *err) {
+int bitnuc_comm_init_all_devices(int n_gpus, const int *devices, bitnuc_ctx **ctxs, bitnuc_comm **comms, bitnuc_err *err) {
     clear_err(err);
     if (n_gpus < 1 || n_gpus > 64 || !ctxs || !comms) return fail(err, BITNUC_UNSUPPORTED);
     RcclApi &r = rccl();
     if (!r.ok) return fail_rccl(err, -1);
-    for (int i = 0; i < n_gpus; ++i) { ctxs[i] = nullptr; comms[i] = nullptr; }
+    int devs[64];
+    for (int i = 0; i < n_gpus; ++i) { ctxs[i] = nullptr; comms[i] = nullptr; devs[i] = devices ? devices[i] : i; }
     for (int i = 0; i < n_gpus; ++i)
-        if (int st = bitnuc_ctx_create(i, &ctxs[i], err)) {
+        if (int st = bitnuc_ctx_create(devs[i], &ctxs[i], err)) {
             for (int j = 0; j < i; ++j) { bitnuc_ctx_destroy(ctxs[j]); ctxs[j] = nullptr; }
             return st;
         }
     void *raw[64];
-    int devs[64];
-    for (int i = 0; i < n_gpus; ++i) devs[i] = i;
     if (int rc = r.CommInitAll(raw, n_gpus, devs)) {
         for (int j = 0; j < n_gpus; ++j) { bitnuc_ctx_destroy(ctxs[j]); ctxs[j] = nullptr; }
         return fail_rccl(err, rc);
     }
     for (int i = 0; i < n_gpus; ++i) {
         bitnuc_comm *bc = new bitnuc_comm();
-        bc->nccl = raw[i]; bc->nranks = n_gpus; bc->rank = i; bc->device = i;
+        bc->nccl = raw[i]; bc->nranks = n_gpus; bc->rank = i; bc->device = devs[i]; bc->single_process = true;
         comms[i] = bc;
     }
     return BITNUC_OK;
+}
+
+int bitnuc_comm_init_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, bitnuc_err *err) {
+    return bitnuc_comm_init_all_devices(n_gpus, nullptr, ctxs, comms, err);
 }
 
 void bitnuc_comm_destroy(bitnuc_comm *comm) {
@@ -170,11 +214,12 @@ void bitnuc_comm_destroy(bitnuc_comm *comm) {
 
 int bitnuc_comm_nranks(const bitnuc_comm *comm) { return comm ? comm->nranks : 0; }
 int bitnuc_comm_rank(const bitnuc_comm *comm) { return comm ? comm->rank : -1; }
+int bitnuc_comm_single_process(const bitnuc_comm *comm) { return comm ? (int)comm->single_process : -1; }
 
 int bitnuc_allgather_words_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint64_t *d_local, size_t count, uint64_t *d_all, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
-    if (!comm || comm->device != c->device) return fail(err, BITNUC_UNSUPPORTED);
+    if (!comm || comm->device != c->device || per_rank_call_would_block(comm)) return fail(err, BITNUC_UNSUPPORTED);
     if (count == 0) return BITNUC_OK;
     if (!d_local || !d_all) return fail(err, BITNUC_UNSUPPORTED);
     RcclApi &r = rccl();
@@ -187,7 +232,7 @@ int bitnuc_allgather_words_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint64_t 
 int bitnuc_encode_sharded_allgather_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, uint64_t *d_all, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
-    if (!comm || comm->device != c->device) return fail(err, BITNUC_UNSUPPORTED);
+    if (!comm || comm->device != c->device || per_rank_call_would_block(comm)) return fail(err, BITNUC_UNSUPPORTED);
     // every rank contributes the same number of whole words: shard_len must be a multiple of 32
     // (ragged tails belong in the last rank of a bitnuc_amd.dist.shard_range-style split + padding)
     if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
@@ -206,7 +251,7 @@ int bitnuc_encode_sharded_allgather_dev(bitnuc_ctx *c, bitnuc_comm *comm, const 
 int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, int n_chunks, uint64_t *d_all, bitnuc_err *err) {
     clear_err(err);
     if (int st = check_ctx(c, err)) return st;
-    if (!comm || comm->device != c->device || n_chunks < 1 || n_chunks > 4096) return fail(err, BITNUC_UNSUPPORTED);
+    if (!comm || comm->device != c->device || per_rank_call_would_block(comm) || n_chunks < 1 || n_chunks > 4096) return fail(err, BITNUC_UNSUPPORTED);
     if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
     if (shard_len == 0) return BITNUC_OK;
     if (!d_seq_shard || !d_all || (reinterpret_cast<uintptr_t>(d_all) & 7)) return fail(err, BITNUC_UNSUPPORTED);
@@ -214,7 +259,7 @@ int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *c, bitnuc_comm *c
     if (!r.ok) return fail_rccl(err, -1);
     DeviceGuard g(c->device);
     if (int st = comm_overlap_resources(comm, n_chunks, err)) return st;
-    static const bool bcast = [] { const char *e = getenv("BITNUC_GATHER_MODE"); return e && !strcmp(e, "bcast"); }();
+    const bool bcast = gather_by_broadcast();
     const size_t count = shard_len / 32;
     const int P = comm->nranks, me = comm->rank;
     uint64_t *mine = d_all + (size_t)me * count;
@@ -259,28 +304,93 @@ int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *c, bitnuc_comm *c
 
 int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err) {
     clear_err(err);
-    if (n_gpus < 1 || !ctxs || !comms || !d_seq_shards || !d_alls) return fail(err, BITNUC_UNSUPPORTED);
-    if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
+    if (int st = check_all_args(n_gpus, ctxs, comms, d_seq_shards, shard_len, d_alls, err)) return st;
     if (shard_len == 0) return BITNUC_OK;
     RcclApi &r = rccl();
     if (!r.ok) return fail_rccl(err, -1);
     const size_t count = shard_len / 32;
     for (int i = 0; i < n_gpus; ++i) // encode phase: independent, no communication
-        if (int st = bitnuc_encode_dev(ctxs[i], d_seq_shards[i], shard_len, d_alls[i] + (size_t)i * count, err)) return st;
+        if (int st = bitnuc_encode_dev(ctxs[i], d_seq_shards[i], shard_len, d_alls[i] + (size_t)i * count, err)) { (void)sync_all(n_gpus, ctxs, nullptr); return st; }
     if (int rc = r.GroupStart()) return fail_rccl(err, rc);
-    for (int i = 0; i < n_gpus; ++i) {
+    int rc = 0;
+    for (int i = 0; i < n_gpus && rc == 0; ++i) {
         DeviceGuard g(ctxs[i]->device);
-        if (int rc = r.AllGather(d_alls[i] + (size_t)i * count, d_alls[i], count, kNcclUint64, comms[i]->nccl, ctxs[i]->stream)) {
-            (void)r.GroupEnd();
-            return fail_rccl(err, rc);
+        rc = r.AllGather(d_alls[i] + (size_t)i * count, d_alls[i], count, kNcclUint64, comms[i]->nccl, ctxs[i]->stream);
+    }
+    const int rc_end = r.GroupEnd();
+    const int st = sync_all(n_gpus, ctxs, err);
+    if (rc) return fail_rccl(err, rc);
+    if (rc_end) return fail_rccl(err, rc_end);
+    return st;
+}
+
+// The chunked in-place exchange of bitnuc_encode_sharded_allgather_overlapped_dev, driven for ALL ranks by the calling thread: piece
+// by piece, every device's stream gets its encode, then ONE ncclGroupStart ... every rank's sends and receives (on that rank's
+// transfer stream) ... ncclGroupEnd -- the form RCCL requires of a thread that holds several ranks.  Synchronises every stream
+// before it returns, like the one-shot _all form.
+int bitnuc_encode_sharded_allgather_overlapped_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, int n_chunks, uint64_t *const *d_alls, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_all_args(n_gpus, ctxs, comms, d_seq_shards, shard_len, d_alls, err)) return st;
+    if (n_chunks < 1 || n_chunks > 4096) return fail(err, BITNUC_UNSUPPORTED);
+    if (shard_len == 0) return BITNUC_OK;
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    const bool bcast = gather_by_broadcast();
+    const size_t count = shard_len / 32;
+    const int P = n_gpus;
+    for (int i = 0; i < P; ++i) {
+        DeviceGuard g(ctxs[i]->device);
+        if (int st = comm_overlap_resources(comms[i], n_chunks, err)) return st;
+        // rank i's transfer stream starts behind what its context's stream already holds (d_alls[i]'s previous readers)
+        HIPCHK(hipEventRecord(comms[i]->all_moved, ctxs[i]->stream));
+        HIPCHK(hipStreamWaitEvent(comms[i]->xfer, comms[i]->all_moved, 0));
+    }
+    // however the loop below ends, every context's stream is made to wait for its transfer stream and is then synchronised, so the
+    // caller owns all buffers again when this returns
+    auto finish = [&](int st_call, bitnuc_err *e_call) {
+        for (int i = 0; i < P; ++i) {
+            DeviceGuard g(ctxs[i]->device);
+            if (hipEventRecord(comms[i]->all_moved, comms[i]->xfer) == hipSuccess) (void)hipStreamWaitEvent(ctxs[i]->stream, comms[i]->all_moved, 0);
+            else (void)hipGetLastError();
         }
+        bitnuc_err e_sync;
+        const int st_sync = sync_all(P, ctxs, &e_sync);
+        if (st_call != BITNUC_OK) { if (err && e_call) *err = *e_call; return st_call; }
+        if (st_sync != BITNUC_OK && err) *err = e_sync;
+        return st_sync;
+    };
+    bitnuc_err e;
+    memset(&e, 0, sizeof e);
+    for (int p = 0; p < n_chunks; ++p) {
+        const size_t w0 = count * (size_t)p / (size_t)n_chunks, w1 = count * (size_t)(p + 1) / (size_t)n_chunks;
+        if (w1 == w0) continue;
+        for (int i = 0; i < P; ++i) { // piece p of every shard: encode on the rank's own stream, then release it to the rank's transfer stream
+            DeviceGuard g(ctxs[i]->device);
+            uint64_t *mine = d_alls[i] + (size_t)i * count;
+            if (int st = encode_dev_at(ctxs[i], d_seq_shards[i] + 32 * w0, 32 * (w1 - w0), mine + w0, 32ull * w0, &e)) return finish(st, &e);
+            hipError_t h = hipEventRecord(comms[i]->piece_done[(size_t)p], ctxs[i]->stream);
+            if (h == hipSuccess) h = hipStreamWaitEvent(comms[i]->xfer, comms[i]->piece_done[(size_t)p], 0);
+            if (h != hipSuccess) { fail_hip(&e, h); return finish(BITNUC_BACKEND_ERROR, &e); }
+        }
+        if (P == 1) continue;
+        if (int rc = r.GroupStart()) { fail_rccl(&e, rc); return finish(BITNUC_BACKEND_ERROR, &e); }
+        int rc = 0;
+        for (int i = 0; i < P && rc == 0; ++i) {
+            DeviceGuard g(ctxs[i]->device);
+            uint64_t *mine = d_alls[i] + (size_t)i * count;
+            for (int s = 0; s < P && rc == 0; ++s) {
+                uint64_t *theirs = d_alls[i] + (size_t)s * count + w0;
+                if (bcast) rc = r.Broadcast(theirs, theirs, w1 - w0, kNcclUint64, s, comms[i]->nccl, comms[i]->xfer);
+                else if (s != i) {
+                    rc = r.Send(mine + w0, w1 - w0, kNcclUint64, s, comms[i]->nccl, comms[i]->xfer);
+                    if (rc == 0) rc = r.Recv(theirs, w1 - w0, kNcclUint64, s, comms[i]->nccl, comms[i]->xfer);
+                }
+            }
+        }
+        const int rc_end = r.GroupEnd();
+        if (rc || rc_end) { fail_rccl(&e, rc ? rc : rc_end); return finish(BITNUC_BACKEND_ERROR, &e); }
     }
-    if (int rc = r.GroupEnd()) return fail_rccl(err, rc);
-    for (int i = 0; i < n_gpus; ++i) {
-        bitnuc_err e;
-        if (int st = bitnuc_ctx_sync(ctxs[i], &e)) { if (err) *err = e; return st; }
-    }
-    return BITNUC_OK;
+    return finish(BITNUC_OK, nullptr);
 }
 
 // ---- xGMI link probe (measure the per-link rate on the box before quoting a fabric roofline) -----------

@@ -54,6 +54,8 @@ struct bitnuc_ctx {
     // ---- scratch ----
     uint8_t *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool scratch_in_graph[8] = {false, false, false, false, false, false, false, false}; // handed to a launch recorded into a hipGraph: never freed before the context
+    std::vector<uint8_t *> retired_scratch; // ... outgrown since: alive until bitnuc_ctx_destroy (a replay still writes through them)
     uint32_t *d_sink = nullptr;
     unsigned long long *d_acc = nullptr; // accumulators of the single-launch reductions, zero between launches: [0..2] base_counts C,G,T; [4] hdist (u32); [5] scan count
     unsigned *d_tickets = nullptr;       // [0] base_counts, [1] hdist, [2] scan count: arrival counters, zero between launches

@@ -99,11 +99,26 @@ void defer(bitnuc_ctx *c, const bitnuc_err &e) {
 namespace bitnuc_rt {
 
 int ensure_scratch(bitnuc_ctx *c, int which, size_t bytes, bitnuc_err *err) {
-    if (bytes <= c->scratch_cap[which]) return BITNUC_OK;
+    const bool capturing = stream_is_capturing(c->stream);
+    if (bytes <= c->scratch_cap[which]) {
+        // the launches that follow bake this buffer's address into the graph being recorded: it must outlive every replay
+        if (capturing) c->scratch_in_graph[which] = true;
+        return BITNUC_OK;
+    }
+    // Growth is an allocation (and, for a buffer no graph holds, a wait for the stream + a free): impossible while the stream is being
+    // captured -- refused before anything is touched, the capture stays valid.  Warm up with the largest batch first, or use
+    // bitnuc_batch_plan (its tables are the plan's own, sized once).
+    if (capturing) return fail(err, BITNUC_UNSUPPORTED, bytes);
     const size_t old_cap = c->scratch_cap[which];
     if (c->scratch[which]) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        HIPCHK(hipFree(c->scratch[which]));
+        if (c->scratch_in_graph[which]) {
+            // a recorded graph will write through the old address at its next replay: keep the old buffer alive until the context goes
+            c->retired_scratch.push_back(c->scratch[which]);
+            c->scratch_in_graph[which] = false;
+        } else {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipFree(c->scratch[which]));
+        }
         c->scratch[which] = nullptr;
         c->scratch_cap[which] = 0;
     }
@@ -181,7 +196,10 @@ void set_last_slot_base(bitnuc_ctx *c, unsigned long long base) {
 // =====================================================================================
 extern "C" {
 
-const char *bitnuc_version(void) { return "bitnuc_hip 0.3.0 gfx950"; }
+#ifndef BITNUC_CSRC_SHA
+#define BITNUC_CSRC_SHA "unknown" // bitnuc_amd/build.py passes the hash of csrc/ + include/bitnuc_hip.h; a build without it cannot be held against its sources
+#endif
+const char *bitnuc_version(void) { return kEvidenceBuild ? "bitnuc_hip 0.4.0 gfx950 csrc:" BITNUC_CSRC_SHA " sweep" : "bitnuc_hip 0.4.0 gfx950 csrc:" BITNUC_CSRC_SHA; }
 
 int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, bitnuc_err *err) {
     clear_err(err);
@@ -248,6 +266,7 @@ void bitnuc_ctx_destroy(bitnuc_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 8; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    for (uint8_t *p : c->retired_scratch) (void)hipFree(p);
     for (SlotBlock &b : c->slots) slot_block_free(&b);
     if (c->d_cap) (void)hipFree(c->d_cap);
     if (c->h_cap) (void)hipHostFree(c->h_cap);
@@ -269,9 +288,11 @@ int bitnuc_ctx_sync(bitnuc_ctx *c, bitnuc_err *err) {
     bitnuc_err e;
     int st = drain_scope(c, &e, kDrainAll);
     if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
-    if (c->have_deferred) { // an earlier implicit drain saw an error first
+    if (c->have_deferred) { // an earlier implicit drain saw an error first: it is this sync's; what this drain found waits for the next one
+        const bitnuc_err first = c->deferred;
         c->have_deferred = false;
-        e = c->deferred;
+        if (st != BITNUC_OK) defer(c, e);
+        e = first;
         st = e.status;
     }
     if (err) *err = e;

@@ -259,17 +259,30 @@ int bitnuc_split_packed_dev(bitnuc_ctx *ctx, const uint64_t *d_ebuf, size_t n_wo
  * multiples of 32 bases encodes shard by shard with no communication; the only exchange is the
  * optional concatenation of the packed words, one RCCL all-gather over xGMI.  A communicator
  * rank is bound to one context (one device + stream).  librccl.so is loaded on first use.
- *   - one process per GPU: rank 0 calls bitnuc_comm_get_unique_id, hands the 128 bytes to the
- *     other ranks (env, file, MPI, torch.distributed ...), every rank calls bitnuc_comm_init_rank;
- *   - one process, all GPUs: bitnuc_comm_init_all creates n contexts + communicators at once. */
+ *   - one process (or thread) per GPU: rank 0 calls bitnuc_comm_get_unique_id, hands the 128 bytes to the
+ *     other ranks (env, file, MPI, torch.distributed ...), every rank calls bitnuc_comm_init_rank and then
+ *     the per-rank entry points (bitnuc_allgather_words_dev, bitnuc_encode_sharded_allgather_dev,
+ *     bitnuc_encode_sharded_allgather_overlapped_dev), EACH RANK FROM ITS OWN THREAD OR PROCESS: like every
+ *     collective they complete only when all ranks have called them, and RCCL may block the calling thread
+ *     until its peers have;
+ *   - one thread, all GPUs: bitnuc_comm_init_all[_devices] creates n contexts + communicators at once; that
+ *     thread then drives all ranks with the _all entry points (bitnuc_encode_sharded_allgather_all,
+ *     bitnuc_encode_sharded_allgather_overlapped_all), which issue every rank's part of an exchange inside one
+ *     ncclGroupStart / ncclGroupEnd.  The per-rank entry points REFUSE such a communicator of more than one
+ *     rank (BITNUC_UNSUPPORTED): called rank after rank from the one thread, the first call would wait for
+ *     peers that thread has not reached yet.  bitnuc_comm_single_process() tells the two kinds apart. */
 typedef struct bitnuc_comm bitnuc_comm;
 #define BITNUC_UNIQUE_ID_BYTES 128
 int bitnuc_comm_get_unique_id(uint8_t id[BITNUC_UNIQUE_ID_BYTES], bitnuc_err *err);
 int bitnuc_comm_init_rank(bitnuc_ctx *ctx, int nranks, int rank, const uint8_t id[BITNUC_UNIQUE_ID_BYTES], bitnuc_comm **out, bitnuc_err *err);
 int bitnuc_comm_init_all(int n_gpus, bitnuc_ctx **ctxs /* out: n_gpus */, bitnuc_comm **comms /* out: n_gpus */, bitnuc_err *err);
+/* ... on the HIP devices devices[0..n_gpus) instead of 0..n_gpus-1 (rank i on devices[i]; NULL = the identity). */
+int bitnuc_comm_init_all_devices(int n_gpus, const int *devices, bitnuc_ctx **ctxs, bitnuc_comm **comms, bitnuc_err *err);
 void bitnuc_comm_destroy(bitnuc_comm *comm);
 int bitnuc_comm_nranks(const bitnuc_comm *comm);
 int bitnuc_comm_rank(const bitnuc_comm *comm);
+/* 1: made by bitnuc_comm_init_all[_devices] (use the _all entry points), 0: by bitnuc_comm_init_rank, -1: NULL. */
+int bitnuc_comm_single_process(const bitnuc_comm *comm);
 /* All-gather `count` packed words per rank: d_all[r*count .. (r+1)*count) = rank r's d_local.
  * d_local may alias d_all + rank*count (in place).  Asynchronous on the context's stream. */
 int bitnuc_allgather_words_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, const uint64_t *d_local, size_t count, uint64_t *d_all, bitnuc_err *err);
@@ -283,9 +296,14 @@ int bitnuc_encode_sharded_allgather_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, cons
  * BITNUC_GATHER_MODE=bcast uses grouped in-place ncclBroadcast instead).  The context's stream waits for
  * the exchange, so bitnuc_ctx_sync() covers the whole call; an InvalidBase index is relative to the shard. */
 int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, const uint8_t *d_seq_shard, size_t shard_len, int n_chunks, uint64_t *d_all, bitnuc_err *err);
-/* Single-process form over bitnuc_comm_init_all's contexts: one call drives all n GPUs
- * (encode on every device, then one grouped all-gather), then synchronises all streams. */
+/* Single-process forms over bitnuc_comm_init_all's contexts and communicators (all n of them, in rank order):
+ * one call drives all n GPUs and synchronises every stream before it returns.  _all: encode on every device,
+ * then one grouped ncclAllGather.  _overlapped_all: the chunked in-place exchange above -- per piece, the encode
+ * on every device's stream, then ONE group holding every rank's sends and receives on that rank's transfer stream.
+ * An InvalidBase is reported for the lowest rank that has one: err.index relative to that rank's shard,
+ * err.value = the rank; the other ranks' slots are still exchanged. */
 int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err);
+int bitnuc_encode_sharded_allgather_overlapped_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, int n_chunks, uint64_t *const *d_alls, bitnuc_err *err);
 
 /* xGMI link probe (no reference counterpart; SURVEY section 5 asks for the measured per-link rate before any
  * fabric fraction is quoted): hipMemcpyPeerAsync of `bytes` from src_device to each of dst_devices[0..n), one

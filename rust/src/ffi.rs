@@ -85,15 +85,18 @@ extern "C" {
     pub fn bitnuc_comm_get_unique_id(id: *mut u8, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_comm_init_rank(ctx: *mut bitnuc_ctx, nranks: c_int, rank: c_int, id: *const u8, out: *mut *mut bitnuc_comm, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_comm_init_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_comm_init_all_devices(n_gpus: c_int, devices: *const c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_comm_destroy(comm: *mut bitnuc_comm);
     pub fn bitnuc_comm_nranks(comm: *const bitnuc_comm) -> c_int;
     pub fn bitnuc_comm_rank(comm: *const bitnuc_comm) -> c_int;
+    pub fn bitnuc_comm_single_process(comm: *const bitnuc_comm) -> c_int;
     pub fn bitnuc_allgather_words_dev(ctx: *mut bitnuc_ctx, comm: *mut bitnuc_comm, d_local: *const u64, count: usize, d_all: *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_encode_sharded_allgather_dev(ctx: *mut bitnuc_ctx, comm: *mut bitnuc_comm, d_seq_shard: *const u8, shard_len: usize, d_all: *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_encode_sharded_allgather_overlapped_dev(ctx: *mut bitnuc_ctx, comm: *mut bitnuc_comm, d_seq_shard: *const u8, shard_len: usize, n_chunks: c_int, d_all: *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_peer_link_probe(src_device: c_int, dst_devices: *const c_int, n: c_int, bytes: usize, reps: c_int, gb_s_each: *mut f64, gb_s_all: *mut f64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_host_pipe_info(ctx: *mut bitnuc_ctx, out: *mut f64, n: c_int, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_encode_sharded_allgather_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, d_seq_shards: *const *const u8, shard_len: usize, d_alls: *const *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_encode_sharded_allgather_overlapped_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, d_seq_shards: *const *const u8, shard_len: usize, n_chunks: c_int, d_alls: *const *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_nucgen_dev(ctx: *mut bitnuc_ctx, d_out: *mut u8, len: usize, seed: u64, first: u64, flags: c_int, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_stream_probe_dev(ctx: *mut bitnuc_ctx, mode: c_int, d_src: *const c_void, d_dst: *mut c_void, bytes: usize, err: *mut bitnuc_err) -> c_int;
     // layout plan of a ragged batch (include/bitnuc_hip.h): built once per offsets table, used by every encode / decode of it

@@ -14,7 +14,7 @@
 //   * a send buffer may be reused in stream order after the call: the sender's stream waits until the receiver has copied;
 //   * operations inside ncclGroupStart / ncclGroupEnd are issued together (sends never block the receives of the same group);
 //   * ncclCommInitRank returns when every rank of the id has joined.
-// A receive whose send does not show up within 60 s returns ncclInternalError instead of hanging the box.
+// A receive whose send does not show up within 60 s (MOCK_RCCL_PATIENCE_MS) returns ncclInternalError instead of hanging the box.
 // MOCK_RCCL_DELAY_US=n makes the "fabric" slow: every receive's copy is preceded, in the receiver's stream order, by a host
 // function that sleeps n microseconds.  Transfers then finish long after the encode that feeds them (as on xGMI, where the
 // gather costs about 8x the encode), so a missing wait between the two streams shows up as stale words instead of passing by luck.
@@ -39,7 +39,8 @@
 namespace {
 
 constexpr int kOk = 0, kUnhandledHip = 1, kInternal = 3, kInvalidArgument = 4, kInvalidUsage = 5;
-constexpr auto kPatience = std::chrono::seconds(60);
+// how long a receive waits for its send (and a send for its receive): MOCK_RCCL_PATIENCE_MS, default 60 s
+const auto kPatience = std::chrono::milliseconds([] { const char *e = getenv("MOCK_RCCL_PATIENCE_MS"); return e && atoi(e) > 0 ? atoi(e) : 60000; }());
 
 struct Msg {
     const void *src = nullptr;

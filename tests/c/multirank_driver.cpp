@@ -6,6 +6,9 @@
 //
 //   multirank_driver P shard_len n_chunks mode rounds [bad_rank bad_offset]
 //     mode: oneshot | overlap           (overlap + BITNUC_GATHER_MODE=bcast in the environment = the broadcast exchange)
+//           oneshot_all | overlap_all   ONE thread holds all P ranks (bitnuc_comm_init_all_devices on device 0 P times -- the mock
+//                                       accepts the duplicate device, RCCL would not) and drives them with the _all entry points;
+//                                       also checks that the per-rank entry points REFUSE such a communicator (they would block)
 //     rounds: calls back to back on the SAME buffers with new data each round (in-place reuse: the transfer stream of round r+1
 //             must not run ahead of round r's readers)
 //     bad_rank / bad_offset: plant an invalid byte in that rank's shard in the last round: that rank's sync must report
@@ -56,14 +59,85 @@ void complain(int rank, const std::string &what) {
 
 constexpr uint64_t kSeed = 0xB17C0DE;
 
+// One thread, all ranks: the _all forms over a bitnuc_comm_init_all_devices communicator.
+void run_single_process(int P, size_t shard_len, int n_chunks, bool overlap, int rounds, int bad_rank, size_t bad_offset, const std::vector<std::vector<uint64_t>> &expect) {
+    const int rank = -1; // for the macros' messages
+    const size_t count = shard_len / 32, total_words = count * (size_t)P;
+    bitnuc_err err;
+    memset(&err, 0, sizeof err);
+    std::vector<int> devs((size_t)P, 0);
+    std::vector<bitnuc_ctx *> ctxs((size_t)P, nullptr);
+    std::vector<bitnuc_comm *> comms((size_t)P, nullptr);
+    BNOK(bitnuc_comm_init_all_devices(P, devs.data(), ctxs.data(), comms.data(), &err));
+    std::vector<uint8_t *> d_seq((size_t)P, nullptr);
+    std::vector<uint64_t *> d_all((size_t)P, nullptr);
+    for (int i = 0; i < P; ++i) {
+        if (bitnuc_comm_nranks(comms[(size_t)i]) != P || bitnuc_comm_rank(comms[(size_t)i]) != i || bitnuc_comm_single_process(comms[(size_t)i]) != 1) complain(i, "communicator reports the wrong rank / size / kind");
+        HIPOK(hipMalloc(&d_seq[(size_t)i], shard_len));
+        HIPOK(hipMalloc(&d_all[(size_t)i], total_words * 8 + 64));
+        HIPOK(hipMemset(d_all[(size_t)i], 0xEE, total_words * 8 + 64));
+    }
+    HIPOK(hipDeviceSynchronize());
+    if (P > 1) { // a per-rank call from the thread that holds all ranks would wait for peers it cannot reach: refused, nothing enqueued
+        uint64_t sends0 = 0, recvs0 = 0, sends1 = 0, recvs1 = 0;
+        auto totals = reinterpret_cast<void (*)(uint64_t *, uint64_t *)>(dlsym(RTLD_DEFAULT, "mock_rccl_totals"));
+        totals(&sends0, &recvs0);
+        const int a = bitnuc_encode_sharded_allgather_overlapped_dev(ctxs[0], comms[0], d_seq[0], shard_len, n_chunks, d_all[0], &err);
+        const int b = bitnuc_encode_sharded_allgather_dev(ctxs[0], comms[0], d_seq[0], shard_len, d_all[0], &err);
+        const int c = bitnuc_allgather_words_dev(ctxs[0], comms[0], d_all[0], count, d_all[0], &err);
+        totals(&sends1, &recvs1);
+        if (a != BITNUC_UNSUPPORTED || b != BITNUC_UNSUPPORTED || c != BITNUC_UNSUPPORTED || sends0 != sends1 || recvs0 != recvs1)
+            complain(0, "per-rank entry points on a single-process communicator: statuses " + std::to_string(a) + " " + std::to_string(b) + " " + std::to_string(c) + " (expected 6 6 6, nothing sent)");
+        // and the _all forms refuse communicators that are not the whole single-process set in rank order
+        std::vector<bitnuc_comm *> swapped(comms);
+        std::swap(swapped[0], swapped[1]);
+        if (bitnuc_encode_sharded_allgather_overlapped_all(P, ctxs.data(), swapped.data(), d_seq.data(), shard_len, n_chunks, d_all.data(), &err) != BITNUC_UNSUPPORTED) complain(0, "_overlapped_all accepted communicators out of rank order");
+        if (bitnuc_encode_sharded_allgather_all(P - 1, ctxs.data(), comms.data(), d_seq.data(), shard_len, d_all.data(), &err) != BITNUC_UNSUPPORTED) complain(0, "_all accepted a subset of the ranks");
+    }
+    std::vector<uint64_t> got(total_words + 8);
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = 0; i < P; ++i) BNOK(bitnuc_nucgen_dev(ctxs[(size_t)i], d_seq[(size_t)i], shard_len, kSeed + (uint64_t)r, (uint64_t)i * shard_len, 0, &err));
+        const bool plant = r == rounds - 1 && bad_rank >= 0;
+        if (plant) { BNOK(bitnuc_ctx_sync(ctxs[(size_t)bad_rank], &err)); HIPOK(hipMemset(d_seq[(size_t)bad_rank] + bad_offset, 'N', 1)); HIPOK(hipDeviceSynchronize()); }
+        const int st = overlap ? bitnuc_encode_sharded_allgather_overlapped_all(P, ctxs.data(), comms.data(), d_seq.data(), shard_len, n_chunks, d_all.data(), &err)
+                               : bitnuc_encode_sharded_allgather_all(P, ctxs.data(), comms.data(), d_seq.data(), shard_len, d_all.data(), &err);
+        if (plant) {
+            if (st != BITNUC_INVALID_BASE || err.byte != 'N' || err.index != bad_offset || err.value != (uint64_t)bad_rank)
+                complain(bad_rank, "planted byte: status " + std::to_string(st) + " byte " + std::to_string(err.byte) + " index " + std::to_string(err.index) + " rank " + std::to_string(err.value));
+        } else if (st != BITNUC_OK) complain(-1, "_all call: status " + std::to_string(st) + " backend " + std::to_string(err.backend_code));
+        // the _all forms synchronise every stream themselves: the buffers are the caller's now (plain blocking copies below)
+        for (int i = 0; i < P; ++i) {
+            HIPOK(hipMemcpy(got.data(), d_all[(size_t)i], total_words * 8 + 64, hipMemcpyDeviceToHost));
+            for (size_t s = 0; s < (size_t)P; ++s) {
+                if ((int)s == bad_rank && r == rounds - 1) continue;
+                if (memcmp(got.data() + s * count, expect[(size_t)r].data() + s * count, count * 8) != 0) {
+                    size_t w = 0;
+                    while (got[s * count + w] == expect[(size_t)r][s * count + w]) ++w;
+                    complain(i, "round " + std::to_string(r) + ": slot of rank " + std::to_string(s) + " differs from the single-GPU encode at word " + std::to_string(w) + " of " + std::to_string(count));
+                    break;
+                }
+            }
+            for (size_t k = 0; k < 8; ++k)
+                if (got[total_words + k] != 0xEEEEEEEEEEEEEEEEull) { complain(i, "wrote past the gathered buffer"); break; }
+        }
+    }
+    for (int i = 0; i < P; ++i) {
+        bitnuc_comm_destroy(comms[(size_t)i]);
+        (void)hipFree(d_seq[(size_t)i]);
+        (void)hipFree(d_all[(size_t)i]);
+        bitnuc_ctx_destroy(ctxs[(size_t)i]);
+    }
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
-    if (argc < 6) { fprintf(stderr, "usage: %s P shard_len n_chunks oneshot|overlap rounds [bad_rank bad_offset]\n", argv[0]); return 2; }
+    if (argc < 6) { fprintf(stderr, "usage: %s P shard_len n_chunks oneshot|overlap|oneshot_all|overlap_all rounds [bad_rank bad_offset]\n", argv[0]); return 2; }
     const int P = atoi(argv[1]);
     const size_t shard_len = strtoull(argv[2], nullptr, 10);
     const int n_chunks = atoi(argv[3]);
-    const bool overlap = !strcmp(argv[4], "overlap");
+    const bool overlap = !strncmp(argv[4], "overlap", 7);
+    const bool single_process = strstr(argv[4], "_all") != nullptr;
     const int rounds = atoi(argv[5]);
     const int bad_rank = argc > 7 ? atoi(argv[6]) : -1;
     const size_t bad_offset = argc > 7 ? strtoull(argv[7], nullptr, 10) : 0;
@@ -96,7 +170,8 @@ int main(int argc, char **argv) {
 
     Barrier bar(P);
     std::vector<std::thread> threads;
-    for (int rank = 0; rank < P; ++rank)
+    if (single_process) run_single_process(P, shard_len, n_chunks, overlap, rounds, bad_rank, bad_offset, expect);
+    for (int rank = 0; rank < P && !single_process; ++rank)
         threads.emplace_back([&, rank] {
             bitnuc_err err;
             memset(&err, 0, sizeof err);

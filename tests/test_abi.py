@@ -39,6 +39,52 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.bitnuc_version()
 
 
+def test_library_carries_the_hash_of_its_sources():
+    """bitnuc_version() ends in the csrc_sha16 the library was compiled from; the loader holds it against the sources on disk."""
+    from bitnuc_amd import _lib, build
+    ver = _lib.load().bitnuc_version().decode()
+    assert ver.split("csrc:")[1].split()[0] == build.csrc_sha16() == build.library_sha16(build.LIB), ver
+    assert not build.is_stale(build.LIB)
+
+
+def test_a_stale_library_is_refused_and_rebuilt(tmp_path, monkeypatch):
+    """Plant a library that was built from OTHER sources where the product library is expected (a copy whose embedded hash differs, as
+    if csrc/ had been edited after the build and the .so had travelled with the tree): the loader refuses it, ensure_built(build=False)
+    and a process under a profiler say "build first" instead of compiling, ensure_built() rebuilds it in place and reports that."""
+    import shutil
+    import subprocess
+    import sys
+    from bitnuc_amd import _lib, build
+    stale = str(tmp_path / "libbitnuc_hip.so")
+    shutil.copy(build.LIB, stale)
+    data = bytearray(open(stale, "rb").read())
+    i = data.find(b" gfx950 csrc:") + len(b" gfx950 csrc:")
+    data[i:i + 16] = b"0123456789abcdef"
+    open(stale, "wb").write(bytes(data))
+    assert build.library_sha16(stale) == "0123456789abcdef" and build.is_stale(stale)
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib.load(stale)
+    with pytest.raises(RuntimeError, match="bitnuc_amd.build"):
+        build.ensure_built(build=False, lib=stale)
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert build.under_profiler()
+    with pytest.raises(RuntimeError, match="under a profiler"):
+        build.ensure_built(lib=stale)
+    monkeypatch.delenv("LD_PRELOAD")
+    assert not build.under_profiler()
+    assert build.ensure_built(lib=stale) == stale
+    assert build.LAST_ACTION[stale] == "rebuilt on this box" and build.library_sha16(stale) == build.csrc_sha16()
+    # a fresh process loads the rebuilt file and reports the sources' hash
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); from bitnuc_amd import _lib; print(_lib.load({stale!r}).bitnuc_version().decode())"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and build.csrc_sha16() in r.stdout, (r.stdout, r.stderr[-2000:])
+    # a missing library is built as well
+    missing = str(tmp_path / "sub" / "libbitnuc_hip.so")
+    os.makedirs(os.path.dirname(missing))
+    with pytest.raises(RuntimeError, match="is missing"):
+        build.ensure_built(build=False, lib=missing)
+
+
 def test_no_oracle_in_product():
     # the product must not route through the oracle or any CPU fallback
     for dirpath, _, files in os.walk(os.path.join(ROOT, "bitnuc_amd")):

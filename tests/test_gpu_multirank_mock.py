@@ -90,3 +90,38 @@ def test_invalid_byte_is_reported_by_its_rank_only(driver, mode):
     holds the other shards' words."""
     driver(4, ODD, 8, mode, 2, 2, 5 * (ODD // 8) + 12345)
     driver(8, ODD, 8, mode, 1, 7, ODD - 1)
+
+
+# ---- one thread holds all ranks: bitnuc_comm_init_all[_devices] + the _all entry points -----------------------------------------
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_single_process_one_shot_all(driver, P):
+    driver(P, ODD, 1, "oneshot_all", 2)
+
+
+@pytest.mark.parametrize("P,chunks", [(2, 1), (2, 3), (3, 5), (4, 8), (8, 8), (8, 13)])
+def test_single_process_chunked_in_place_gather_all(driver, P, chunks):
+    """bitnuc_encode_sharded_allgather_overlapped_all: per piece ONE group holds every rank's sends and receives, issued by the one
+    thread that owns all ranks.  The same driver run checks that the per-rank entry points refuse the communicator (status 6, nothing
+    sent) -- against this mock, as against RCCL, a per-rank group issued rank after rank from one thread waits for peers for ever
+    (here: the mock's 60 s patience, then ncclInternalError)."""
+    out = driver(P, ODD, chunks, "overlap_all", 2)
+    assert f"messages={2 * chunks * P * (P - 1)}" in out
+
+
+@pytest.mark.parametrize("P,chunks,mode", [(8, 8, "sendrecv"), (4, 6, "sendrecv"), (2, 4, "sendrecv"), (4, 4, "bcast")])
+def test_single_process_all_slow_fabric(driver, P, chunks, mode):
+    extra = {"BITNUC_GATHER_MODE": "bcast"} if mode == "bcast" else {}
+    driver(P, ODD if P > 2 else 32 * 4_000_003, chunks, "overlap_all", 3, MOCK_RCCL_DELAY_US="2000", **extra)
+    driver(P, ODD, 1, "oneshot_all", 2, MOCK_RCCL_DELAY_US="2000")
+
+
+@pytest.mark.parametrize("mode", ["oneshot_all", "overlap_all"])
+def test_single_process_all_reports_the_rank_of_an_invalid_byte(driver, mode):
+    """err.value = the rank whose shard holds the byte, err.index relative to that shard; every other rank's slot is still exchanged."""
+    driver(4, ODD, 8, mode, 2, 2, 5 * (ODD // 8) + 12345)
+    driver(8, ODD, 8, mode, 1, 7, ODD - 1)
+
+
+def test_single_process_all_fewer_words_than_pieces(driver):
+    out = driver(4, 96, 8, "overlap_all", 2)
+    assert "messages=%d" % (2 * 3 * 4 * 3) in out

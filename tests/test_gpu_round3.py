@@ -170,7 +170,7 @@ def test_overlapped_allgather_single_rank_equals_one_shot(oracle, chunks):
 
 @pytest.mark.parametrize("world", WORLDS)
 def test_multi_gpu_sharded_allgather_single_process(oracle, world):
-    """bitnuc_comm_init_all + bitnuc_encode_sharded_allgather_all on `world` GPUs == single-GPU encode of the concatenation."""
+    """bitnuc_comm_init_all + bitnuc_encode_sharded_allgather_all / _overlapped_all on `world` GPUs == single-GPU encode of the concatenation."""
     if _gpus() < world:
         pytest.skip(f"needs >= {world} GPUs")
     import torch
@@ -199,6 +199,18 @@ def test_multi_gpu_sharded_allgather_single_process(oracle, world):
     for r in range(world):
         assert torch.equal(alls[r].to("cuda:0"), ref), r
     assert np.array_equal(ref[:4096].cpu().numpy().view(np.uint64), oracle.encode(oracle.nucgen(32 * 4096, SEED)))
+    # the chunked in-place exchange driven by this one thread: per piece one RCCL group holds every rank's sends and receives
+    for chunks in (1, 4, 7):
+        for r in range(world):
+            alls[r].zero_()
+            torch.cuda.synchronize(r)
+        assert lib.bitnuc_encode_sharded_allgather_overlapped_all(world, ctxs, comms, sp, n, chunks, ap, C.byref(err)) == 0, (chunks, err.backend_code)
+        for r in range(world):
+            assert torch.equal(alls[r].to("cuda:0"), ref), (chunks, r)
+    # the per-rank entry points refuse a communicator whose ranks all live in this thread (they would wait for each other)
+    assert lib.bitnuc_comm_single_process(comms[0]) == 1
+    assert lib.bitnuc_encode_sharded_allgather_overlapped_dev(ctxs[0], comms[0], shards[0].data_ptr(), n, 4, alls[0].data_ptr(), C.byref(err)) == L.UNSUPPORTED
+    assert lib.bitnuc_encode_sharded_allgather_dev(ctxs[0], comms[0], shards[0].data_ptr(), n, alls[0].data_ptr(), C.byref(err)) == L.UNSUPPORTED
     c0.close()
     for r in range(world):
         lib.bitnuc_comm_destroy(comms[r])

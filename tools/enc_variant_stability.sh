@@ -1,6 +1,9 @@
 #!/bin/bash
 # Process-to-process stability of the timed step for a few encode variants: N separate bench.py processes each (fresh allocations, so a
 # different physical placement every time), same box.  usage on the GPU box: bash tools/enc_variant_stability.sh "39 2 14 41" 5
+# both libraries are built BEFORE the first rocprofv3 line: a profiled process has the GPU initialised by the profiler's preload
+# and must not start a compiler chain (bitnuc_amd.build.ensure_built refuses to build there and says so)
+python3 -m bitnuc_amd.build > /dev/null && python3 -m bitnuc_amd.build --sweep > /dev/null || { echo "build failed"; exit 1; }
 VARS=${1:-"39 2 14"}
 N=${2:-5}
 for i in $(seq 1 $N); do

@@ -10,6 +10,10 @@ fabric fast (MOCK_RCCL_DELAY_US=0) and slow (2000).  A defect counts as noticed 
      recorded later on the same stream, so this one is expected to go unnoticed -- it is listed to show the check is not
      simply failing everything)
   D  one receive lands one word too far                               (addressing)
+and the same four in the single-process form (bitnuc_encode_sharded_allgather_overlapped_all, driver mode overlap_all):
+  E  = A there, F = B there, G = D there
+  H  the per-rank entry points do not refuse a single-process communicator: the driver's refusal check fails (and the call would
+     block for the mock's patience, 60 s, before RCCL-like ncclInternalError)
 """
 import os
 import shutil
@@ -27,9 +31,15 @@ MUT = {
     "B": ("            if (hipEventRecord(comm->all_moved, comm->xfer) == hipSuccess) (void)hipStreamWaitEvent(c->stream, comm->all_moved, 0);", "            if (false) {}"),
     "C": ("    HIPCHK(hipStreamWaitEvent(comm->xfer, comm->all_moved, 0));\n", ""),
     "D": ("uint64_t *theirs = d_all + (size_t)s * count + w0;", "uint64_t *theirs = d_all + (size_t)s * count + w0 + (s == 1 && p == 2 ? 1 : 0);"),
+    "E": ("            if (h == hipSuccess) h = hipStreamWaitEvent(comms[i]->xfer, comms[i]->piece_done[(size_t)p], 0);\n", ""),
+    "F": ("            if (hipEventRecord(comms[i]->all_moved, comms[i]->xfer) == hipSuccess) (void)hipStreamWaitEvent(ctxs[i]->stream, comms[i]->all_moved, 0);", "            if (false) {}"),
+    "G": ("uint64_t *theirs = d_alls[i] + (size_t)s * count + w0;", "uint64_t *theirs = d_alls[i] + (size_t)s * count + w0 + (s == 1 && p == 2 ? 1 : 0);"),
+    "H": ("bool per_rank_call_would_block(const bitnuc_comm *comm) { return comm->single_process && comm->nranks > 1; }", "bool per_rank_call_would_block(const bitnuc_comm *) { return false; }"),
 }
+PER_RANK, ALL_RANKS = "ABCD", "EFGH"
 ODD, BIG = 32 * 100_003, 32 * 4_000_003
 SCENARIOS = [(4, ODD, 6, "overlap", 5), (8, ODD, 8, "overlap", 2), (4, BIG, 8, "overlap", 3), (2, BIG, 4, "overlap", 2)]
+SCENARIOS_ALL = [(4, ODD, 6, "overlap_all", 3), (8, ODD, 8, "overlap_all", 2), (4, BIG, 8, "overlap_all", 2), (2, BIG, 4, "overlap_all", 2)]
 
 
 def main():
@@ -63,21 +73,24 @@ def main():
     exe = os.path.join(work, "multirank_driver")
     subprocess.run([hipcc, "-O1", "-g", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "c", "multirank_driver.cpp"),
                     "-L" + libs["product"], "-lbitnuc_hip", "-ldl", "-lpthread"], check=True, capture_output=True)
-    noticed = {}
+    noticed, runs = {}, {}
     for name, d in libs.items():
         for delay in (0, 2000):
-            for sc in SCENARIOS:
-                env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([d, mock, os.environ.get("LD_LIBRARY_PATH", "")]), MOCK_RCCL_DELAY_US=str(delay))
+            for sc in (SCENARIOS_ALL if name in ALL_RANKS else SCENARIOS + SCENARIOS_ALL if name == "product" else SCENARIOS):
+                if name == "H" and (delay or sc[0] != 4 or sc[1] != ODD):
+                    continue  # one run shows it (every blocked operation costs the mock's patience, shortened to 0.3 s here)
+                env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([d, mock, os.environ.get("LD_LIBRARY_PATH", "")]), MOCK_RCCL_DELAY_US=str(delay), **({"MOCK_RCCL_PATIENCE_MS": "300"} if name == "H" else {}))
                 r = subprocess.run([exe, *map(str, sc)], capture_output=True, text=True, timeout=300, env=env)
                 first = (r.stderr.strip().splitlines() or [""])[0][:110]
                 print(f"{name:8s} fabric delay {delay:4d} us  P={sc[0]} shard={sc[1]:>9d} pieces={sc[2]} rounds={sc[4]}: {'ok' if r.returncode == 0 else 'FAILS  ' + first}", flush=True)
                 noticed[name] = noticed.get(name, 0) + (r.returncode != 0)
+                runs[name] = runs.get(name, 0) + 1
     print()
     for name, k in noticed.items():
-        print(f"{name:8s}: {k} of {2 * len(SCENARIOS)} runs fail")
+        print(f"{name:8s}: {k} of {runs[name]} runs fail")
     shutil.rmtree(work, ignore_errors=True)
-    ok = noticed["product"] == 0 and all(noticed[m] > 0 for m in "ABD")
-    print("verdict:", "the product passes every run; defects A, B and D are noticed" if ok else "UNEXPECTED")
+    ok = noticed["product"] == 0 and all(noticed[m] > 0 for m in "ABDEFGH")
+    print("verdict:", "the product passes every run; defects A, B, D (per-rank form) and E, F, G, H (single-process form) are noticed" if ok else "UNEXPECTED")
     return 0 if ok else 1
 
 

@@ -1,6 +1,9 @@
 #!/bin/bash
 # LDS counters of the ragged-batch kernels (one --pmc pass, no trace domain): usage on the GPU box: bash tools/pmc_batch_lds.sh OUTDIR
 set -u
+# both libraries are built BEFORE the first rocprofv3 line: a profiled process has the GPU initialised by the profiler's preload
+# and must not start a compiler chain (bitnuc_amd.build.ensure_built refuses to build there and says so)
+python3 -m bitnuc_amd.build > /dev/null && python3 -m bitnuc_amd.build --sweep > /dev/null || { echo "build failed"; exit 1; }
 OUT=$PWD/${1:-gpurun_out/pmc_lds}
 mkdir -p "$OUT"
 export TMPDIR=/tmp

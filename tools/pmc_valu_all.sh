@@ -2,6 +2,9 @@
 # Vector-ALU utilisation of every kernel of the default bench run (one --pmc pass, counters only).
 # usage on the GPU box: bash tools/pmc_valu_all.sh OUTDIR
 set -u
+# both libraries are built BEFORE the first rocprofv3 line: a profiled process has the GPU initialised by the profiler's preload
+# and must not start a compiler chain (bitnuc_amd.build.ensure_built refuses to build there and says so)
+python3 -m bitnuc_amd.build > /dev/null && python3 -m bitnuc_amd.build --sweep > /dev/null || { echo "build failed"; exit 1; }
 OUT=$PWD/${1:-gpurun_out/pmc_valu}
 mkdir -p "$OUT"
 export TMPDIR=/tmp

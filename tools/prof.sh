@@ -3,6 +3,9 @@
 # never combined with a trace domain), then kernel-trace stats of the full default run (side measurements included).
 # usage (on the GPU box, from the repo root): bash tools/prof.sh r02
 set -u
+# both libraries are built BEFORE the first rocprofv3 line: a profiled process has the GPU initialised by the profiler's preload
+# and must not start a compiler chain (bitnuc_amd.build.ensure_built refuses to build there and says so)
+python3 -m bitnuc_amd.build > /dev/null && python3 -m bitnuc_amd.build --sweep > /dev/null || { echo "build failed"; exit 1; }
 TAG=${1:-r00}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -2,6 +2,9 @@
 # usage: bash tools/prof_pmc.sh <tag> "<counters>" -- <python script args...>
 # runs `python3 <args>` under rocprofv3 --pmc (counters only, no tracing domains) and prints per-kernel averages
 set -u
+# both libraries are built BEFORE the first rocprofv3 line: a profiled process has the GPU initialised by the profiler's preload
+# and must not start a compiler chain (bitnuc_amd.build.ensure_built refuses to build there and says so)
+python3 -m bitnuc_amd.build > /dev/null && python3 -m bitnuc_amd.build --sweep > /dev/null || { echo "build failed"; exit 1; }
 TAG=$1; CTRS=$2; shift 3
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"

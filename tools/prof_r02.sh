@@ -2,6 +2,9 @@
 # Round-2 profile set, one gpurun call: rocprofv3 kernel stats + HBM PMC passes of bench.py, SQ/LDS counters of the batch kernels.
 # usage (on the GPU box, from the repo root): bash tools/prof_r02.sh
 set -u
+# both libraries are built BEFORE the first rocprofv3 line: a profiled process has the GPU initialised by the profiler's preload
+# and must not start a compiler chain (bitnuc_amd.build.ensure_built refuses to build there and says so)
+python3 -m bitnuc_amd.build > /dev/null && python3 -m bitnuc_amd.build --sweep > /dev/null || { echo "build failed"; exit 1; }
 bash tools/prof.sh r02
 OUT=$PWD/gpurun_out/prof_r02
 export TMPDIR=/tmp

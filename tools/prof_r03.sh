@@ -4,6 +4,9 @@
 # SQ / LDS counters of the two every-window kernels.  Counters only in --pmc passes (never combined with a trace domain).
 # usage (on the GPU box, from the repo root): bash tools/prof_r03.sh
 set -u
+# both libraries are built BEFORE the first rocprofv3 line: a profiled process has the GPU initialised by the profiler's preload
+# and must not start a compiler chain (bitnuc_amd.build.ensure_built refuses to build there and says so)
+python3 -m bitnuc_amd.build > /dev/null && python3 -m bitnuc_amd.build --sweep > /dev/null || { echo "build failed"; exit 1; }
 bash tools/prof.sh r03
 OUT=$PWD/gpurun_out/prof_r03
 export TMPDIR=/tmp

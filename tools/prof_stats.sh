@@ -1,6 +1,9 @@
 #!/bin/bash
 # usage: bash tools/prof_stats.sh <tag> -- <python script args...> : rocprofv3 --kernel-trace --stats, prints our kernels' averages
 set -u
+# both libraries are built BEFORE the first rocprofv3 line: a profiled process has the GPU initialised by the profiler's preload
+# and must not start a compiler chain (bitnuc_amd.build.ensure_built refuses to build there and says so)
+python3 -m bitnuc_amd.build > /dev/null && python3 -m bitnuc_amd.build --sweep > /dev/null || { echo "build failed"; exit 1; }
 TAG=$1; shift 2
 OUT=$PWD/gpurun_out/stats_$TAG
 mkdir -p "$OUT"

@@ -16,14 +16,11 @@ import sys
 
 
 def csrc_sha16(root):
-    """Same identity bench.py computes: a stored traffic figure is only valid for these kernel sources."""
-    h = hashlib.sha256()
-    d = os.path.join(root, "bitnuc_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()[:16]
+    """Same identity bench.py reports and the library carries (bitnuc_amd.build.csrc_sha16): a stored traffic figure is only valid
+    for these kernel sources."""
+    sys.path.insert(0, root)
+    from bitnuc_amd import build
+    return build.csrc_sha16()
 
 
 def kernel_short(name):
