@@ -227,24 +227,60 @@ def traffic_child(args):
 # ---------------------------------------------------------------------------------------------
 # CPU baseline (oracle/bitnuc_avx2.c) -- the checker timed beside the product, never inside it
 # ---------------------------------------------------------------------------------------------
-def cpu_baseline(n_sample, reps, all_cores):
+def cpu_baseline(n_sample, reps, all_cores, seed=SEED, gpu=None):
     """Reference-algorithm restatement (oracle/bitnuc_avx2.c, the reference's AVX2 path as
-    written) timed on this host.  kind = "port": the Rust reference cannot be built here."""
+    written) timed on this host.  kind = "port": the Rust reference cannot be built here.
+    gpu = {"words": ndarray u64, "back": ndarray u8} -- what the timed GPU launches left for the SAME seeded stream -- makes the
+    line's parity claim literal: the oracle's words for the stream (it encodes them here anyway) are compared with the GPU's word
+    for word, and the GPU's decoded bases with the stream (the oracle's own decode is checked against the stream inside
+    orc_avx2_time_roundtrip).  The result is returned under "parity"; the oracle is the checker here, never the thing shipped."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import oracle_py
-    seq = oracle_py.nucgen(n_sample, SEED)
-    enc, dec = [], []
-    for _ in range(reps):
-        e, d = oracle_py.avx2_time_roundtrip(seq)
-        enc.append(e)
-        dec.append(d)
-    e1, d1 = statistics.median(enc), statistics.median(dec)
+    seq = oracle_py.nucgen(n_sample, seed)
+
+    def time_with(L):
+        enc, dec = [], []
+        for _ in range(reps):
+            e, d = oracle_py.avx2_time_roundtrip(seq, L)
+            enc.append(e)
+            dec.append(d)
+        return statistics.median(enc), statistics.median(dec)
+    e1, d1 = time_with(None)
     out = {"value": round(2 * n_sample / (e1 + d1) / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
            "sample": f"{n_sample:.3g} bases of the same seeded stream, encode+decode, median of {reps}",
            "encode_gbases_s": round(n_sample / e1 / 1e9, 4), "decode_gbases_s": round(n_sample / d1 / 1e9, 4),
            "what": "C restatement of the reference's AVX2 path as written (oracle/bitnuc_avx2.c); "
                    "the reference itself is single-threaded Rust and cannot be built in this image",
            "build_flags": oracle_py.build_flags() if hasattr(oracle_py, "build_flags") else None}
+    # BASELINE.md section 3 / the reference's .cargo/config.toml:1-2 time a target-cpu=native build: the same sources compiled
+    # -march=native on THIS host (into a temporary directory), timed the same way, reported beside the portable build's figure
+    L_nat, nat_flags = oracle_py.native_lib()
+    if L_nat is not None:
+        e2, d2 = time_with(L_nat)
+        out.update({"native_value": round(2 * n_sample / (e2 + d2) / 1e9, 4), "native_encode_gbases_s": round(n_sample / e2 / 1e9, 4),
+                    "native_decode_gbases_s": round(n_sample / d2 / 1e9, 4), "native_build_flags": nat_flags})
+    else:
+        out.update({"native_value": None, "native_build_flags": f"-march=native build failed on this host: {nat_flags}"})
+    if gpu is not None:
+        try:
+            o_words = oracle_py.encode(seq, avx2=True)
+            nws = o_words.size
+            g_words, g_back = gpu["words"][:nws], gpu["back"][:n_sample]
+            if g_words.size != nws or g_back.size != n_sample:
+                out["parity"] = {"ok": None, "note": f"the GPU step ran on fewer bases than the CPU sample ({g_back.size} < {n_sample}): not compared"}
+            else:
+                ok_w, ok_b = bool(np.array_equal(g_words, o_words)), bool(np.array_equal(g_back, seq))
+                # localise a failure: 64-bit sum per 1 MiB block of words
+                first_bad = None
+                if not ok_w:
+                    first_bad = int(np.nonzero(g_words != o_words)[0][0])
+                out["parity"] = {"ok": ok_w and ok_b, "encode_words_compared": int(nws), "encode_ok": ok_w, "decode_bases_compared": int(n_sample), "decode_ok": ok_b,
+                                 "first_differing_word": first_bad, "stream_seed": hex(seed),
+                                 "how": "the words / bases the timed launches left on the GPU (copied to the host after the timed region) against the words "
+                                        "oracle/bitnuc_avx2.c produces for the same seeded stream and against the stream itself, every element"}
+        except Exception as e:  # noqa: BLE001
+            out["parity"] = {"ok": None, "error": repr(e)[:300]}
     if all_cores:
         # a one-GPU box's CPU share is 16 cores (os.cpu_count() reports the whole host)
         cores = min(len(os.sched_getaffinity(0)), 16)
@@ -253,13 +289,13 @@ def cpu_baseline(n_sample, reps, all_cores):
             res = [None] * cores
 
             def work(i):
-                res[i] = oracle_py.avx2_time_roundtrip(seq[i * per:(i + 1) * per])
+                res[i] = oracle_py.avx2_time_roundtrip(seq[i * per:(i + 1) * per], L_nat)
             t0 = time.perf_counter()
             th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
             [t.start() for t in th]
             [t.join() for t in th]
             wall = time.perf_counter() - t0
-            out["all_cores"] = {"value": round(2 * per * cores / wall / 1e9, 4), "cores": cores,
+            out["all_cores"] = {"value": round(2 * per * cores / wall / 1e9, 4), "cores": cores, "build": "native" if L_nat is not None else "portable",
                                 "note": "courtesy split at 32-base boundaries over threads; the reference has no threading"}
     try:
         with open("/proc/cpuinfo") as f:
@@ -505,6 +541,10 @@ def run_rank(args, real_stdout, traffic):
         # parity guard inside the bench: the last step's round trip must be the identity
         r_last = (args.steps - 1) % R if args.warm_decode else ((args.steps - 1) % R + 1) % R
         assert torch.equal(seqs[r_last], backs[r_last]), "decode(encode(x)) != x"
+        # what the timed launches left for buffer set r_last (stream seed SEED + r_last), copied out now -- after the timed region,
+        # before the side measurements reuse the buffers -- for the word-for-word comparison with the CPU oracle (cpu_baseline)
+        if rank == 0 and not args.no_cpu_baseline and args.steps + args.warmup >= R:
+            state["gpu_result"] = {"words": words[r_last].cpu().numpy().view("uint64"), "back": backs[r_last].cpu().numpy(), "seed": SEED + r_last}
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if on_gpu_collectives else "cpu")
     if use_dist:
@@ -540,7 +580,7 @@ def run_rank(args, real_stdout, traffic):
             "ms_per_step": round(sec_per_step * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident, bit-exact vs CPU oracle",
+            "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident",
                        "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
                        "seed": hex(SEED), "rotating_buffer_sets": R,
                        "hip_events": (f"per-kernel HIP events recorded on every {ev_every}th timed step ({len([e for e in (events or []) if e])} of {args.steps} steps): recording them on every step "
@@ -579,9 +619,24 @@ def run_rank(args, real_stdout, traffic):
         line.update(extra)
         if with_cpu and rank == 0 and not args.no_cpu_baseline:
             try:  # north_star: the CPU SIMD path "in the same run" at every GPU count (N > 1: 3 repetitions on rank 0's host cores, the other ranks idle)
-                line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps if world == 1 else min(args.cpu_reps, 3), all_cores=True)
+                g = state.get("gpu_result")
+                cb = cpu_baseline(args.cpu_sample, args.cpu_reps if world == 1 else min(args.cpu_reps, 3), all_cores=True,
+                                  seed=g["seed"] if g else SEED, gpu=g)
+                par = cb.pop("parity", None)
+                line["cpu_baseline"] = cb
+                if par is not None:
+                    line["parity_vs_oracle"] = par
+                    if par.get("ok"):
+                        line["config"]["workload"] += ", bit-exact vs CPU oracle (parity_vs_oracle: every word and base of the timed step's last buffer set)"
+                    elif par.get("ok") is False:
+                        state["rc"] = 3  # a fast kernel whose results differ from the reference's is not done
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)[:300]}
+        # LAST key (the driver keeps the tail of the line): the roofline fraction of every BASELINE config measured in this run
+        def frac(block):
+            return (extra.get(block) or {}).get("roofline", {}).get("frac")
+        line["configs"] = {"cfg2_encode": r_enc["frac"], "cfg2_decode": r_dec["frac"], "cfg3_kmer_batch": frac("kmer_batch"), "cfg5_kmer_hdist_scan": frac("kmer_hdist_scan"),
+                           "unit": "fraction of 8 TB/s HBM3E on algorithmic bytes; null = block not run"}
         return line
 
     state["headline"] = make_line

@@ -56,7 +56,7 @@ static int hdist_words_launch(bitnuc_ctx *c, bool query_mode, const uint64_t *d_
     DeviceGuard g(c->device);
     const unsigned long long *a = reinterpret_cast<const unsigned long long *>(d_a), *b = reinterpret_cast<const unsigned long long *>(d_b);
     size_t done = 0;
-    if (c->hdist_words_impl == 1 && aligned16(d_a) && (query_mode || aligned16(d_b)) && (reinterpret_cast<uintptr_t>(d_dist) & 3) == 0 && count >= 256) {
+    if (knobs(c).hdist_words_impl == 1 && aligned16(d_a) && (query_mode || aligned16(d_b)) && (reinterpret_cast<uintptr_t>(d_dist) & 3) == 0 && count >= 256) {
         // whole 256-word wave tiles through the coalesced kernel (one tile per wave: the hardware dispatcher walks them)
         const unsigned long long tiles = count / 256;
         const unsigned grid = grid_for(c, (tiles + kBlock / 64 - 1) / (kBlock / 64));

@@ -24,7 +24,7 @@ static int batch_owners(bitnuc_ctx *c, const uint64_t *d_offsets, const uint64_t
     const unsigned long long ratio64 = count >= total_words ? ~0ull : (unsigned long long)((((unsigned __int128)count) << 64) / total_words);
     // measured (profiles/r01_ab_owner_estimate.txt): the multiply-high guess wins by 9 us of 17 for long sequences, the
     // 128-bit division by 6 of 28 for read-sized ones (same loads either way; the slower arithmetic spreads them out)
-    const int est_mode = c->owner_est < 3 ? c->owner_est : (total_words >= 16 * (unsigned long long)count ? 2 : 0);
+    const int est_mode = knobs(c).owner_est < 3 ? knobs(c).owner_est : (total_words >= 16 * (unsigned long long)count ? 2 : 0);
     if (est_mode == 0) block_owner_kernel<0><<<og, kBlock, 0, c->stream>>>(po, pw, count, total_words, ntiles, ratio64, o);
     else if (est_mode == 1) block_owner_kernel<1><<<og, kBlock, 0, c->stream>>>(po, pw, count, total_words, ntiles, ratio64, o);
     else block_owner_kernel<2><<<og, kBlock, 0, c->stream>>>(po, pw, count, total_words, ntiles, ratio64, o);
@@ -95,18 +95,18 @@ static int launch_plan_encode(bitnuc_ctx *c, const unsigned long long *d_base, c
                               const uint8_t *d_seq, uint64_t *d_out, bitnuc_err *err) {
     unsigned long long *slot;
     if (int st = take_slot(c, 0, &slot, err)) return st;
-    const int threads = c->plan_enc_block; // 64, 128 or 256 threads: a wave owns a tile, so any number of waves per workgroup works
+    const int threads = knobs(c).plan_enc_block; // 64, 128 or 256 threads: a wave owns a tile, so any number of waves per workgroup works
     const size_t per_block = (size_t)kBatchTile * (size_t)(threads / 64);
     const unsigned long long blocks = (total_words + per_block - 1) / per_block;
     unsigned long long *o = reinterpret_cast<unsigned long long *>(d_out);
-    const unsigned long long U = (unsigned long long)c->plan_enc_tiles;
+    const unsigned long long U = (unsigned long long)knobs(c).plan_enc_tiles;
     const unsigned grid = grid_for(c, (blocks + U - 1) / U, threads);
 #define PLAN_ENC(UU) encode_batch_plan_kernel<UU><<<grid, threads, 0, c->stream>>>(d_seq, d_base, d_P, total_words, d_bounds, o, slot)
     if constexpr (kEvidenceBuild) {
 #define PLAN_ENC_ABL(A) encode_batch_plan_kernel<1, A><<<grid, threads, 0, c->stream>>>(d_seq, d_base, d_P, total_words, d_bounds, o, slot)
         if (U == 2) PLAN_ENC(2);
         else if (U == 4) PLAN_ENC(4);
-        else switch (c->plan_enc_abl) { // timing-only ablations, right only for 32-base reads (tools/ab_plan_enc_ablate.py)
+        else switch (knobs(c).plan_enc_abl) { // timing-only ablations, right only for 32-base reads (tools/ab_plan_enc_ablate.py)
         case 1: PLAN_ENC_ABL(1); break;
         case 2: PLAN_ENC_ABL(2); break;
         case 4: PLAN_ENC_ABL(4); break;
@@ -126,14 +126,20 @@ static int launch_plan_encode(bitnuc_ctx *c, const unsigned long long *d_base, c
 static int launch_plan_decode(bitnuc_ctx *c, const unsigned long long *d_base, const uint8_t *d_P, size_t total_words, const uint64_t *d_words,
                               uint8_t *d_out, bitnuc_err *err) {
     const unsigned long long *w = reinterpret_cast<const unsigned long long *>(d_words);
-    const int tiles_per_wave = c->plan_tiles;
+    const int tiles_per_wave = knobs(c).plan_tiles;
     const size_t per_block2 = (size_t)kBatchTile * kBatchWaves * (size_t)tiles_per_wave;
     const unsigned grid2 = grid_for(c, (total_words + per_block2 - 1) / per_block2);
+    if (knobs(c).plan_dec_lines) { // line-owning tiles (batch_device.h): one tile per wave trip, the shipped store policy
+        const size_t per_block1 = (size_t)kBatchTile * kBatchWaves;
+        decode_batch_plan_lines_kernel<2><<<grid_for(c, (total_words + per_block1 - 1) / per_block1), kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out);
+        HIPCHK(hipGetLastError());
+        return BITNUC_OK;
+    }
 #define PLAN_DEC(POL, U) decode_batch_plan_kernel<POL, U><<<grid2, kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out)
 #define PLAN_DEC_U(POL) do { if (tiles_per_wave == 1) PLAN_DEC(POL, 1); else if (tiles_per_wave == 2) PLAN_DEC(POL, 2); else PLAN_DEC(POL, 4); } while (0)
     if constexpr (kEvidenceBuild) {
-        if (c->plan_store == 0) PLAN_DEC_U(0);
-        else if (c->plan_store == 1) PLAN_DEC_U(1);
+        if (knobs(c).plan_store == 0) PLAN_DEC_U(0);
+        else if (knobs(c).plan_store == 1) PLAN_DEC_U(1);
         else PLAN_DEC_U(2);
     } else {
         PLAN_DEC(2, 1);
@@ -150,7 +156,7 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t 
     if (count == 0 || total_words == 0) return BITNUC_OK;
     if (!d_seq || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    if (c->batch_tables_impl == 1 || !kEvidenceBuild) {
+    if (knobs(c).batch_tables_impl == 1 || !kEvidenceBuild) {
         uint8_t *P;
         unsigned long long *tile_base, *bounds;
         if (int st = emit_scratch_plan(c, d_offsets, d_word_offsets, count, total_words, &P, &tile_base, &bounds, err)) return st;
@@ -166,7 +172,7 @@ int bitnuc_encode_batch_dev(bitnuc_ctx *c, const uint8_t *d_seq, const uint64_t 
         if (int st = take_slot(c, 0, &slot, err)) return st;
         const size_t per_block = (size_t)kBatchTile * kBatchWaves;
         const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
-        switch (c->batch_abl) { // timing-only ablations (tools/ab_batch_ablate.py): anything but 0 produces wrong words
+        switch (knobs(c).batch_abl) { // timing-only ablations (tools/ab_batch_ablate.py): anything but 0 produces wrong words
 #define ABL_CASE(A) case A: encode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(d_seq, po, pw, count, total_words, recs, o, slot); break;
         ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11)
 #undef ABL_CASE
@@ -184,7 +190,7 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64
     if (count == 0 || total_words == 0) return BITNUC_OK;
     if (!d_words || !d_offsets || !d_word_offsets || !d_out || (reinterpret_cast<uintptr_t>(d_words) & 7)) return fail(err, BITNUC_UNSUPPORTED);
     DeviceGuard g(c->device);
-    if (c->batch_tables_impl == 1 || !kEvidenceBuild) {
+    if (knobs(c).batch_tables_impl == 1 || !kEvidenceBuild) {
         uint8_t *P;
         unsigned long long *tile_base, *bounds;
         if (int st = emit_scratch_plan(c, d_offsets, d_word_offsets, count, total_words, &P, &tile_base, &bounds, err)) return st;
@@ -198,7 +204,7 @@ int bitnuc_decode_batch_dev(bitnuc_ctx *c, const uint64_t *d_words, const uint64
         if (int st = batch_owners(c, d_offsets, d_word_offsets, count, total_words, &recs, err)) return st;
         const size_t per_block = (size_t)kBatchTile * kBatchWaves;
         const unsigned grid = grid_for(c, (total_words + per_block - 1) / per_block);
-        switch (c->batch_abl) {
+        switch (knobs(c).batch_abl) {
 #define ABL_CASE(A) case A: decode_batch2_kernel<A><<<grid, kBlock, 0, c->stream>>>(w, pw, po, count, total_words, recs, d_out); break;
         ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(9) ABL_CASE(11) ABL_CASE(15)
 #undef ABL_CASE
@@ -228,7 +234,7 @@ int bitnuc_encode_batch(bitnuc_ctx *c, const uint8_t *seq, const uint64_t *offse
     HIPCHK(hipMemcpyAsync(d_off, offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
     size_t total = 0;
     const uint64_t *d_wo;
-    if (c->batch_host_plan) { // the layout plan: word offsets + tile bases + pad bytes in one go (the context keeps one for its host calls)
+    if (knobs(c).batch_host_plan) { // the layout plan: word offsets + tile bases + pad bytes in one go (the context keeps one for its host calls)
         if (!c->host_plan) if (int st = bitnuc_batch_plan_create(c, &c->host_plan, err)) return st;
         if (int st = bitnuc_batch_plan_build_dev(c, c->host_plan, d_off, count, &total, err)) return st;
         d_wo = bitnuc_batch_plan_word_offsets_dev(c->host_plan);
@@ -243,7 +249,7 @@ int bitnuc_encode_batch(bitnuc_ctx *c, const uint8_t *seq, const uint64_t *offse
     // the kernels index the sequence buffer with the caller's offsets: rebase the device pointer
     const uint8_t *d_seq = c->scratch[0] - b0;
     if (total) {
-        if (c->batch_host_plan) { if (int st = bitnuc_encode_batch_plan_dev(c, c->host_plan, d_seq, reinterpret_cast<uint64_t *>(c->scratch[1]), err)) return st; }
+        if (knobs(c).batch_host_plan) { if (int st = bitnuc_encode_batch_plan_dev(c, c->host_plan, d_seq, reinterpret_cast<uint64_t *>(c->scratch[1]), err)) return st; }
         else if (int st = bitnuc_encode_batch_dev(c, d_seq, d_off, d_wo, count, total, reinterpret_cast<uint64_t *>(c->scratch[1]), err)) return st;
         HIPCHK(hipMemcpyAsync(out, c->scratch[1], total * 8, hipMemcpyDeviceToHost, c->stream));
     }
@@ -279,7 +285,7 @@ int bitnuc_decode_batch(bitnuc_ctx *c, const uint64_t *words, const uint64_t *wo
     HIPCHK(hipMemcpyAsync(c->scratch[1], words, total * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_off, offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_wo, word_offsets, (count + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    if (c->batch_host_plan) { // the caller's word_offsets were checked against the offsets above; the plan rebuilds them on the device
+    if (knobs(c).batch_host_plan) { // the caller's word_offsets were checked against the offsets above; the plan rebuilds them on the device
         size_t ptotal = 0;
         if (!c->host_plan) if (int st = bitnuc_batch_plan_create(c, &c->host_plan, err)) return st;
         if (int st = bitnuc_batch_plan_build_dev(c, c->host_plan, d_off, count, &ptotal, err)) return st;
@@ -431,7 +437,7 @@ int bitnuc_encode_fixed_dev(bitnuc_ctx *c, const uint8_t *d_seq, size_t read_len
     const unsigned long long seq_end = (unsigned long long)(count - 1) * stride + read_len;
     const unsigned magic = (unsigned)((0x100000000ull + wpr - 1) / wpr); // ceil(2^32 / wpr): exact floor(t / wpr) for t < 2^16
     const unsigned long long magic64 = wpr == 1 ? 0ull : ~0ull / wpr + 1;  // floor(2^64 / wpr) + 1: exact floor(w / wpr) by multiply-high while w * wpr < 2^64
-    if (stride == read_len) encode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, magic64, total, seq_end, c->fixed_stream, o, slot);
+    if (stride == read_len) encode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, magic64, total, seq_end, knobs(c).fixed_stream, o, slot);
     else encode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(d_seq, (unsigned)read_len, stride, wpr, magic, magic64, total, seq_end, 0, o, slot);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
@@ -452,9 +458,9 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
     const unsigned magic = (unsigned)((0x100000000ull + wpr - 1) / wpr);
     const unsigned long long magic64 = wpr == 1 ? 0ull : ~0ull / wpr + 1;
     if (stride != read_len) decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
-    else if (c->fixed_dec_strip == 2 || !kEvidenceBuild) decode_fixed_tile_kernel<2><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
+    else if (knobs(c).fixed_dec_strip == 2 || !kEvidenceBuild) decode_fixed_tile_kernel<2><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
     else if constexpr (kEvidenceBuild) {
-        if (c->fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
+        if (knobs(c).fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
         else decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
     }
     HIPCHK(hipGetLastError());

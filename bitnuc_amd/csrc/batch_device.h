@@ -1215,6 +1215,138 @@ decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const uns
     }
 }
 
+// ---- line-owning plan decode ------------------------------------------------------------------------------------------------
+// decode_batch_plan_kernel's tiles are 64 WORDS: a tile's output run starts and ends wherever its words do, so two neighbouring
+// waves write into the same 128-byte line (and, through the two unaligned 16-byte edge stores, into the same 16-byte chunk).
+// profiles/r02_plan_decode_ablation.txt: without the edge stores the kernel is 8 % faster; zeroing and OR-ing the strip cost
+// nothing measurable.  Here a wave OWNS WHOLE LINES instead: its run is extended to the next line boundary past its last base with
+// the first bases of the NEXT tile (whose first kExtraWords words it loads as well), and it leaves the part of its own first line
+// before the boundary to the previous wave.  Every store is then a whole, aligned 16-byte chunk of a line no other wave touches --
+// the store pattern of the bulk decode -- except at the two ends of the batch.
+//   covered(t) := tile t+1 exists and the bases of its first kExtraWords words reach the line boundary at or after tile t's end.
+// Tile t computes covered(t) from the extra words' pad bytes and covered(t-1) from its OWN first kExtraWords pad bytes: the same
+// sums over the same bytes on both sides, so the two waves agree on who writes the shared line without communicating.  Where
+// coverage fails (words of very few bases, or the batch's ends) the run keeps its own end and strip_drain's edge stores, as before.
+constexpr unsigned kExtraWords = 8;                 // 8 full words = 256 bases >= 127: enough for every batch whose words average >= 16 bases
+constexpr int kLineStrip = kBatchTile * 2 + 2 * (int)kExtraWords + 8; // dwords: 64 + 8 words, the <= 15-byte lead, strip_or_word's third dword
+
+// strip_drain for a run [lo, hi) whose ends are line boundaries except at the ends of the batch: chunks of an UNSHARED line are stored
+// nt like the interior; a run of up to 2 KiB + 127 bytes has up to 136 chunks (three per lane).
+template <int POLICY>
+__device__ __forceinline__ void strip_drain_owned(const uint32_t *strip, uint8_t (*edge)[16], uint8_t *__restrict__ out, uintptr_t lo16, uintptr_t lo, uintptr_t hi, unsigned lane) {
+    const unsigned nchunk = (unsigned)((hi - lo16 + 15) >> 4); // <= 137
+    const uintptr_t op = reinterpret_cast<uintptr_t>(out);
+    if (hi - lo >= 16) { // wave-uniform
+        const unsigned lead = (unsigned)(lo - lo16), tail = (unsigned)(hi - lo16);
+        const unsigned c0 = lead ? 1u : 0u, c1 = tail >> 4; // whole chunks: c0 <= c < c1
+        // chunks on a line this run shares with a neighbour: the first line when lo is not a line boundary (c < cl0), the last when hi is not (c >= cl1)
+        const unsigned cl0 = (lo & 127) ? (unsigned)((((lo | 127) + 1) - lo16) >> 4) : 0u;
+        const uintptr_t last_line = (hi - 1) & ~(uintptr_t)127;
+        const unsigned cl1 = (hi & 127) ? (last_line > lo16 ? (unsigned)((last_line - lo16) >> 4) : 0u) : ~0u;
+        uint8_t *base = out + (lo16 - op); // derived from `out`: global (not flat) stores
+        if (lead == 0 && (tail & 15u) == 0) { // wave-uniform: whole chunks only -- every tile but the batch's first and last, where coverage holds
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const unsigned c = lane + 64 * j;
+                if (c >= nchunk) break;
+                const u32x4 d = dec16(strip[c]);
+                uint8_t *dst = base + 16u * c;
+                bool plain = POLICY == 1;
+                if constexpr (POLICY == 2) plain = c < cl0 || c >= cl1;
+                if (plain) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned c = lane + 64 * j;
+            if (c >= nchunk) break;
+            const bool whole = c >= c0 && c < c1;
+            const unsigned boff = whole ? 16u * c : (c == 0 ? lead : tail - 16u); // first byte (from lo16) of the 16 this lane stores
+            const unsigned bit = 2u * boff;
+            const uint32_t w0 = strip[bit >> 5], w1 = strip[(bit >> 5) + 1];
+            const u32x4 d = dec16(__builtin_amdgcn_alignbit(w1, w0, bit & 31));
+            uint8_t *dst = base + boff;
+            bool plain = !whole || POLICY == 1;
+            if constexpr (POLICY == 2) plain = plain || c < cl0 || c >= cl1;
+            if (plain) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory"); // any byte address (unaligned-access mode)
+            else asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { // a run shorter than 16 bytes: byte-wise through the wave's stage buffer
+        const unsigned c = lane + 64 * j;
+        if (c >= nchunk) break;
+        const uintptr_t g = lo16 + 16 * (uintptr_t)c;
+        uint8_t *e = edge[c ? 1 : 0];
+        *reinterpret_cast<u32x4 *>(e) = dec16(strip[c]);
+        store_stage_chunk(e, g, lo, hi);
+    }
+}
+
+template <int POLICY>
+__global__ void __launch_bounds__(kBlock)
+decode_batch_plan_lines_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
+                               unsigned long long total_words, uint8_t *__restrict__ out) {
+    __shared__ uint32_t strips[kBatchWaves][kLineStrip];
+    __shared__ __attribute__((aligned(16))) uint8_t edge[kBatchWaves][2][16];
+    const unsigned lane = threadIdx.x & 63, wave = wave_in_block();
+    uint32_t *strip = strips[wave];
+    const unsigned long long ntiles = (total_words + kBatchTile - 1) / kBatchTile;
+    const uintptr_t op = reinterpret_cast<uintptr_t>(out);
+    for (unsigned long long tile = (unsigned long long)blockIdx.x * kBatchWaves + wave; tile < ntiles; tile += (unsigned long long)gridDim.x * kBatchWaves) {
+        const unsigned long long wb = tile * kBatchTile;
+        const unsigned last = (unsigned)((total_words - wb < kBatchTile ? total_words - wb : kBatchTile) - 1);
+        const unsigned long long word = __builtin_nontemporal_load(words + wb + (lane < last ? lane : last));
+        const uint32_t n = lane <= last ? (uint32_t)P[wb + lane + 1] : 0u;
+        // the next tile's first words (every lane loads one of them: eight addresses, one request)
+        const unsigned long long xw = wb + kBatchTile + (lane & (kExtraWords - 1));
+        const bool has_x = xw < total_words;
+        const unsigned long long xword = words[has_x ? xw : total_words - 1]; // plain load: the next tile's wave reads the same line
+        const uint32_t xnb = has_x && lane < kExtraWords ? 32u - (uint32_t)P[xw + 1] : 0u;
+        const unsigned long long base0 = tile_base[tile];
+        const bool dense = __ballot(n != 0u) == 0ull;
+        const uintptr_t lo = op + base0;
+        if (dense && last == 63u && (lo & 127) == 0) {
+            // fast tile (wave-uniform): 2 KiB of whole lines, exactly its own words' bases (both neighbours see a line boundary here)
+            wave_lds_fence();
+            reinterpret_cast<unsigned long long *>(strip)[lane] = word;
+            wave_lds_fence();
+            const uint32_t h0 = strip[lane], h1 = strip[64 + lane];
+            uint8_t *dst = out + base0;
+            store_group<true, true>(dst + 16 * lane, dec16(h0));
+            store_group<true, true>(dst + 16 * (lane + 64), dec16(h1));
+            continue;
+        }
+        // one scan for both running sums: pad bytes of the tile's words (low half) and bases of the extra words (high half)
+        const uint32_t incl = wave_inclusive_sum(n | (xnb << 16));
+        const unsigned nb = 32u - n, base_rel = 32u * lane - ((incl & 0xFFFFu) - n);
+        const unsigned end_rel = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)last);
+        const unsigned first8 = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)(last < kExtraWords - 1 ? last : kExtraWords - 1)); // bases of this tile's first words
+        const unsigned next8 = (unsigned)__builtin_amdgcn_readlane((int)(incl >> 16), 63);                                                     // bases of the next tile's first words
+        const uintptr_t hi = lo + end_rel;
+        const unsigned gap_lo = (unsigned)(0 - lo) & 127u, gap_hi = (unsigned)(0 - hi) & 127u;
+        const bool prev_covers = tile > 0 && first8 >= gap_lo;               // covered(tile - 1), from this tile's own pad bytes
+        const bool covers = wb + kBatchTile < total_words && next8 >= gap_hi; // covered(tile), from the extra words' pad bytes
+        const uintptr_t own_lo = prev_covers ? lo + gap_lo : lo, own_hi = covers ? hi + gap_hi : hi;
+        if (own_hi <= own_lo) continue; // (wave-uniform) a last tile that lies inside the line its predecessor completed
+        const uintptr_t lo16 = lo & ~(uintptr_t)15;
+        wave_lds_fence(); // the previous tile's strip readers are done
+#pragma unroll
+        for (int j = 0; j < (kLineStrip + 63) / 64; ++j)
+            if (lane + 64 * j < (unsigned)kLineStrip) strip[lane + 64 * j] = 0u;
+        wave_lds_fence();
+        const unsigned lead_bits = 2u * (unsigned)(lo - lo16);
+        if (lane <= last) strip_or_word(strip, lead_bits + 2u * base_rel, word, nb);
+        if (covers && xnb) strip_or_word(strip, lead_bits + 2u * (end_rel + ((incl >> 16) - xnb)), xword, xnb);
+        wave_lds_fence();
+        const uintptr_t own16 = own_lo & ~(uintptr_t)15;
+        strip_drain_owned<POLICY>(strip + ((own16 - lo16) >> 4), edge[wave], out, own16, own_lo, own_hi, lane);
+    }
+}
+
 // Back-to-back fixed-length reads through the same tile body: the plan's two lookups are arithmetic here.  Wave-uniform
 // (scalar unit): r0 = floor(wb / wpr) by the host's multiply-high constant, j0 = wb - r0 wpr, base0 = r0 read_len + 32 j0.
 // Per lane, all 32-bit and relative to the tile: t = j0 + lane, q = floor(t / wpr) (t < wpr + 64), j = t - q wpr,

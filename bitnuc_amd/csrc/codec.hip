@@ -109,9 +109,9 @@ hipError_t launch_encode_t(bitnuc_ctx *c, const uint8_t *seq, uint32_t *out32, u
                            unsigned long long *slot, bool al) {
     const unsigned long long tile = (unsigned long long)BLOCK * UNROLL;
     const unsigned grid = grid_for(c, (len >> 4) / tile + 1, BLOCK);
-    // c->dyn_lds (evidence build, tools/ab_occupancy.py): unused dynamic LDS that only limits how many workgroups a CU holds
-    if (al) encode_kernel<UNROLL, BLOCK, NTLD, NTST, true, XPOSE, XCD><<<grid, BLOCK, c->dyn_lds, c->stream>>>(seq, out32, len, slot);
-    else if constexpr (!XPOSE) encode_kernel<UNROLL, BLOCK, NTLD, NTST, false, false, XCD><<<grid, BLOCK, c->dyn_lds, c->stream>>>(seq, out32, len, slot);
+    // knobs(c).dyn_lds (evidence build, tools/ab_occupancy.py): unused dynamic LDS that only limits how many workgroups a CU holds
+    if (al) encode_kernel<UNROLL, BLOCK, NTLD, NTST, true, XPOSE, XCD><<<grid, BLOCK, knobs(c).dyn_lds, c->stream>>>(seq, out32, len, slot);
+    else if constexpr (!XPOSE) encode_kernel<UNROLL, BLOCK, NTLD, NTST, false, false, XCD><<<grid, BLOCK, knobs(c).dyn_lds, c->stream>>>(seq, out32, len, slot);
     return hipGetLastError();
 }
 
@@ -169,8 +169,8 @@ template <int UNROLL, int BLOCK, bool NTLD, bool NTST, bool XPOSE, bool XCD>
 hipError_t launch_decode_t(bitnuc_ctx *c, const uint32_t *in32, uint8_t *out, unsigned long long n_bases, bool al) {
     const unsigned long long tile = (unsigned long long)BLOCK * UNROLL;
     const unsigned grid = grid_for(c, (n_bases >> 4) / tile + 1, BLOCK);
-    if (al) decode_kernel<UNROLL, BLOCK, NTLD, NTST, true, XPOSE, XCD><<<grid, BLOCK, c->dyn_lds, c->stream>>>(in32, out, n_bases);
-    else decode_kernel<UNROLL, BLOCK, NTLD, NTST, false, XPOSE, XCD><<<grid, BLOCK, c->dyn_lds, c->stream>>>(in32, out, n_bases);
+    if (al) decode_kernel<UNROLL, BLOCK, NTLD, NTST, true, XPOSE, XCD><<<grid, BLOCK, knobs(c).dyn_lds, c->stream>>>(in32, out, n_bases);
+    else decode_kernel<UNROLL, BLOCK, NTLD, NTST, false, XPOSE, XCD><<<grid, BLOCK, knobs(c).dyn_lds, c->stream>>>(in32, out, n_bases);
     return hipGetLastError();
 }
 

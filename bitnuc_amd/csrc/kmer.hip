@@ -15,14 +15,14 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
                         unsigned long long *slot) {
     unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
     size_t done = 0;
-    if (stride == k && count >= 64 && c->batch_dense) {
+    if (stride == k && count >= 64 && knobs(c).batch_dense) {
         // dense layout: whole waves of 64 k-mers go through the bulk-encode-shaped kernel
         const unsigned long long items = count / 64;
-        const int un = c->dense_unroll, kb = c->kmer_block;
+        const int un = knobs(c).dense_unroll, kb = knobs(c).kmer_block;
         const unsigned grid = grid_for(c, (items + (kb / 64) * un - 1) / ((kb / 64) * un), kb);
 #define DENSE_LAUNCH(AL, NL, NS, U) kmer_dense_kernel<AL, NL, NS, U><<<grid, kb, 0, c->stream>>>(kmers, (unsigned)k, items, o, slot)
 #define DENSE_POLICY(U)                                              \
-    switch (c->dense_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    switch (knobs(c).dense_policy) { /* bit0: nt loads, bit1: nt stores */ \
     case 0: DENSE_LAUNCH(true, false, false, U); break;              \
     case 1: DENSE_LAUNCH(true, true, false, U); break;               \
     case 2: DENSE_LAUNCH(true, false, true, U); break;               \
@@ -40,12 +40,12 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         done = items * 64;
         if (done == count) return hipSuccess;
     }
-    if (stride == 1 && done == 0 && c->batch_slide && c->slide_impl == 1 && aligned16(kmers) && aligned16(out) && count - 1 + k >= 1056) {
+    if (stride == 1 && done == 0 && knobs(c).batch_slide && knobs(c).slide_impl == 1 && aligned16(kmers) && aligned16(out) && count - 1 + k >= 1056) {
         // every window of a sequence (src/lib.rs:170-173): line-aligned rounds of 1024 windows, computed where they are stored
         const unsigned long long rounds = (count - 1 + k - 32) >> 10; // round r reads bytes [1024 r, 1024 r + 1056)
-        const int U = kEvidenceBuild ? c->slide2_rounds : 4; // the shipped form: 4 rounds per trip (profiles/r03_ab_windows.txt)
+        const int U = kEvidenceBuild ? knobs(c).slide2_rounds : 4; // the shipped form: 4 rounds per trip (profiles/r03_ab_windows.txt)
         const unsigned grid = grid_for(c, (rounds + (unsigned long long)U * (kBlock / 64) - 1) / ((unsigned long long)U * (kBlock / 64)));
-        const bool nts = (c->dense_policy & 2) != 0;
+        const bool nts = (knobs(c).dense_policy & 2) != 0;
 #define SLIDE2(NT, UU) kmer_slide2_kernel<NT, UU><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot)
         if constexpr (!kEvidenceBuild) { SLIDE2(true, 4); }
         else if (U == 1) { if (nts) SLIDE2(true, 1); else SLIDE2(false, 1); }
@@ -58,14 +58,14 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
     }
     // (k >= stride: every byte of the span belongs to some k-mer, so validating whole 16-byte groups examines no byte the
     // reference's loop would not; with gaps between k-mers the general kernel looks at each k-mer's own bytes only)
-    if ((stride == 1 || stride == 2 || stride == 4 || stride == 8 || stride == 16) && k >= stride && done == 0 && c->batch_slide &&
+    if ((stride == 1 || stride == 2 || stride == 4 || stride == 8 || stride == 16) && k >= stride && done == 0 && knobs(c).batch_slide &&
         aligned16(kmers) && aligned16(out) && (count - 1) * stride + k >= 1024) {
         // windows at a small power-of-two stride (1 = every window of a sequence): whole 1 KiB wave rounds through the
         // sliding kernel, 992 / stride windows each; the round that would read past the batch's last byte is left over
         const unsigned long long rounds = ((count - 1) * stride + k - 1024) / kScanWaveWindows + 1;
-        const unsigned long long per_wave = (unsigned long long)c->slide_rounds;
+        const unsigned long long per_wave = (unsigned long long)knobs(c).slide_rounds;
         const unsigned grid = grid_for(c, (rounds + per_wave * (kBlock / 64) - 1) / (per_wave * (kBlock / 64)));
-        const bool nts = (c->dense_policy & 2) != 0;
+        const bool nts = (knobs(c).dense_policy & 2) != 0;
 #define SLIDE_U(S, NT) do { if constexpr (kEvidenceBuild) { \
                               if (per_wave == 2) { kmer_slide_kernel<S, NT, 2><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); break; } \
                               if (per_wave == 4) { kmer_slide_kernel<S, NT, 4><<<grid, kBlock, 0, c->stream>>>(kmers, (unsigned)k, rounds, o, slot); break; } \
@@ -86,7 +86,7 @@ hipError_t launch_batch(bitnuc_ctx *c, const uint8_t *kmers, size_t k, size_t st
         done = (size_t)(rounds * (kScanWaveWindows / stride));
         if (done >= count) return hipSuccess;
     }
-    if (stride >= 3 && stride < 32 && k >= stride && done == 0 && c->batch_slide && aligned16(kmers) &&
+    if (stride >= 3 && stride < 32 && k >= stride && done == 0 && knobs(c).batch_slide && aligned16(kmers) &&
         (count - 1) * stride + k >= 1024) {
         // any other small stride with overlapping k-mers: the sliding round with per-lane window selection
         const unsigned long long rounds = ((count - 1) * stride + k - 1024) / kScanWaveWindows + 1;
@@ -123,14 +123,14 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
                        unsigned long long *slot) {
     uint32_t ql, qh;
     query_planes(query, k, &ql, &qh);
-    const int unroll = c->scan_unroll, kb = c->kmer_block;
+    const int unroll = knobs(c).scan_unroll, kb = knobs(c).kmer_block;
     const bool al = aligned16(ref) && aligned16(dist);
-    if (c->scan_impl == 1 && al) { // line-aligned rounds of 1024 windows
+    if (knobs(c).scan_impl == 1 && al) { // line-aligned rounds of 1024 windows
         const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
         const unsigned grid = grid_for(c, rounds / ((kb / 64) * unroll) + 1, kb);
 #define SCAN2(NL, NS, U) kmer_scan2_kernel<true, NL, NS, U, false><<<grid, kb, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, 0u, dist, nullptr, nullptr, nullptr, slot)
 #define SCAN2_POLICY(U)                                              \
-    switch (c->scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    switch (knobs(c).scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
     case 0: SCAN2(false, false, U); break;                           \
     case 1: SCAN2(true, false, U); break;                            \
     case 2: SCAN2(false, true, U); break;                            \
@@ -147,7 +147,7 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
 #define SCAN_LAUNCH(AL, NL, NS, U) \
     kmer_scan_kernel<AL, NL, NS, U><<<grid, kb, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot)
 #define SCAN_POLICY(U)                                             \
-    switch (c->scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
+    switch (knobs(c).scan_policy) { /* bit0: nt loads, bit1: nt stores */ \
     case 0: SCAN_LAUNCH(true, false, false, U); break;             \
     case 1: SCAN_LAUNCH(true, true, false, U); break;              \
     case 2: SCAN_LAUNCH(true, false, true, U); break;              \
@@ -315,7 +315,7 @@ int bitnuc_hdist_dev(bitnuc_ctx *c, const uint64_t *d_a, size_t na, const uint64
     if (!d_a || !d_b) return fail(err, BITNUC_UNSUPPORTED);
     const unsigned long long tiles = (n_bases / 32) / (kBlock * 2) + 1;
     const unsigned grid = (unsigned)(tiles < c->hdist_blocks ? tiles : c->hdist_blocks);
-    if (c->hdist_tiled) hdist_kernel<true><<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
+    if (knobs(c).hdist_tiled) hdist_kernel<true><<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
                                                  reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result, reinterpret_cast<unsigned *>(c->d_acc + 4), c->d_tickets + 1);
     else hdist_kernel<false><<<grid, kBlock, 0, c->stream>>>(reinterpret_cast<const unsigned long long *>(d_a),
                                                  reinterpret_cast<const unsigned long long *>(d_b), n_bases, d_result, reinterpret_cast<unsigned *>(c->d_acc + 4), c->d_tickets + 1);

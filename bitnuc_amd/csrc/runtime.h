@@ -30,6 +30,38 @@ constexpr size_t kDefaultHostCutoff = (size_t)1 << 20;       // encode, hdist
 constexpr size_t kDefaultHostCutoffDecode = (size_t)1 << 19; // decode
 constexpr int kDefaultEnc = 39, kDefaultDec = 22;            // codec.hip: the variant tables
 
+// Selectors of ALTERNATIVE FORMULATIONS -- the ones that lost their A/B (profiles/README.md) and timing-only ablations.  The product
+// context does not hold them: knobs(c) is this struct's defaults, a compile-time constant, and bitnuc_ctx_set_variant() answers -2 to
+// anything but the shipped value.  Only the evidence build (-DBITNUC_SWEEP_VARIANTS, libbitnuc_hip_sweep.so: tools/ and the variant
+// tests) keeps a copy per context that can be changed.  The default of every field IS what ships.
+struct SweepKnobs {
+    int dyn_lds = 0;             // bytes of unused dynamic LDS per workgroup of the bulk codec launches (an occupancy limiter, tools/ab_occupancy.py)
+    int batch_dense = 1;         // stride == k batches use kmer_dense_kernel (0: the general strided kernel)
+    int batch_slide = 1;         // stride 1 (every window of a sequence), 2, 4, 8, 16 batches use the sliding kernels (0: the general strided kernel)
+    int slide_impl = 1;          // stride-1 windows: 1 = line-aligned rounds of 1024 windows (kmer_slide2_kernel), 0 = rounds of 992 (kmer_slide_kernel)
+    int slide_rounds = 1;        // kmer_slide_kernel: consecutive rounds per wave trip (1, 2, 4, 8)
+    int slide2_rounds = 4;       // kmer_slide2_kernel: consecutive 1 KiB rounds per wave trip (1, 2, 4)
+    int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
+    int kmer_block = 256;        // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
+    int dense_unroll = 1;        // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
+    int scan_unroll = 4;         // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
+    int scan_impl = 1;           // 1 = line-aligned rounds of 1024 windows (kmer_scan2_kernel), 0 = rounds of 992 windows (kmer_scan_kernel)
+    int hdist_tiled = 0;         // bulk hdist: 1 = grid-stride at tile granularity (16 KiB of each operand per workgroup trip), 0 = at thread granularity
+    int hdist_words_impl = 1;    // many-pair / one-query hdist: 1 = coalesced loads + bpermute for whole 256-word tiles, 0 = four contiguous words per lane
+    int fixed_stream = 1;        // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
+    int fixed_dec_strip = 2;     // decode_fixed (back-to-back reads): 0 = byte scatter, 1 = bit strip with per-lane 64-bit positions, 2 = the plan decode's tile body with arithmetic lookups
+    int owner_est = 3;           // block_owner_kernel's first guess: 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, 3 = 2 or 0 by average sequence length
+    int batch_tables_impl = 1;   // table-driven ragged batches: 1 = one asynchronous pass emits the layout plan into context scratch, then the plan kernels; 0 = tile records + O(1) lookup kernels
+    int batch_host_plan = 1;     // host-pointer ragged-batch calls build a layout plan (bitnuc_batch_plan) and use the plan kernels (0: the table-driven form)
+    int plan_dec_lines = 1;      // plan decode: 1 = line-owning tiles (decode_batch_plan_lines_kernel), 0 = word tiles with shared edge lines (decode_batch_plan_kernel)
+    int plan_tiles = 1;          // decode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
+    int plan_store = 2;          // decode_batch_plan_kernel's whole-chunk store policy: 0 nt, 1 plain, 2 plain on the shared edge lines + nt elsewhere
+    int plan_enc_block = 256;    // threads per workgroup of the plan encode (64, 128, 256)
+    int plan_enc_tiles = 1;      // encode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
+    int plan_enc_abl = 0;        // timing-only ablations of the plan encode's loads (see plan_enc_issue)
+    int batch_abl = 0;           // timing-only ablation mask of the second table-driven formulation (tools/ab_batch_ablate.py)
+};
+
 // One block of per-launch error slots: device words (all-ones = no error) + a pinned mirror + the index base of each launch.
 struct SlotBlock {
     unsigned long long *d = nullptr, *h = nullptr;
@@ -61,34 +93,13 @@ struct bitnuc_ctx {
     unsigned *d_tickets = nullptr;       // [0] base_counts, [1] hdist, [2] scan count: arrival counters, zero between launches
     unsigned reduce_blocks = 512;        // base_counts: resident grid (2 workgroups per CU)
     unsigned hdist_blocks = 256;         // bulk hdist: resident grid (1 workgroup per CU: 8 loads in flight per thread; profiles/r03_ab_hdist_grid.txt)
-    // ---- knobs (bitnuc_ctx_set_variant) ----
-    int enc_variant = bitnuc_rt::kDefaultEnc, dec_variant = bitnuc_rt::kDefaultDec;
+    // ---- knobs (bitnuc_ctx_set_variant): what an integrator may turn ----
+    int enc_variant = bitnuc_rt::kDefaultEnc, dec_variant = bitnuc_rt::kDefaultDec; // the bulk codec's shipped variants (codec.hip)
     int grid_mult = 0;                   // see grid_for()
-    unsigned dyn_lds = 0;                // evidence build: bytes of unused dynamic LDS per workgroup of the bulk codec launches (an occupancy limiter for tools/ab_occupancy.py)
-    int batch_dense = 1;                 // stride == k batches use kmer_dense_kernel
-    int slide_rounds = 1;                // kmer_slide_kernel: consecutive rounds per wave trip (1, 2 or 4)
-    int slide2_rounds = 4;               // kmer_slide2_kernel: consecutive 1 KiB rounds per wave trip (evidence build: 1, 2 or 4; tools/ab_r03.py)
-    int slide_impl = 1;                  // stride-1 windows: 1 = line-aligned rounds of 1024 windows (kmer_slide2_kernel), 0 = rounds of 992 (kmer_slide_kernel)
-    int batch_slide = 1;                 // stride 1 (every window of a sequence), 2, 4, 8, 16 batches use the sliding kernels
-    int dense_policy = 3, scan_policy = 3; // bit0: nt loads, bit1: nt stores
-    int fixed_stream = 1;                  // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
-    int fixed_dec_strip = 2;               // decode_fixed (back-to-back reads): 0 = byte scatter, 1 = bit strip with per-lane 64-bit positions, 2 = the plan decode's tile body with arithmetic lookups (tools/ab_fixed_dec.py)
-    int owner_est = 3;                     // block_owner_kernel's first guess (evidence build): 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, 3 = 2 or 0 by average sequence length
-    int batch_tables_impl = 1;             // table-driven ragged batches: 1 = one asynchronous pass emits the layout plan into context scratch, then the plan kernels; 0 = tile records + O(1) lookup kernels (evidence build)
-    int batch_host_plan = 1;               // host-pointer ragged-batch calls build a layout plan (bitnuc_batch_plan) and use the plan kernels
-    bitnuc_batch_plan *host_plan = nullptr; // ... kept by the context
-    int plan_tiles = 1;                    // decode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
-    int plan_enc_abl = 0;                  // evidence build: timing-only ablations of the plan encode's loads (see plan_enc_issue)
-    int plan_enc_block = 256;              // threads per workgroup of the plan encode (64, 128, 256)
-    int plan_enc_tiles = 1;                // encode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
-    int plan_store = 2;                    // decode_batch_plan_kernel's whole-chunk store policy: 0 nt, 1 plain, 2 plain on the shared edge lines + nt elsewhere
-    int batch_abl = 0;                     // timing-only ablation mask of the second formulation (tools/ab_batch_ablate.py); 0 in normal use
-    int kmer_block = 256;                  // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
-    int dense_unroll = 1;                  // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
-    int scan_unroll = 4;                   // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
-    int scan_impl = 1;                     // 1 = line-aligned rounds of 1024 windows (kmer_scan2_kernel), 0 = rounds of 992 windows (kmer_scan_kernel)
-    int hdist_tiled = 0;                   // bulk hdist: 1 = grid-stride at tile granularity (16 KiB of each operand per workgroup trip), 0 = at thread granularity
-    int hdist_words_impl = 1;              // many-pair / one-query hdist: 1 = coalesced loads + bpermute for whole 256-word tiles, 0 = four contiguous words per lane
+#ifdef BITNUC_SWEEP_VARIANTS
+    bitnuc_rt::SweepKnobs sweep;         // evidence build only: selectors of the formulations that lost their A/B (see SweepKnobs)
+#endif
+    bitnuc_batch_plan *host_plan = nullptr; // the layout plan the host-pointer ragged-batch calls build and keep
     int force_gpu = 0;                     // 1: single-word and below-cutoff calls launch kernels too (GPU parity tests, BITNUC_FORCE_GPU=1)
     size_t host_cutoff = bitnuc_rt::kDefaultHostCutoff; // bulk host-pointer encode / hdist below this many bases run on the host (host_word.h)
     size_t host_cutoff_decode = bitnuc_rt::kDefaultHostCutoffDecode; // ... decode
@@ -175,8 +186,11 @@ inline bool on_host(const bitnuc_ctx *c, size_t n, bool decode = false) {
 // set_variant() to anything but the shipped value returns -2 and changes nothing.
 #ifdef BITNUC_SWEEP_VARIANTS
 constexpr bool kEvidenceBuild = true;
+inline const SweepKnobs &knobs(const bitnuc_ctx *c) { return c->sweep; }
 #else
 constexpr bool kEvidenceBuild = false;
+constexpr SweepKnobs kShipped{};
+inline constexpr const SweepKnobs &knobs(const bitnuc_ctx *) { return kShipped; } // a constant: the launch code's branches on it fold away
 #endif
 
 // ---- cross-unit entry points that are not part of the C ABI ------------------------------------------------------------

@@ -299,8 +299,68 @@ int bitnuc_ctx_sync(bitnuc_ctx *c, bitnuc_err *err) {
     return st;
 }
 
+namespace {
+
+// The selectors of alternative formulations (runtime.h SweepKnobs): key, field, and the values the evidence build accepts.
+struct SweepKey {
+    const char *key;
+    int bitnuc_rt::SweepKnobs::*field;
+    int lo, hi;          // accepted range ...
+    unsigned long long only; // ... or, when non-zero, a set: bit v set = value v accepted (v < 64), plus `also`
+    int also[3];         // values >= 64 of the set (0 = none)
+};
+constexpr SweepKey kSweepKeys[] = {
+    {"dyn_lds", &bitnuc_rt::SweepKnobs::dyn_lds, 0, 64 * 1024, 0, {0, 0, 0}},
+    {"batch_dense", &bitnuc_rt::SweepKnobs::batch_dense, 0, 1, 0, {0, 0, 0}},
+    {"batch_slide", &bitnuc_rt::SweepKnobs::batch_slide, 0, 1, 0, {0, 0, 0}},
+    {"slide_impl", &bitnuc_rt::SweepKnobs::slide_impl, 0, 1, 0, {0, 0, 0}},
+    {"slide_rounds", &bitnuc_rt::SweepKnobs::slide_rounds, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4 | 1ull << 8, {0, 0, 0}},
+    {"slide2_rounds", &bitnuc_rt::SweepKnobs::slide2_rounds, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
+    {"dense_policy", &bitnuc_rt::SweepKnobs::dense_policy, 0, 3, 0, {0, 0, 0}},
+    {"scan_policy", &bitnuc_rt::SweepKnobs::scan_policy, 0, 3, 0, {0, 0, 0}},
+    {"kmer_block", &bitnuc_rt::SweepKnobs::kmer_block, 0, 0, 0, {64, 128, 256}},
+    {"dense_unroll", &bitnuc_rt::SweepKnobs::dense_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
+    {"scan_unroll", &bitnuc_rt::SweepKnobs::scan_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
+    {"scan_impl", &bitnuc_rt::SweepKnobs::scan_impl, 0, 1, 0, {0, 0, 0}},
+    {"hdist_tiled", &bitnuc_rt::SweepKnobs::hdist_tiled, 0, 1, 0, {0, 0, 0}},
+    {"hdist_words_impl", &bitnuc_rt::SweepKnobs::hdist_words_impl, 0, 1, 0, {0, 0, 0}},
+    {"fixed_stream", &bitnuc_rt::SweepKnobs::fixed_stream, 0, 1, 0, {0, 0, 0}},
+    {"fixed_dec_strip", &bitnuc_rt::SweepKnobs::fixed_dec_strip, 0, 2, 0, {0, 0, 0}},
+    {"owner_est", &bitnuc_rt::SweepKnobs::owner_est, 0, 3, 0, {0, 0, 0}},
+    {"batch_tables_impl", &bitnuc_rt::SweepKnobs::batch_tables_impl, 0, 1, 0, {0, 0, 0}},
+    {"batch_host_plan", &bitnuc_rt::SweepKnobs::batch_host_plan, 0, 1, 0, {0, 0, 0}},
+    {"plan_dec_lines", &bitnuc_rt::SweepKnobs::plan_dec_lines, 0, 1, 0, {0, 0, 0}},
+    {"plan_tiles", &bitnuc_rt::SweepKnobs::plan_tiles, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
+    {"plan_store", &bitnuc_rt::SweepKnobs::plan_store, 0, 2, 0, {0, 0, 0}},
+    {"plan_enc_block", &bitnuc_rt::SweepKnobs::plan_enc_block, 0, 0, 0, {64, 128, 256}},
+    {"plan_enc_tiles", &bitnuc_rt::SweepKnobs::plan_enc_tiles, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
+    {"plan_enc_abl", &bitnuc_rt::SweepKnobs::plan_enc_abl, 0, 7, 0, {0, 0, 0}},
+    {"batch_abl", &bitnuc_rt::SweepKnobs::batch_abl, 0, 15, 0, {0, 0, 0}},
+};
+
+// -3: not one of these keys; otherwise the previous value, or -2 for a value this build does not hold
+int set_sweep_key(bitnuc_ctx *c, const char *key, int value) {
+    for (const SweepKey &k : kSweepKeys) {
+        if (strcmp(key, k.key)) continue;
+        const int prev = bitnuc_rt::knobs(c).*(k.field);
+        if (value < 0) return prev; // query
+#ifdef BITNUC_SWEEP_VARIANTS
+        bool ok = k.only ? (value < 64 && (k.only >> value & 1)) : (k.also[0] ? false : value >= k.lo && value <= k.hi);
+        for (int a : k.also) ok = ok || (a && a == value);
+        if (ok) c->sweep.*(k.field) = value; // (an unaccepted value changes nothing, as before)
+        return prev;
+#else
+        return value == prev ? prev : -2; // the product holds the shipped formulation only
+#endif
+    }
+    return -3;
+}
+
+} // namespace
+
 int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     if (!c || !key) return -1;
+    if (const int r = set_sweep_key(c, key, value); r != -3) return r;
     int prev = -1;
     if (!strcmp(key, "encode")) {
         prev = c->enc_variant;
@@ -317,35 +377,6 @@ int bitnuc_ctx_set_variant(bitnuc_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "host_pipeline")) { prev = c->host_pipeline; if (value == 0 || value == 1) c->host_pipeline = value; }
     else if (!strcmp(key, "sweep_build")) { prev = kEvidenceBuild ? 1 : 0; }
     else if (!strcmp(key, "grid_mult")) { prev = c->grid_mult; if (value >= 0 && value <= 64) c->grid_mult = value; }
-    else if (!strcmp(key, "dyn_lds")) { prev = (int)c->dyn_lds; if (value > 0 && !kEvidenceBuild) return -2; if (value >= 0 && value <= 64 * 1024) c->dyn_lds = (unsigned)value; }
-    else if (!strcmp(key, "batch_dense")) { prev = c->batch_dense; if (value >= 0 && value <= 1) c->batch_dense = value; }
-    else if (!strcmp(key, "batch_slide")) { prev = c->batch_slide; if (value >= 0 && value <= 1) c->batch_slide = value; }
-    else if (!strcmp(key, "dense_policy")) { prev = c->dense_policy; if (value >= 0 && !kEvidenceBuild && value != 3) return -2; if (value >= 0 && value <= 3) c->dense_policy = value; }
-    else if (!strcmp(key, "scan_policy")) { prev = c->scan_policy; if (value >= 0 && !kEvidenceBuild && value != 3) return -2; if (value >= 0 && value <= 3) c->scan_policy = value; }
-    else if (!strcmp(key, "fixed_stream")) { prev = c->fixed_stream; if (value == 0 || value == 1) c->fixed_stream = value; }
-    else if (!strcmp(key, "fixed_dec_strip")) { prev = c->fixed_dec_strip; if (value >= 0 && !kEvidenceBuild && value != 2) return -2; if (value >= 0 && value <= 2) c->fixed_dec_strip = value; }
-    else if (!strcmp(key, "owner_est")) { prev = c->owner_est; if (value >= 0 && value <= 3) c->owner_est = value; }
-    else if (!strcmp(key, "batch_tables_impl")) { prev = c->batch_tables_impl; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 0 || value == 1) c->batch_tables_impl = value; }
-    else if (!strcmp(key, "batch_host_plan")) { prev = c->batch_host_plan; if (value == 0 || value == 1) c->batch_host_plan = value; }
-    else if (!strcmp(key, "plan_tiles")) { prev = c->plan_tiles; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->plan_tiles = value; }
-    else if (!strcmp(key, "plan_enc_abl")) { prev = c->plan_enc_abl; if (value >= 0 && !kEvidenceBuild && value != 0) return -2; if (value >= 0 && value <= 7) c->plan_enc_abl = value; }
-    else if (!strcmp(key, "plan_enc_block")) { prev = c->plan_enc_block; if (value == 64 || value == 128 || value == 256) c->plan_enc_block = value; }
-    else if (!strcmp(key, "plan_enc_tiles")) { prev = c->plan_enc_tiles; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->plan_enc_tiles = value; }
-    else if (!strcmp(key, "slide_rounds")) { prev = c->slide_rounds; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4 || value == 8) c->slide_rounds = value; }
-    else if (!strcmp(key, "slide2_rounds")) { prev = c->slide2_rounds; if (value >= 0 && !kEvidenceBuild && value != 4) return -2; if (value == 1 || value == 2 || value == 4) c->slide2_rounds = value; }
-    else if (!strcmp(key, "slide_impl")) { prev = c->slide_impl; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 0 || value == 1) c->slide_impl = value; }
-    else if (!strcmp(key, "plan_store")) { prev = c->plan_store; if (value >= 0 && !kEvidenceBuild && value != 2) return -2; if (value >= 0 && value <= 2) c->plan_store = value; }
-    else if (!strcmp(key, "batch_abl")) {
-        prev = c->batch_abl;
-        if (kEvidenceBuild) { if (value >= 0 && value <= 15) c->batch_abl = value; }
-        else if (value > 0) return -2; // ablated kernels exist in the evidence build only
-    }
-    else if (!strcmp(key, "kmer_block")) { prev = c->kmer_block; if (value == 64 || value == 128 || value == 256) c->kmer_block = value; }
-    else if (!strcmp(key, "dense_unroll")) { prev = c->dense_unroll; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 1 || value == 2 || value == 4) c->dense_unroll = value; }
-    else if (!strcmp(key, "scan_impl")) { prev = c->scan_impl; if (value >= 0 && !kEvidenceBuild && value != 1) return -2; if (value == 0 || value == 1) c->scan_impl = value; }
-    else if (!strcmp(key, "scan_unroll")) { prev = c->scan_unroll; if (value >= 0 && !kEvidenceBuild && value != 4) return -2; if (value == 1 || value == 2 || value == 4) c->scan_unroll = value; }
-    else if (!strcmp(key, "hdist_tiled")) { prev = c->hdist_tiled; if (value == 0 || value == 1) c->hdist_tiled = value; }
-    else if (!strcmp(key, "hdist_words_impl")) { prev = c->hdist_words_impl; if (value == 0 || value == 1) c->hdist_words_impl = value; }
     else if (!strcmp(key, "reduce_mult")) { prev = (int)(c->reduce_blocks / (unsigned)c->num_cu); if (value >= 1 && value <= 32) c->reduce_blocks = (unsigned)c->num_cu * (unsigned)value; }
     else if (!strcmp(key, "hdist_mult")) { prev = (int)(c->hdist_blocks / (unsigned)c->num_cu); if (value >= 1 && value <= 32) c->hdist_blocks = (unsigned)c->num_cu * (unsigned)value; }
     else if (!strcmp(key, "num_variants")) { prev = codec_num_variants(); }

@@ -209,10 +209,40 @@ def build_flags():
     return None
 
 
-def avx2_time_roundtrip(seq):
+_native = None
+
+
+def native_lib():
+    """The same two oracle sources compiled `-O3 -march=native` ON THIS HOST into a temporary directory (never into the tree: the
+    tracked build is -march=x86-64-v3 because it is built in the CPU container and travels).  BASELINE.md section 3 and the reference's
+    .cargo/config.toml:1-2 (target-cpu=native) ask for the native figure; bench.py's cpu_baseline reports both.
+    -> (CDLL, flags string) or (None, reason)."""
+    global _native
+    if _native is None:
+        import tempfile
+        d = tempfile.mkdtemp(prefix="bitnuc_oracle_native_")
+        out = os.path.join(d, "libbitnuc_oracle_native.so")
+        flags = ["-O3", "-march=native", "-fPIC", "-Wall", "-Wextra", "-std=c11", "-D_POSIX_C_SOURCE=200809L"]
+        cc = os.environ.get("CC", "gcc")
+        try:
+            r = subprocess.run([cc, *flags, "-shared", "-o", out, os.path.join(ORACLE_DIR, "bitnuc_oracle.c"), os.path.join(ORACLE_DIR, "bitnuc_avx2.c")],
+                               capture_output=True, text=True, timeout=300)
+        except Exception as e:  # noqa: BLE001
+            _native = (None, repr(e)[:200])
+            return _native
+        if r.returncode != 0:
+            _native = (None, r.stderr[-300:])
+            return _native
+        L = C.CDLL(out)
+        L.orc_avx2_time_roundtrip.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _native = (L, cc + " " + " ".join(flags[:2]) + " (built on this host into a temporary directory)")
+    return _native
+
+
+def avx2_time_roundtrip(seq, L=None):
     s = _u8(seq)
     e, d = C.c_double(0), C.c_double(0)
-    st = lib().orc_avx2_time_roundtrip(_p(s), s.size, C.byref(e), C.byref(d))
+    st = (L or lib()).orc_avx2_time_roundtrip(_p(s), s.size, C.byref(e), C.byref(d))
     if st:
         raise RuntimeError(f"avx2 round trip failed: {st}")
     return e.value, d.value

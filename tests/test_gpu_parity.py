@@ -157,7 +157,10 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
                                  ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 1, (0,)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
-                                 ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,))):
+                                 ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,)),
+                                 ("batch_dense", 1, (0,)), ("batch_slide", 1, (0,)), ("batch_host_plan", 1, (0,)), ("fixed_stream", 1, (0,)), ("owner_est", 3, (0, 1, 2)),
+                                 ("plan_enc_block", 256, (64, 128)), ("kmer_block", 256, (64, 128)), ("hdist_tiled", 0, (1,)), ("hdist_words_impl", 1, (0,)),
+                                 ("plan_enc_abl", 0, (1,)), ("dyn_lds", 0, (1024,))):
         assert ctx.get(key) == shipped, key
         assert all(ctx.set_variant(key, v) == -2 for v in others) and ctx.get(key) == shipped, key
     for v in built:
@@ -291,7 +294,7 @@ def test_dev_path_unaligned_and_async_errors(ctx, oracle):
     ctx.sync()
 
 
-def test_kmer_dev_paths_unaligned(ctx, oracle):
+def test_kmer_dev_paths_unaligned(ctx, sweep_ctx, oracle):
     import torch
     dev = torch.device("cuda:0")
     for k, stride, count in [(31, 31, 5000), (32, 32, 777), (16, 16, 64), (31, 31, 63), (21, 40, 3000)]:
@@ -309,12 +312,13 @@ def test_kmer_dev_paths_unaligned(ctx, oracle):
             assert np.array_equal(o[1:-1], oracle.as_2bit_batch(s, k, stride, count)), (k, stride, count, off)
     # dense-kernel switch off == on
     s = rand_seq(31 * 4096)
-    prev = ctx.set_variant("batch_dense", 0)
-    a = ctx.as_2bit_batch(s, 31, 31, 4096)
-    ctx.set_variant("batch_dense", 1)
-    b = ctx.as_2bit_batch(s, 31, 31, 4096)
-    ctx.set_variant("batch_dense", prev)
-    assert np.array_equal(a, b) and np.array_equal(a, oracle.as_2bit_batch(s, 31, 31, 4096))
+    assert ctx.set_variant("batch_dense", 0) == -2  # a switch of the evidence build: the product holds the shipped routing only
+    prev = sweep_ctx.set_variant("batch_dense", 0)
+    a = sweep_ctx.as_2bit_batch(s, 31, 31, 4096)
+    sweep_ctx.set_variant("batch_dense", 1)
+    b = sweep_ctx.as_2bit_batch(s, 31, 31, 4096)
+    sweep_ctx.set_variant("batch_dense", prev)
+    assert np.array_equal(a, b) and np.array_equal(a, oracle.as_2bit_batch(s, 31, 31, 4096)) and np.array_equal(a, ctx.as_2bit_batch(s, 31, 31, 4096))
     # scan with unaligned ref / dist pointers
     n, k = 70001, 31
     s = rand_seq(n)
@@ -363,7 +367,7 @@ def test_kmer_batch_vs_oracle(ctx, oracle, k, stride):
 
 
 @pytest.mark.parametrize("k", [1, 2, 4, 15, 16, 17, 21, 31, 32])
-def test_kmer_windows_stride1_vs_oracle(ctx, oracle, k):
+def test_kmer_windows_stride1_vs_oracle(ctx, sweep_ctx, oracle, k):
     """`for w in seq.windows(k) { as_2bit(w) }` (src/lib.rs:170-173): the sliding kernel (whole 1 KiB rounds) plus
     the generic kernel for the leftover windows, against the oracle's loop; sizes around the round boundaries."""
     import torch
@@ -391,11 +395,11 @@ def test_kmer_windows_stride1_vs_oracle(ctx, oracle, k):
         assert np.array_equal(o[out_off:out_off + count], exp), (k, in_off, out_off)
         assert not o[:out_off].any() and not o[out_off + count:].any()
     # sliding kernel off == on
-    prev = ctx.set_variant("batch_slide", 0)
+    prev = sweep_ctx.set_variant("batch_slide", 0)  # (evidence build: the product has no such switch)
     try:
-        assert np.array_equal(ctx.as_2bit_batch(s, k, 1, count), exp)
+        assert np.array_equal(sweep_ctx.as_2bit_batch(s, k, 1, count), exp)
     finally:
-        ctx.set_variant("batch_slide", prev)
+        sweep_ctx.set_variant("batch_slide", prev)
 
 
 @pytest.mark.parametrize("stride", [2, 4, 8, 16])
@@ -424,7 +428,7 @@ def test_kmer_windows_small_power_of_two_strides(ctx, oracle, k, stride):
 
 
 @pytest.mark.parametrize("k,stride", [(31, 3), (31, 5), (31, 6), (31, 7), (21, 12), (31, 24), (32, 31), (32, 17), (16, 9), (7, 3), (31, 30)])
-def test_kmer_windows_other_small_strides(ctx, oracle, k, stride):
+def test_kmer_windows_other_small_strides(ctx, sweep_ctx, oracle, k, stride):
     """Overlapping k-mers at a stride that is not a power of two: the sliding round with per-lane window selection."""
     import bitnuc_amd as bn
     for count in [1, 40, 330 // max(1, stride // 3), 1024 // stride + 1, 2016 // stride + 3, 5 * 992 // stride + 7, 10007, 100003]:
@@ -442,12 +446,12 @@ def test_kmer_windows_other_small_strides(ctx, oracle, k, stride):
     with pytest.raises(oracle.OracleError) as oe:
         oracle.as_2bit_batch(s, k, stride, count)
     assert (ei.value.byte, ei.value.index) == (oe.value.byte, oe.value.index) == (ord("N"), pos)
-    prev = ctx.set_variant("batch_slide", 0)  # general kernel == sliding kernel
+    prev = sweep_ctx.set_variant("batch_slide", 0)  # general kernel == sliding kernel (evidence build: the product has no such switch)
     try:
         t = rand_seq((20000 - 1) * stride + k)
-        ref = ctx.as_2bit_batch(t, k, stride, 20000)
+        ref = sweep_ctx.as_2bit_batch(t, k, stride, 20000)
     finally:
-        ctx.set_variant("batch_slide", prev)
+        sweep_ctx.set_variant("batch_slide", prev)
     assert np.array_equal(ctx.as_2bit_batch(t, k, stride, 20000), ref)
 
 
@@ -593,7 +597,7 @@ def batch_ctx(request, ctx, sweep_ctx):
     kernels (tile records by a search pre-kernel + O(1) pad-scatter lookup), which live on in the evidence build.  The plan
     kernels with 2 and 4 tiles per wave trip exist in the evidence build only (they lost their A/B)."""
     use_plan, tiles, impl = request.param
-    c = ctx if (tiles == 1 and impl == 1) else sweep_ctx
+    c = ctx if (use_plan, tiles, impl) == (1, 1, 1) else sweep_ctx  # the product holds the shipped routing only
     prev = c.set_variant("batch_host_plan", use_plan)
     prev_e = c.set_variant("plan_enc_tiles", tiles)
     prev_d = c.set_variant("plan_tiles", tiles)
@@ -879,7 +883,7 @@ def test_beyond_4gib_batches(ctx, oracle):
     plan.close()
 
 
-def test_batch_fuzz_vs_oracle_loop(ctx, oracle):
+def test_batch_fuzz_vs_oracle_loop(ctx, sweep_ctx, oracle):
     """Random ragged batches (length mixes incl. empties and sub-word sequences, a batch that starts anywhere in its buffer,
     lower case) through the plan and the table-driven kernels, against the oracle's per-sequence loop; then one invalid byte
     at a random position: (byte, index) of the first one in buffer order."""
@@ -895,7 +899,9 @@ def test_batch_fuzz_vs_oracle_loop(ctx, oracle):
         buf = np.concatenate([np.full(pre, ord("N"), np.uint8), seq, np.full(int(rng.integers(0, 20)), ord("N"), np.uint8)])
         off2 = off + np.uint64(pre)
         ew, ewo = _oracle_batch(oracle, seq, off)
+        product = ctx
         for use_plan in (1, 0):
+            ctx = product if use_plan else sweep_ctx  # host calls through the table-driven form: a switch of the evidence build
             prev = ctx.set_variant("batch_host_plan", use_plan)
             try:
                 w, wo = ctx.encode_batch(buf, off2)

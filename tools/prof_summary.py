@@ -8,6 +8,8 @@ bytes of a coalesced streaming read, so it is doubled; WRITE_SIZE is taken as is
 import collections
 import csv
 import datetime
+import glob
+import shutil
 import hashlib
 import json
 import os
@@ -36,7 +38,7 @@ def main():
              "(PMC passes: same command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separately; no trace domains combined with --pmc.)", "",
              "## kernel stats (--kernel-trace --stats)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
     lines[3] = "(PMC passes: same command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separately; no trace domains combined with --pmc.  `kernel_stats_full_run.csv`: the same trace of the default run, side measurements included.)"
-    stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
+    stats = list(csv.DictReader(open((glob.glob(os.path.join(src, "trace", "**", "trace_kernel_stats.csv"), recursive=True) or [os.path.join(src, "trace", "trace_kernel_stats.csv")])[0])))
     avg = {}
     for r in stats:
         k = kernel_short(r["Name"])
@@ -44,8 +46,8 @@ def main():
         lines.append(f"| `{k[:90]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        path = os.path.join(src, sub, "pmc_counter_collection.csv")
-        if not os.path.exists(path):
+        path = (glob.glob(os.path.join(src, sub, "**", "pmc_counter_collection.csv"), recursive=True) or [None])[0]
+        if not path:
             continue
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == ctr:
@@ -69,6 +71,44 @@ def main():
     if enc_us and dec_us:
         lines += ["", f"Achieved (algorithmic 1.25e9 B / avg duration): encode {1.25e9/enc_us:.1f} GB/s = {1.25e9/enc_us/8000*100:.1f}% of 8 TB/s; "
                       f"decode {1.25e9/dec_us:.1f} GB/s = {1.25e9/dec_us/8000*100:.1f}% of 8 TB/s"]
+    # ---- BASELINE configs 3 and 5 alone at full size (tools/run_cfg35.py under the same three passes) ----
+    side = {}
+    CFG = {"cfg3": ("kmer_dense_kernel", 10**8 * 39, "10^8 dense 31-mers: 39 B per k-mer (31 read + 8 written)"),
+           "cfg5": ("kmer_scan2_kernel", 2 * (10**9 - 30), "10^9-base scan: 2 B per window (1 read + 1 written)")}
+    for cfg, (kname, alg, what) in CFG.items():
+        tpath = glob.glob(os.path.join(src, cfg + "_trace", "**", "trace_kernel_stats.csv"), recursive=True)
+        if not tpath:
+            continue
+        row = next((r for r in csv.DictReader(open(tpath[0])) if kname in r["Name"]), None)
+        if row is None:
+            continue
+        vals = {}
+        for sub, ctr in ((cfg + "_pmc_fetch", "FETCH_SIZE"), (cfg + "_pmc_write", "WRITE_SIZE")):
+            ppath = glob.glob(os.path.join(src, sub, "**", "pmc_counter_collection.csv"), recursive=True)
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(ppath[0])) if r["Counter_Name"] == ctr and kname in r["Kernel_Name"]] if ppath else []
+            vals[ctr] = sum(v) / len(v) if v else None
+        avg_ns = float(row["AverageNs"])
+        hbm_bytes = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 if vals["FETCH_SIZE"] is not None and vals["WRITE_SIZE"] is not None else None
+        side[cfg] = {"kernel": kernel_short(row["Name"])[:60], "calls": int(row["Calls"]), "avg_ns": avg_ns, "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"]),
+                     "algorithmic_bytes_per_launch": alg, "achieved_gb_s": round(alg / avg_ns, 1), "frac_of_8tb_s": round(alg / avg_ns / 8000, 4),
+                     "hbm_bytes_per_launch": hbm_bytes, "traffic_over_algorithmic": round(hbm_bytes / alg, 4) if hbm_bytes else None, "what": what}
+        if not lines[-1] == "":
+            lines.append("")
+        lines += [f"## {cfg}: {what}", "", f"`{kernel_short(row['Name'])[:100]}`: {row['Calls']} launches alone at full size (tools/run_cfg35.py {cfg}), avg {avg_ns/1e3:.1f} us "
+                  f"(min {float(row['MinNs'])/1e3:.1f}, max {float(row['MaxNs'])/1e3:.1f}) -> {alg/avg_ns:.1f} GB/s on algorithmic bytes = {alg/avg_ns/80:.1f} % of 8 TB/s; "
+                  + (f"HBM traffic (2*FETCH_SIZE + WRITE_SIZE) * 1024 = {hbm_bytes:.4g} B per launch = {hbm_bytes/alg:.4f} x algorithmic" if hbm_bytes else "no PMC pass"), ""]
+    # the raw CSVs the numbers above come from, tracked under profiles/<tag>_rocprof/
+    dst = os.path.join(root, "profiles", f"{tag}_rocprof")
+    os.makedirs(dst, exist_ok=True)
+    copies = [("trace/**/trace_kernel_stats.csv", "kernel_stats.csv"), ("trace_full/**/trace_kernel_stats.csv", "kernel_stats_full_run.csv"),
+              ("pmc_fetch/**/pmc_counter_collection.csv", "pmc_fetch.csv"), ("pmc_write/**/pmc_counter_collection.csv", "pmc_write.csv")]
+    for cfg in CFG:
+        copies += [(f"{cfg}_trace/**/trace_kernel_stats.csv", f"kernel_stats_{cfg}.csv"), (f"{cfg}_pmc_fetch/**/pmc_counter_collection.csv", f"pmc_fetch_{cfg}.csv"),
+                   (f"{cfg}_pmc_write/**/pmc_counter_collection.csv", f"pmc_write_{cfg}.csv")]
+    for pat, name in copies:
+        hit = glob.glob(os.path.join(src, pat), recursive=True)
+        if hit:
+            shutil.copy(hit[0], os.path.join(dst, name))
     os.makedirs(os.path.dirname(out_md), exist_ok=True)
     open(out_md, "w").write("\n".join(lines) + "\n")
     try:
@@ -77,7 +117,7 @@ def main():
         commit = None
     json.dump({"tag": tag, "commit": commit, "date": datetime.date.today().isoformat(), "csrc_sha16": csrc_sha16(root),
                "encode_bytes_per_launch": enc, "decode_bytes_per_launch": dec,
-               "encode_avg_ns": enc_us, "decode_avg_ns": dec_us,
+               "encode_avg_ns": enc_us, "decode_avg_ns": dec_us, **side,
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts half of a coalesced stream)"},
               open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1)
     print(open(out_md).read())
