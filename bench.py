@@ -1026,13 +1026,18 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
     backs[0].zero_()
     ms_e = timed_sustained(torch, stream, lambda i: ctx.encode_batch_dev(seqs[0], roff, rwo, rcount, rtotal, wsets[i & 1]))
     ms_d = timed_sustained(torch, stream, lambda i: ctx.decode_batch_dev(wsets[i & 1], rwo, roff, rcount, rtotal, bsets[i & 1]))
-    extra["reads_batch_tables"] = batch_block(ms_e, ms_d, "the same batch through encode_batch_dev / decode_batch_dev (offset tables only, nothing kept between calls: every call runs plan_emit_kernel + the plan kernel)",
-                                              timing="sustained", roundtrip_ok=bool(torch.equal(seqs[0][:rb], backs[0][:rb])),
-                                              tables_bytes_per_launch=16 * (rcount + 1),
-                                              encode_gb_s_with_tables=round((alg + 16 * (rcount + 1)) / (ms_e * 1e-3) / 1e9, 1),
-                                              decode_gb_s_with_tables=round((alg + 16 * (rcount + 1)) / (ms_d * 1e-3) / 1e9, 1),
-                                              note="encode_gb_s / decode_gb_s count bases + packed words only; every call of this form must also read the two "
-                                                   "8-byte-per-read tables (+8.4 % for 150-base reads), which the *_with_tables figures include")
+    # this form's algorithmic bytes INCLUDE its two tables (every call must read offsets[] and word_offsets[], 16 B per read: +8.4 % for
+    # 150-base reads): the primary fractions count them; the bases + words only figures stay beside them for comparison with (a)
+    alg_t = alg + 16 * (rcount + 1)
+    tb_blk = batch_block(ms_e, ms_d, "the same batch through encode_batch_dev / decode_batch_dev (offset tables only, nothing kept between calls: every call runs plan_emit_kernel + the plan kernel)",
+                         timing="sustained", roundtrip_ok=bool(torch.equal(seqs[0][:rb], backs[0][:rb])), tables_bytes_per_launch=16 * (rcount + 1))
+    tb_blk.update({"encode_gb_s_without_tables": tb_blk["encode_gb_s"], "decode_gb_s_without_tables": tb_blk["decode_gb_s"],
+                   "encode_frac_without_tables": tb_blk["encode_frac"], "decode_frac_without_tables": tb_blk["decode_frac"],
+                   "encode_gb_s": round(alg_t / (ms_e * 1e-3) / 1e9, 1), "decode_gb_s": round(alg_t / (ms_d * 1e-3) / 1e9, 1),
+                   "encode_frac": round(alg_t / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "decode_frac": round(alg_t / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "algorithmic_bytes_per_launch": alg_t,
+                   "note": "algorithmic bytes = bases + packed words + the two 8-byte-per-read tables this form reads on every call; *_without_tables = bases + words only"})
+    extra["reads_batch_tables"] = tb_blk
     ms_fe = timed_sustained(torch, stream, lambda i: ctx.encode_fixed_dev(seqs[0], L, L, rcount, wsets[i & 1]))
     ms_fd = timed_sustained(torch, stream, lambda i: ctx.decode_fixed_dev(wsets[i & 1], L, L, rcount, bsets[i & 1]))
     extra["reads_fixed"] = batch_block(ms_fe, ms_fd, f"{rcount} fixed-length 150-base reads, encode_fixed / decode_fixed (no offsets tables)", timing="sustained")
@@ -1131,7 +1136,7 @@ def stream_probes(ctx, torch, stream, seqs, backs, n):
             "note": "isolated launches, best of a few cache-policy variants per shape",
             "sustained": {"read": sustained(0 | 8, nb), "copy": sustained(1 | 8 | 16, 2 * nb), "fill_nt": sustained(2 | 16, nb), "fill_plain": sustained(2, nb),
                           "note": "bursts of 24 launches over rotating buffers (~24 GB per burst): the two directions of this memory system; a kernel that reads r and "
-                                  "writes w bytes cannot finish before r / read + w / fill (DESIGN section 3)"}}
+                                  "writes w bytes cannot finish before r / read + w / fill (profiles/NARRATIVE_r01_r03.md section 3)"}}
 
 
 def host_path_block(ctx, torch):
@@ -1221,7 +1226,7 @@ def small_call_latency():
                             ("hdist_scalar", 4, (32,))):
         out[name] = {str(s): round(lib.bitnuc_selftime_small(op, s, 200000), 2) for s in sizes}
     out["unit"] = "ns per call (host path, median-free mean over 2e5 calls, C loop inside the library)"
-    out["gpu_launch_path_us"] = "a forced-GPU single call costs ~35 us (copy in, launch, copy out, one wait): DESIGN section 5"
+    out["gpu_launch_path_us"] = "a forced-GPU single call costs ~35 us (copy in, launch, copy out, one wait): profiles/NARRATIVE_r01_r03.md section 1"
     return out
 
 

@@ -129,11 +129,14 @@ static int launch_plan_decode(bitnuc_ctx *c, const unsigned long long *d_base, c
     const int tiles_per_wave = knobs(c).plan_tiles;
     const size_t per_block2 = (size_t)kBatchTile * kBatchWaves * (size_t)tiles_per_wave;
     const unsigned grid2 = grid_for(c, (total_words + per_block2 - 1) / per_block2);
-    if (knobs(c).plan_dec_lines) { // line-owning tiles (batch_device.h): one tile per wave trip, the shipped store policy
-        const size_t per_block1 = (size_t)kBatchTile * kBatchWaves;
-        decode_batch_plan_lines_kernel<2><<<grid_for(c, (total_words + per_block1 - 1) / per_block1), kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out);
-        HIPCHK(hipGetLastError());
-        return BITNUC_OK;
+    if constexpr (kEvidenceBuild) {
+        if (knobs(c).plan_dec_lines) { // line-owning tiles (batch_device.h; lost its A/B, profiles/r04_ab_plan_lines.txt): one tile per wave trip, the shipped store policy
+            const size_t per_block1 = (size_t)kBatchTile * kBatchWaves;
+            if (knobs(c).plan_dec_lines == 2) decode_batch_plan_lines_kernel<2, 16><<<grid_for(c, (total_words + per_block1 - 1) / per_block1), kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out);
+            else decode_batch_plan_lines_kernel<2, 128><<<grid_for(c, (total_words + per_block1 - 1) / per_block1), kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out);
+            HIPCHK(hipGetLastError());
+            return BITNUC_OK;
+        }
     }
 #define PLAN_DEC(POL, U) decode_batch_plan_kernel<POL, U><<<grid2, kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out)
 #define PLAN_DEC_U(POL) do { if (tiles_per_wave == 1) PLAN_DEC(POL, 1); else if (tiles_per_wave == 2) PLAN_DEC(POL, 2); else PLAN_DEC(POL, 4); } while (0)

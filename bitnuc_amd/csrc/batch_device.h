@@ -1227,6 +1227,10 @@ decode_batch_plan_kernel(const unsigned long long *__restrict__ words, const uns
 // Tile t computes covered(t) from the extra words' pad bytes and covered(t-1) from its OWN first kExtraWords pad bytes: the same
 // sums over the same bytes on both sides, so the two waves agree on who writes the shared line without communicating.  Where
 // coverage fails (words of very few bases, or the batch's ends) the run keeps its own end and strip_drain's edge stores, as before.
+// RESULT (round 4, tools/ab_plan_lines.py, profiles/r04_ab_plan_lines.txt): bit-identical output on every shape, and 4-18 % SLOWER
+// (150-base reads: 0.2318 ms against 0.2069 ms).  The ablation's 8 % was the price of issuing the two edge stores, not of sharing the
+// lines; what this form adds -- a second load + pad lookup per tile, a third drain iteration for the up to 137 chunks of the longer
+// run, eight more strip ORs -- costs more than the shared lines did.  Evidence build only; the word-tile kernel ships.
 constexpr unsigned kExtraWords = 8;                 // 8 full words = 256 bases >= 127: enough for every batch whose words average >= 16 bases
 constexpr int kLineStrip = kBatchTile * 2 + 2 * (int)kExtraWords + 8; // dwords: 64 + 8 words, the <= 15-byte lead, strip_or_word's third dword
 
@@ -1286,7 +1290,10 @@ __device__ __forceinline__ void strip_drain_owned(const uint32_t *strip, uint8_t
     }
 }
 
-template <int POLICY>
+// GRAN = 128: whole lines as described; GRAN = 16: the same rule at 16-byte chunk granularity -- a wave completes its last partial
+// CHUNK with the next tile's first bases and leaves its own leading partial chunk to its predecessor: lines are still shared, but the
+// two unaligned edge stores per tile become one aligned store (one or two extra words suffice for reads).
+template <int POLICY, unsigned GRAN>
 __global__ void __launch_bounds__(kBlock)
 decode_batch_plan_lines_kernel(const unsigned long long *__restrict__ words, const unsigned long long *__restrict__ tile_base, const uint8_t *__restrict__ P,
                                unsigned long long total_words, uint8_t *__restrict__ out) {
@@ -1309,8 +1316,8 @@ decode_batch_plan_lines_kernel(const unsigned long long *__restrict__ words, con
         const unsigned long long base0 = tile_base[tile];
         const bool dense = __ballot(n != 0u) == 0ull;
         const uintptr_t lo = op + base0;
-        if (dense && last == 63u && (lo & 127) == 0) {
-            // fast tile (wave-uniform): 2 KiB of whole lines, exactly its own words' bases (both neighbours see a line boundary here)
+        if (dense && last == 63u && (lo & (GRAN - 1)) == 0) {
+            // fast tile (wave-uniform): 2 KiB of whole lines, exactly its own words' bases (both neighbours see a boundary here)
             wave_lds_fence();
             reinterpret_cast<unsigned long long *>(strip)[lane] = word;
             wave_lds_fence();
@@ -1327,7 +1334,7 @@ decode_batch_plan_lines_kernel(const unsigned long long *__restrict__ words, con
         const unsigned first8 = (unsigned)__builtin_amdgcn_readlane((int)(base_rel + nb), (int)(last < kExtraWords - 1 ? last : kExtraWords - 1)); // bases of this tile's first words
         const unsigned next8 = (unsigned)__builtin_amdgcn_readlane((int)(incl >> 16), 63);                                                     // bases of the next tile's first words
         const uintptr_t hi = lo + end_rel;
-        const unsigned gap_lo = (unsigned)(0 - lo) & 127u, gap_hi = (unsigned)(0 - hi) & 127u;
+        const unsigned gap_lo = (unsigned)(0 - lo) & (GRAN - 1), gap_hi = (unsigned)(0 - hi) & (GRAN - 1);
         const bool prev_covers = tile > 0 && first8 >= gap_lo;               // covered(tile - 1), from this tile's own pad bytes
         const bool covers = wb + kBatchTile < total_words && next8 >= gap_hi; // covered(tile), from the extra words' pad bytes
         const uintptr_t own_lo = prev_covers ? lo + gap_lo : lo, own_hi = covers ? hi + gap_hi : hi;

@@ -125,7 +125,26 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
     query_planes(query, k, &ql, &qh);
     const int unroll = knobs(c).scan_unroll, kb = knobs(c).kmer_block;
     const bool al = aligned16(ref) && aligned16(dist);
-    if (knobs(c).scan_impl == 1 && al) { // line-aligned rounds of 1024 windows
+    // the shipped form: line-aligned rounds of 1024 windows, one trip of 4 rounds per wave, two-LUT plane build + scalar halo (GEN 1)
+    if (al && (!kEvidenceBuild || (knobs(c).scan_impl == 1 && unroll == 4 && knobs(c).scan_policy == 3 && kb == kBlock))) {
+        const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+        const unsigned grid = grid_for(c, rounds / ((kBlock / 64) * 4) + 1, kBlock);
+        kmer_scan2_kernel<true, true, true, 4, false, 1><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, 0u, dist, nullptr, nullptr, nullptr, slot);
+        return hipGetLastError();
+    }
+    if constexpr (kEvidenceBuild) if (knobs(c).scan_impl >= 2 && knobs(c).scan_impl <= 5 && al) { // line-aligned rounds, a wave owns consecutive rounds and carries the halo planes (kmer_scan3_kernel)
+        const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+        const int impl = knobs(c).scan_impl;
+        const int C = impl == 2 ? 12 : impl == 3 ? 20 : impl == 4 ? 16 : 32;
+        const unsigned long long waves = (rounds + C - 1) / C;
+        const unsigned long long blocks = waves / (kBlock / 64) + 1; // (+ 1: the tail loop needs a workgroup even when there is no whole round)
+        const unsigned grid = (unsigned)(blocks < 0x7FFFFFFFull ? blocks : 0x7FFFFFFFull);
+#define SCAN3(CC) kmer_scan3_kernel<true, true, 4, CC><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot)
+        if (C == 12) SCAN3(12); else if (C == 20) SCAN3(20); else if (C == 16) SCAN3(16); else SCAN3(32);
+#undef SCAN3
+        return hipGetLastError();
+    }
+    if ((knobs(c).scan_impl == 1 || knobs(c).scan_impl == 6) && al) { // line-aligned rounds of 1024 windows, round 2-3's plane build (GEN 0): evidence build (6 = that form at the shipped policy)
         const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
         const unsigned grid = grid_for(c, rounds / ((kb / 64) * unroll) + 1, kb);
 #define SCAN2(NL, NS, U) kmer_scan2_kernel<true, NL, NS, U, false><<<grid, kb, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, 0u, dist, nullptr, nullptr, nullptr, slot)
@@ -136,7 +155,7 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
     case 2: SCAN2(false, true, U); break;                            \
     default: SCAN2(true, true, U); break;                            \
     }
-        if constexpr (!kEvidenceBuild) { SCAN2(true, true, 4); } // the shipped form: scan_policy 3, scan_unroll 4
+        if constexpr (!kEvidenceBuild) { (void)0; } // (the product returned above)
         else if (unroll == 1) { SCAN2_POLICY(1) } else if (unroll == 2) { SCAN2_POLICY(2) } else { SCAN2_POLICY(4) }
 #undef SCAN2_POLICY
 #undef SCAN2
@@ -295,7 +314,7 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
     const unsigned long long want = rounds / ((kBlock / 64) * 4) + 1, cap = (unsigned long long)c->num_cu * 8;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     unsigned long long *res = reinterpret_cast<unsigned long long *>(d_count);
-    if (aligned16(d_ref)) kmer_scan2_kernel<true, true, false, 4, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
+    if (aligned16(d_ref)) kmer_scan2_kernel<true, true, false, 4, true, 1><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
     else kmer_scan2_kernel<false, false, false, 1, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;

@@ -186,6 +186,39 @@ __device__ __forceinline__ void planes8(uint32_t x0, uint32_t x1, uint32_t &bad,
     h8x2 = __builtin_amdgcn_udot4(d1 & 0x02020202u, 0x80402010u, __builtin_amdgcn_udot4(d0 & 0x02020202u, 0x08040201u, 0u, false), false);
 }
 
+__device__ __forceinline__ void planes8_2lut(uint32_t x0, uint32_t x1, uint32_t &bad, uint32_t &l8, uint32_t &h8) {
+    const uint32_t s0 = x0 & 0x07070707u, s1 = x1 & 0x07070707u; // A=1 C=3 T=4 G=7, case bit ignored
+    // low code bit | the bits every base shares (0x40; T: 0x50); 0x04 for the four indices no base has
+    const uint32_t tl0 = __builtin_amdgcn_perm(0x40040451u, 0x41044004u, s0), tl1 = __builtin_amdgcn_perm(0x40040451u, 0x41044004u, s1);
+    // high code bit alone (G, T)
+    const uint32_t h0 = __builtin_amdgcn_perm(0x01000001u, 0x00000000u, s0), h1 = __builtin_amdgcn_perm(0x01000001u, 0x00000000u, s1);
+    const uint32_t d0 = tl0 ^ (x0 & 0xD8D8D8D8u), d1 = tl1 ^ (x1 & 0xD8D8D8D8u); // == the low code bit (0 / 1) iff the byte is in ACGTacgt
+    bad |= d0 | d1;
+    l8 = __builtin_amdgcn_udot4(d1, 0x80402010u, __builtin_amdgcn_udot4(d0, 0x08040201u, 0u, false), false);
+    h8 = __builtin_amdgcn_udot4(h1, 0x80402010u, __builtin_amdgcn_udot4(h0, 0x08040201u, 0u, false), false);
+}
+__device__ __forceinline__ uint32_t planes16_2lut(const u32x4 &v, uint32_t &bad) { // low half: L plane, high half: H plane (16 bases)
+    uint32_t la, lb, ha, hb;
+    planes8_2lut(v.x, v.y, bad, la, ha);
+    planes8_2lut(v.z, v.w, bad, lb, hb);
+    return (la | (lb << 8)) | ((ha | (hb << 8)) << 16);
+}
+
+// The same 16-base planes word from four WAVE-UNIFORM dwords, on the scalar unit: the code of a byte is ((b >> 1) ^ (b >> 2)) & 3
+// (device_prims.h code_of; no validity here: halo bytes are validated by the round that owns them), and a multiply gathers bit 0 of the
+// four bytes into the top nibble (the partial products land on distinct bits, nothing carries).
+__device__ __forceinline__ uint32_t planes16_uniform(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+    uint32_t L = 0, H = 0;
+    const uint32_t x[4] = {x0, x1, x2, x3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t c = (x[i] >> 1) ^ (x[i] >> 2);
+        L |= (((c & 0x01010101u) * 0x10204080u) >> 28) << (4 * i);
+        H |= ((((c >> 1) & 0x01010101u) * 0x10204080u) >> 28) << (4 * i);
+    }
+    return L | (H << 16);
+}
+
 template <bool ALIGNED, bool NTLD, bool NTST, int UNROLL>
 __global__ void __launch_bounds__(kBlock)
 kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query,
@@ -272,7 +305,11 @@ kmer_scan_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned
 // COUNT: SURVEY 8(d) cfg 5's optional fused output -- only the number of windows with d <= tau leaves the chip
 // (1 B read per window instead of 2 B moved): per window a compare-and-add instead of the byte pack, one u64 atomic per
 // workgroup, published by the last workgroup (single launch, accumulator zero between launches, as hdist_kernel).
-template <bool ALIGNED, bool NTLD, bool NTST, int UNROLL, bool COUNT>
+// GEN = 1 (round 4): the same tiling with fewer vector instructions -- the kernel is VALU-issue bound.  (a) planes16_2lut
+// instead of planes8: no v_and pair per dword (a second v_perm LUT yields the high code bit as a byte of its own).  (b) The halo of the
+// trip's last round is 32 bytes at a wave-uniform address: its planes are computed on the SCALAR unit (SWAR code formula + a multiply
+// gather per dword) instead of by a fifth whole-wave plane build of which two lanes were used.
+template <bool ALIGNED, bool NTLD, bool NTST, int UNROLL, bool COUNT, int GEN = 0>
 __global__ void __launch_bounds__(kBlock)
 kmer_scan2_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query,
                   uint32_t ql, uint32_t qh, unsigned tau, uint8_t *__restrict__ dist, unsigned long long *__restrict__ result,
@@ -296,27 +333,43 @@ kmer_scan2_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigne
             v[u] = load_group<NTLD, ALIGNED>(ref + (r << 10) + 16 * lane);
         }
         u32x4 hv = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
-        if (lane < 2) hv = load_group<false, ALIGNED>(ref + ((r0 + m) << 10) + 16 * lane); // the halo of the trip's last round
+        uint32_t hs0 = 0, hs1 = 0; // GEN 1: the halo's planes, wave-uniform
+        if constexpr (GEN == 0) {
+            if (lane < 2) hv = load_group<false, ALIGNED>(ref + ((r0 + m) << 10) + 16 * lane); // the halo of the trip's last round
+        } else {
+            static_assert(GEN == 0 || ALIGNED, "the scalar halo reads dwords");
+            const uint32_t *hp = reinterpret_cast<const uint32_t *>(ref + ((r0 + m) << 10));
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hp[i]);
+            hs0 = planes16_uniform(w[0], w[1], w[2], w[3]);
+            hs1 = planes16_uniform(w[4], w[5], w[6], w[7]);
+        }
         uint32_t pl[UNROLL + 1];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            uint32_t bad = 0, la, lb, ha, hb;
-            planes8(v[u].x, v[u].y, bad, la, ha);
-            planes8(v[u].z, v[u].w, bad, lb, hb);
-            pl[u] = (la | (lb << 8)) | ((ha | (hb << 8)) << 15);
+            uint32_t bad = 0;
+            if constexpr (GEN == 0) {
+                uint32_t la, lb, ha, hb;
+                planes8(v[u].x, v[u].y, bad, la, ha);
+                planes8(v[u].z, v[u].w, bad, lb, hb);
+                pl[u] = (la | (lb << 8)) | ((ha | (hb << 8)) << 15);
+            } else pl[u] = planes16_2lut(v[u], bad);
             if (__builtin_expect(residue_is_bad(bad) && (unsigned)u < m, 0)) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
         }
-        {
+        if constexpr (GEN == 0) {
             uint32_t bad = 0, la, lb, ha, hb; // halo bytes are validated by the round (or tail) that owns them
             planes8(hv.x, hv.y, bad, la, ha);
             planes8(hv.z, hv.w, bad, lb, hb);
             pl[UNROLL] = (la | (lb << 8)) | ((ha | (hb << 8)) << 15);
-        }
+        } else pl[UNROLL] = 0;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if ((unsigned)u >= m) break; // wave-uniform
-            const uint32_t nx = (unsigned)(u + 1) < m ? pl[u + 1] : pl[UNROLL]; // planes of the next 1 KiB (wave-uniform choice)
-            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)nx, 0), h1 = (uint32_t)__builtin_amdgcn_readlane((int)nx, 1);
+            const bool inner = (unsigned)(u + 1) < m; // the next KiB is one of this trip's rounds (wave-uniform)
+            const uint32_t nx = inner ? pl[u + 1] : pl[UNROLL];
+            uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)nx, 0), h1 = (uint32_t)__builtin_amdgcn_readlane((int)nx, 1);
+            if constexpr (GEN != 0) { h0 = inner ? h0 : hs0; h1 = inner ? h1 : hs1; }
             // lane 63 of a wave_shl is 0 (bound_ctrl), so the halo goes in with one v_and_or.  NOT `lane == 63 ? h : shl(x)`: hipcc turns
             // that select into a branch and runs the DPP move with lane 63 masked off, and a DPP read from a disabled lane returns 0.
             const uint32_t n1 = wave_shl1(pl[u]) | (h0 & m63);
@@ -375,6 +428,108 @@ kmer_scan2_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigne
             if (s) add_performed(total, s);
             if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// scan, round 4: fewer vector instructions per window (the kernel is VALU-issue bound, not HBM-bound)
+// ---------------------------------------------------------------------------------
+// kmer_scan2_kernel spends 10.2 VALU instructions per window (profiles/r02_scan_inner_loop_isa.txt): 7 in the window core (two
+// v_alignbit, two v_xor, v_bitop3, v_bcnt, v_lshl_or) and 3.2 in building the two bit-planes.  Under a continuous queue the chip's
+// power management lowers the clock of exactly such a kernel (profiles/r04_launch_series.txt: 312 us for the first launches after
+// idle, up to 480 us in the dip that follows, 330 us settled), so every instruction less is time.  Two savings, same tiling:
+//   * planes without the two v_and per dword: a second 8-entry v_perm LUT yields the HIGH code bit as a byte of its own (0 / 1), the
+//     first LUT's byte keeps only the LOW code bit next to the validity residue, so both v_dot4 gathers take their operand as it is;
+//   * a wave owns C CONSECUTIVE rounds and carries the planes of the round after its trip into the next trip (they are that trip's
+//     first round): one plane build per round + one per C rounds for the chunk's last halo, instead of five builds per four rounds.
+template <bool NTLD, bool NTST, int U, int C>
+__global__ void __launch_bounds__(kBlock)
+kmer_scan3_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, uint32_t ql, uint32_t qh,
+                  uint8_t *__restrict__ dist, unsigned long long *__restrict__ slot) {
+    static_assert(C % U == 0, "a chunk is whole trips");
+    const unsigned long long nwin = n - k + 1;                        // host guarantees 1 <= k <= 32, n >= k
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0; // round r reads bytes [1024 r, 1024 r + 1056)
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
+    const uint32_t km = k == 32 ? ~0u : ((1u << k) - 1u);
+    const uint32_t m63 = lane == 63 ? ~0u : 0u;
+    const u32x4 kAs = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+
+    const unsigned long long r_begin = wave * C;
+    if (r_begin < rounds) { // wave-uniform
+        const unsigned long long r_end = r_begin + C < rounds ? r_begin + C : rounds;
+        uint32_t cur = 0;
+        const u32x4 vfirst = load_group<NTLD, true>(ref + (r_begin << 10) + 16 * lane); // in flight together with the first trip's loads
+        bool first = true;
+        for (unsigned long long r0 = r_begin; r0 < r_end; r0 += U) {
+            const unsigned m = r_end - r0 < (unsigned long long)U ? (unsigned)(r_end - r0) : (unsigned)U; // rounds of this trip (wave-uniform)
+            // the rounds AFTER each of the trip's rounds: r0 + 1 .. r0 + m.  Inside the chunk they are whole KiB loads (and the next
+            // round to compute); the one at the chunk's end only supplies the 30-base halo: two lanes load, the rest hold 'A's.
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u] = kAs;
+                const unsigned long long ru = r0 + 1 + u;
+                if ((unsigned)u < m && (ru < r_end || lane < 2)) v[u] = ru < r_end ? load_group<NTLD, true>(ref + (ru << 10) + 16 * lane) : load_group<false, true>(ref + (ru << 10) + 16 * lane);
+            }
+            if (first) { // wave-uniform
+                first = false;
+                uint32_t bad = 0;
+                cur = planes16_2lut(vfirst, bad);
+                if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(ref, (r_begin << 10) + 16 * lane, 16, slot);
+            }
+            uint32_t nx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint32_t bad = 0;
+                nx[u] = planes16_2lut(v[u], bad);
+                // only the rounds this wave owns are validated here (a halo's bytes belong to the next chunk's wave or to the tail)
+                if (__builtin_expect(residue_is_bad(bad) && (unsigned)u < m && r0 + 1 + u < r_end, 0)) rescan_bytes(ref, ((r0 + 1 + u) << 10) + 16 * lane, 16, slot);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if ((unsigned)u >= m) break; // wave-uniform
+                const uint32_t pl = u == 0 ? cur : nx[u - 1], nxt = nx[u];
+                const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0), h1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt, 1);
+                const uint32_t n1 = wave_shl1(pl) | (h0 & m63); // (lane 63 of a wave_shl is 0: see kmer_scan2_kernel)
+                const uint32_t n2 = wave_shl1(n1) | (h1 & m63);
+                const uint32_t Llo = __builtin_amdgcn_perm(n1, pl, 0x05040100u);
+                const uint32_t Hlo = __builtin_amdgcn_perm(n1, pl, 0x07060302u);
+                const uint32_t Lhi = n2 & 0xFFFFu, Hhi = n2 >> 16;
+                uint32_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int j = 4 * q + b;
+                        const uint32_t l = j ? __builtin_amdgcn_alignbit(Lhi, Llo, j) : Llo;
+                        const uint32_t h = j ? __builtin_amdgcn_alignbit(Hhi, Hlo, j) : Hlo;
+                        acc |= (uint32_t)__builtin_popcount(((l ^ ql) | (h ^ qh)) & km) << (8 * b);
+                    }
+                    o[q] = acc;
+                }
+                const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                store_group<NTST, true>(dist + ((r0 + u) << 10) + 16 * lane, ov);
+            }
+            cur = nx[m - 1 < (unsigned)U ? m - 1 : 0]; // the planes of round r0 + m: the next trip's first round
+        }
+    }
+
+    // tail: one window per thread, byte loads
+    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (rounds << 10) + gt; i < nwin; i += nthreads) {
+        unsigned long long w = 0;
+        bool flagged = false;
+        for (unsigned b = 0; b < k; ++b) {
+            const uint32_t byte = ref[i + b];
+            if (!valid_base(byte) && !flagged) { latch_bad(slot, i + b, byte); flagged = true; }
+            w |= (unsigned long long)code_of(byte) << (2 * b);
+        }
+        const unsigned long long x = (w ^ query) & kmask;
+        dist[i] = (uint8_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);
     }
 }
 

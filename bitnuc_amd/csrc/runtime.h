@@ -45,7 +45,8 @@ struct SweepKnobs {
     int kmer_block = 256;        // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;        // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;         // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
-    int scan_impl = 1;           // 1 = line-aligned rounds of 1024 windows (kmer_scan2_kernel), 0 = rounds of 992 windows (kmer_scan_kernel)
+    int scan_impl = 1;           // 1 = line-aligned rounds of 1024 windows, two-LUT planes + scalar halo (kmer_scan2_kernel GEN 1: ships), 6 = the same with rounds 2-3's plane build (GEN 0),
+                                 // 0 = rounds of 992 windows (kmer_scan_kernel), 2 / 3 / 4 / 5 = kmer_scan3_kernel (a wave owns 12 / 20 / 16 / 32 consecutive rounds: slower, profiles/r04_ab_scan3.txt)
     int hdist_tiled = 0;         // bulk hdist: 1 = grid-stride at tile granularity (16 KiB of each operand per workgroup trip), 0 = at thread granularity
     int hdist_words_impl = 1;    // many-pair / one-query hdist: 1 = coalesced loads + bpermute for whole 256-word tiles, 0 = four contiguous words per lane
     int fixed_stream = 1;        // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream
@@ -53,7 +54,7 @@ struct SweepKnobs {
     int owner_est = 3;           // block_owner_kernel's first guess: 0 = 128-bit division, 1 = double, 2 = exact 0.64 fixed-point multiply-high, 3 = 2 or 0 by average sequence length
     int batch_tables_impl = 1;   // table-driven ragged batches: 1 = one asynchronous pass emits the layout plan into context scratch, then the plan kernels; 0 = tile records + O(1) lookup kernels
     int batch_host_plan = 1;     // host-pointer ragged-batch calls build a layout plan (bitnuc_batch_plan) and use the plan kernels (0: the table-driven form)
-    int plan_dec_lines = 1;      // plan decode: 1 = line-owning tiles (decode_batch_plan_lines_kernel), 0 = word tiles with shared edge lines (decode_batch_plan_kernel)
+    int plan_dec_lines = 0;      // plan decode: 0 = word tiles with shared edge lines (decode_batch_plan_kernel: ships), 1 = line-owning, 2 = chunk-owning tiles (decode_batch_plan_lines_kernel: slower, profiles/r04_ab_plan_lines.txt)
     int plan_tiles = 1;          // decode_batch_plan_kernel: consecutive tiles per wave trip (1, 2 or 4)
     int plan_store = 2;          // decode_batch_plan_kernel's whole-chunk store policy: 0 nt, 1 plain, 2 plain on the shared edge lines + nt elsewhere
     int plan_enc_block = 256;    // threads per workgroup of the plan encode (64, 128, 256)

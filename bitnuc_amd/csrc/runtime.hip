@@ -321,7 +321,7 @@ constexpr SweepKey kSweepKeys[] = {
     {"kmer_block", &bitnuc_rt::SweepKnobs::kmer_block, 0, 0, 0, {64, 128, 256}},
     {"dense_unroll", &bitnuc_rt::SweepKnobs::dense_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
     {"scan_unroll", &bitnuc_rt::SweepKnobs::scan_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
-    {"scan_impl", &bitnuc_rt::SweepKnobs::scan_impl, 0, 1, 0, {0, 0, 0}},
+    {"scan_impl", &bitnuc_rt::SweepKnobs::scan_impl, 0, 6, 0, {0, 0, 0}},
     {"hdist_tiled", &bitnuc_rt::SweepKnobs::hdist_tiled, 0, 1, 0, {0, 0, 0}},
     {"hdist_words_impl", &bitnuc_rt::SweepKnobs::hdist_words_impl, 0, 1, 0, {0, 0, 0}},
     {"fixed_stream", &bitnuc_rt::SweepKnobs::fixed_stream, 0, 1, 0, {0, 0, 0}},
@@ -329,7 +329,7 @@ constexpr SweepKey kSweepKeys[] = {
     {"owner_est", &bitnuc_rt::SweepKnobs::owner_est, 0, 3, 0, {0, 0, 0}},
     {"batch_tables_impl", &bitnuc_rt::SweepKnobs::batch_tables_impl, 0, 1, 0, {0, 0, 0}},
     {"batch_host_plan", &bitnuc_rt::SweepKnobs::batch_host_plan, 0, 1, 0, {0, 0, 0}},
-    {"plan_dec_lines", &bitnuc_rt::SweepKnobs::plan_dec_lines, 0, 1, 0, {0, 0, 0}},
+    {"plan_dec_lines", &bitnuc_rt::SweepKnobs::plan_dec_lines, 0, 2, 0, {0, 0, 0}},
     {"plan_tiles", &bitnuc_rt::SweepKnobs::plan_tiles, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
     {"plan_store", &bitnuc_rt::SweepKnobs::plan_store, 0, 2, 0, {0, 0, 0}},
     {"plan_enc_block", &bitnuc_rt::SweepKnobs::plan_enc_block, 0, 0, 0, {64, 128, 256}},

@@ -156,7 +156,7 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     assert all(ctx.set_variant("decode", v) == -2 for v in range(47, 56)) and ctx.get("decode") == 22  # decode_x2_kernel: evidence build
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
-                                 ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 1, (0,)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
+                                 ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 1, (0, 2, 6)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,)),
                                  ("batch_dense", 1, (0,)), ("batch_slide", 1, (0,)), ("batch_host_plan", 1, (0,)), ("fixed_stream", 1, (0,)), ("owner_est", 3, (0, 1, 2)),
                                  ("plan_enc_block", 256, (64, 128)), ("kmer_block", 256, (64, 128)), ("hdist_tiled", 0, (1,)), ("hdist_words_impl", 1, (0,)),
@@ -490,15 +490,21 @@ def test_kmer_batch_errors(ctx, oracle):
     assert np.array_equal(ctx.as_2bit_batch(b"", 0, 1, 5), np.zeros(5, np.uint64))
 
 
-@pytest.mark.parametrize("impl", [1, 0], ids=["rounds1024", "rounds992"])
+@pytest.mark.parametrize("impl", [1, 6, 0, 2, 3, 4], ids=["rounds1024", "rounds1024-gen0", "rounds992", "chunks12", "chunks20", "chunks16"])
 @pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 32])
 def test_scan_vs_oracle(ctx, sweep_ctx, oracle, k, unroll, impl):
+    if 2 <= impl <= 5 and unroll != 4:
+        pytest.skip("kmer_scan3_kernel has one trip length")
+    if impl == 6 and unroll != 4:
+        pytest.skip("scan_impl 6 is scan_impl 1's earlier plane build at the shipped trip length; the other trip lengths of impl 1 use it already")
     if (impl, unroll) != (1, 4):
         ctx = sweep_ctx  # the product ships only the form in use; the alternatives live in the evidence build
     prev_impl = ctx.set_variant("scan_impl", impl)
     ctx.set_variant("scan_unroll", unroll)
-    for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 1057, 2015, 2016, 2017, 2047, 2048, 2079, 2080, 2081, 4127, 4128, 4129, 5000, 5152, 200003]:
+    # (12 / 16 / 20 rounds per wave: sizes around one and two chunks as well)
+    for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 1057, 2015, 2016, 2017, 2047, 2048, 2079, 2080, 2081, 4127, 4128, 4129, 5000, 5152,
+              12 * 1024 + 31, 12 * 1024 + 32, 12 * 1024 + 33, 16 * 1024 + 31, 16 * 1024 + 32, 16 * 1024 + 33, 17 * 1024 + 32, 20 * 1024 + 32, 20 * 1024 + 33, 24 * 1024 + 33, 32 * 1024 + 31, 32 * 1024 + 32, 32 * 1024 + 33, 33 * 1024 + 40, 64 * 1024 + 32, 65 * 1024 + 100, 200003]:
         s = rand_seq(n)
         q = int(RNG.integers(0, 1 << 62)) | (int(RNG.integers(0, 4)) << 62)
         got = ctx.kmer_hdist_scan(s, k, q)

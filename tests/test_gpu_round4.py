@@ -262,3 +262,38 @@ def test_config5_every_window_of_the_scan_against_the_oracle(ctx, oracle):
         raise AssertionError(f"window {i}: kernel {h_got[i]}, oracle {h_exp[i]} ({len(badblocks)} of {whole // BLK} blocks differ)")
     assert np.array_equal(h_got[whole:], h_exp[whole:])
     assert np.array_equal(h_got, h_exp)  # a 1 GB memcmp is cheap: the block sums above only localise a failure
+
+
+@pytest.mark.parametrize("impl", [2, 3, 5], ids=["chunks12", "chunks20", "chunks32"])
+def test_scan3_first_invalid_byte_and_later_bytes(sweep_ctx, oracle, impl):
+    """kmer_scan3_kernel (a wave owns 12 / 20 / 32 consecutive rounds and carries the halo planes): the first invalid byte wins at round,
+    trip and chunk boundaries and inside the halo positions; a byte after the last window is never examined; the shipped form gives
+    the same answers (hamming/scalar.rs:11-48 over naive.rs:3-20 per window)."""
+    import bitnuc_amd as bn
+    ctx = sweep_ctx
+    rng = np.random.default_rng(77 + impl)
+    alpha = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+    C = {2: 12, 3: 20, 4: 16, 5: 32}[impl]
+    n = (2 * C + 5) * 1024 + 77
+    s = alpha[rng.integers(0, 8, size=n)].copy()
+    k, q = 31, 0x0123456789ABCDEF & ((1 << 62) - 1)
+    prev = ctx.set_variant("scan_impl", impl)
+    try:
+        assert ctx.get("scan_impl") == impl
+        assert np.array_equal(ctx.kmer_hdist_scan(s, k, q), oracle.kmer_hdist_scan(s, k, q))
+        for pos in (0, 15, 16, 1023, 1024, 1025, 1039, 1040, 1055, 1056, 4095, 4096, 4 * 1024 + 31, C * 1024 - 1, C * 1024, C * 1024 + 17, C * 1024 + 31, C * 1024 + 32,
+                    2 * C * 1024 - 1, 2 * C * 1024 + 1, (2 * C + 4) * 1024 + 5, n - k - 1, n - 1):
+            t = s.copy()
+            t[pos] = ord("N")
+            if pos + 9 < n:
+                t[pos + 9] = ord("X")  # a later invalid byte never wins
+            with pytest.raises(bn.NucleotideError) as ei:
+                ctx.kmer_hdist_scan(t, k, q)
+            assert (ei.value.byte, ei.value.index) == (ord("N"), pos), pos
+        for kk in (1, 2, 16, 17, 32):
+            for m in (kk, 1056, 1057, C * 1024 + 31, C * 1024 + 32, C * 1024 + 33, n):
+                if m < kk:
+                    continue
+                assert np.array_equal(ctx.kmer_hdist_scan(s[:m], kk, q), oracle.kmer_hdist_scan(s[:m], kk, q)), (kk, m)
+    finally:
+        ctx.set_variant("scan_impl", prev)

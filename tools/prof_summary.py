@@ -115,7 +115,17 @@ def main():
         commit = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except Exception:  # noqa: BLE001
         commit = None
-    json.dump({"tag": tag, "commit": commit, "date": datetime.date.today().isoformat(), "csrc_sha16": csrc_sha16(root),
+    # the identity of the binary that WAS PROFILED: the bench line of the trace pass carries the hash its library reports for itself;
+    # only when that is missing (older logs) the hash of the sources beside this script, which is right only if they are unchanged
+    sha, sha_src = csrc_sha16(root), "sources on disk when the summary was written"
+    try:
+        import re
+        m = re.search(r'"library_csrc_sha16": "([0-9a-f]{16})"', open(os.path.join(src, "trace.log")).read())
+        if m:
+            sha, sha_src = m.group(1), "bitnuc_version() of the profiled library (bench line in trace.log)"
+    except OSError:
+        pass
+    json.dump({"tag": tag, "commit": commit, "date": datetime.date.today().isoformat(), "csrc_sha16": sha, "csrc_sha16_from": sha_src,
                "encode_bytes_per_launch": enc, "decode_bytes_per_launch": dec,
                "encode_avg_ns": enc_us, "decode_avg_ns": dec_us, **side,
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts half of a coalesced stream)"},
