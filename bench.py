@@ -636,6 +636,8 @@ def run_rank(args, real_stdout, traffic):
         def frac(block):
             return (extra.get(block) or {}).get("roofline", {}).get("frac")
         line["configs"] = {"cfg2_encode": r_enc["frac"], "cfg2_decode": r_dec["frac"], "cfg3_kmer_batch": frac("kmer_batch"), "cfg5_kmer_hdist_scan": frac("kmer_hdist_scan"),
+                           "cfg5_one_queue_of_64_mean": ((extra.get("kmer_hdist_scan") or {}).get("one_queue_of_64") or {}).get("mean_frac"),
+                           "cfg5_one_queue_of_64_last16": ((extra.get("kmer_hdist_scan") or {}).get("one_queue_of_64") or {}).get("last16_frac"),
                            "unit": "fraction of 8 TB/s HBM3E on algorithmic bytes; null = block not run"}
         return line
 
@@ -887,6 +889,19 @@ def timed_sustained(torch, stream, fn, burst=8, rounds=5):
     return statistics.median(ms)
 
 
+def timed_queue(torch, stream, fn, n_launches=64):
+    """Per-launch durations (ms) of n_launches in ONE queue (events between consecutive launches, no host wait): what a VALU-bound
+    kernel does when the queue never drains and the chip's power management has to settle."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
+    fn(0)
+    ev[0].record(stream)
+    for i in range(n_launches):
+        fn(i + 1)
+        ev[i + 1].record(stream)
+    torch.cuda.synchronize()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(n_launches)]
+
+
 def hbm(alg, ms):
     gbs = alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -930,6 +945,12 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
     extra["kmer_hdist_scan"] = {"workload": "BASELINE configs[4]: sliding 31-mer pack + Hamming distance to one query over 10^9 bases",
                                 "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "isolated_ms": round(iso, 4),
                                 "timing": "sustained bursts of 8 launches, two output buffers", "roofline": hbm(2 * (n - k + 1), ms)}
+    # the scan is VALU-issue bound, so its rate follows the clock: one queue of 64 launches shows the dip after the first launches and
+    # the settled rate; the bursts above restart after every host sync and stay near the settled rate
+    qs = timed_queue(torch, stream, lambda i: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, douts[i & 1]))
+    extra["kmer_hdist_scan"]["one_queue_of_64"] = {"mean_ms": round(sum(qs) / len(qs), 4), "first4_ms": round(sum(qs[:4]) / 4, 4), "slowest_ms": round(max(qs), 4),
+                                                   "last16_ms": round(sum(qs[-16:]) / 16, 4), "mean_frac": hbm(2 * (n - k + 1), sum(qs) / len(qs))["frac"],
+                                                   "last16_frac": hbm(2 * (n - k + 1), sum(qs[-16:]) / 16)["frac"]}
     if hasattr(ctx, "kmer_hdist_count_dev"):
         # SURVEY 8d cfg 5's optional fused output: only the COUNT of windows with d <= tau leaves the chip (1 B read per window)
         cnt1 = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -1020,6 +1041,12 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
                                        plan_build_ms=round(min(tb[1:]), 4), roundtrip_ok=bool(torch.equal(seqs[0][:rb], backs[0][:rb])),
                                        note="plan = word offsets + one byte offset per 64-word tile + one pad byte per word, from one pass over the offsets table "
                                             "(plan_build_ms: host-synchronous, includes the word-offsets scan); the same plan serves the later decode")
+    # what the plan kernels actually move: + 1 pad byte per word + 8 bytes per 64-word tile (2.6-2.9 % of a tile's traffic); the
+    # primary fractions above count bases + words only (SURVEY 8d's algorithmic bytes), these two count the plan's bytes too
+    plan_bytes = rtotal + 8 * ((rtotal + 63) // 64)
+    extra["reads_batch"].update({"plan_bytes_per_launch": plan_bytes,
+                                 "encode_frac_with_plan_bytes": round((alg + plan_bytes) / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "decode_frac_with_plan_bytes": round((alg + plan_bytes) / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     plan.close()
     # (b) from the two offset tables alone, nothing kept between calls: every call emits the plan (pad bytes, tile bases) into
     # context scratch with one asynchronous pass over both tables, then runs the plan kernel -- both launches are inside the time

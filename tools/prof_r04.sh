@@ -16,9 +16,9 @@ cd /tmp
 for CFG in cfg3 cfg5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${CFG}_trace" -o trace -- python3 "$ROOT/tools/run_cfg35.py" $CFG > "$OUT/${CFG}_trace.log" 2>&1
   echo "$CFG trace rc=$?"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${CFG}_pmc_fetch" -o pmc -- python3 "$ROOT/tools/run_cfg35.py" $CFG > "$OUT/${CFG}_pmc_fetch.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${CFG}_pmc_fetch" -o pmc -- python3 "$ROOT/tools/run_cfg35.py" $CFG 12 > "$OUT/${CFG}_pmc_fetch.log" 2>&1
   echo "$CFG pmc fetch rc=$?"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${CFG}_pmc_write" -o pmc -- python3 "$ROOT/tools/run_cfg35.py" $CFG > "$OUT/${CFG}_pmc_write.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${CFG}_pmc_write" -o pmc -- python3 "$ROOT/tools/run_cfg35.py" $CFG 12 > "$OUT/${CFG}_pmc_write.log" 2>&1
   echo "$CFG pmc write rc=$?"
 done
 cd "$ROOT"

@@ -88,15 +88,25 @@ def main():
             v = [float(r["Counter_Value"]) for r in csv.DictReader(open(ppath[0])) if r["Counter_Name"] == ctr and kname in r["Kernel_Name"]] if ppath else []
             vals[ctr] = sum(v) / len(v) if v else None
         avg_ns = float(row["AverageNs"])
+        # per-launch series of the queue (the VALU-bound scan runs slower while the chip's power management settles: DESIGN 3.4)
+        series = []
+        kpath = glob.glob(os.path.join(src, cfg + "_trace", "**", "trace_kernel_trace.csv"), recursive=True)
+        if kpath:
+            series = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kpath[0])) if kname in r["Kernel_Name"]]
+        settled = sum(series[-16:]) / 16 if len(series) >= 32 else None
         hbm_bytes = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 if vals["FETCH_SIZE"] is not None and vals["WRITE_SIZE"] is not None else None
         side[cfg] = {"kernel": kernel_short(row["Name"])[:60], "calls": int(row["Calls"]), "avg_ns": avg_ns, "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"]),
                      "algorithmic_bytes_per_launch": alg, "achieved_gb_s": round(alg / avg_ns, 1), "frac_of_8tb_s": round(alg / avg_ns / 8000, 4),
+                     "first4_avg_ns": sum(series[:4]) / 4 if len(series) >= 4 else None, "last16_avg_ns": settled,
+                     "last16_frac_of_8tb_s": round(alg / settled / 8000, 4) if settled else None,
+                     "launch_series_us": [round(x / 1e3, 1) for x in series],
                      "hbm_bytes_per_launch": hbm_bytes, "traffic_over_algorithmic": round(hbm_bytes / alg, 4) if hbm_bytes else None, "what": what}
         if not lines[-1] == "":
             lines.append("")
         lines += [f"## {cfg}: {what}", "", f"`{kernel_short(row['Name'])[:100]}`: {row['Calls']} launches alone at full size (tools/run_cfg35.py {cfg}), avg {avg_ns/1e3:.1f} us "
                   f"(min {float(row['MinNs'])/1e3:.1f}, max {float(row['MaxNs'])/1e3:.1f}) -> {alg/avg_ns:.1f} GB/s on algorithmic bytes = {alg/avg_ns/80:.1f} % of 8 TB/s; "
-                  + (f"HBM traffic (2*FETCH_SIZE + WRITE_SIZE) * 1024 = {hbm_bytes:.4g} B per launch = {hbm_bytes/alg:.4f} x algorithmic" if hbm_bytes else "no PMC pass"), ""]
+                  + (f"HBM traffic (2*FETCH_SIZE + WRITE_SIZE) * 1024 = {hbm_bytes:.4g} B per launch = {hbm_bytes/alg:.4f} x algorithmic" if hbm_bytes else "no PMC pass"),
+                  (f"Queue of {len(series)} launches: first 4 avg {sum(series[:4])/4e3:.1f} us, last 16 avg {settled/1e3:.1f} us = {alg/settled/80:.1f} % of 8 TB/s; series (us): " + " ".join(f"{x/1e3:.0f}" for x in series)) if settled else "", ""]
     # the raw CSVs the numbers above come from, tracked under profiles/<tag>_rocprof/
     dst = os.path.join(root, "profiles", f"{tag}_rocprof")
     os.makedirs(dst, exist_ok=True)

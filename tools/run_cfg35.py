@@ -3,7 +3,10 @@
 not be mixed with small launches of the same kernel):
   cfg3   10^8 dense 31-mers as_2bit -> u64 (kmer_dense_kernel): 3.1 GB read + 0.8 GB written per launch = 39 B per k-mer
   cfg5   sliding 31-mer pack + Hamming distance to one query over 10^9 bases (kmer_scan2_kernel): 1 B read + 1 B written per window
-12 launches each, two output buffers in rotation (the 256 MiB Infinity Cache holds neither the input nor an output).
+N launches in ONE queue (default 24 for cfg3, 96 for cfg5; the PMC passes use 12), two output buffers in rotation (the 256 MiB Infinity
+Cache holds neither the input nor an output).  cfg5's kernel is VALU-issue bound and the chip lowers its clock under it for the
+first ~40 launches of a queue (profiles/r04_launch_series.txt): a long queue makes the trace's AVERAGE the settled rate while its
+first launches still show the transient; HBM traffic per launch does not depend on the clock.
 The library must exist already (tools/prof_r04.sh builds it first): a process under the profiler does not start a compiler."""
 import os
 import sys
@@ -16,7 +19,7 @@ from bitnuc_amd import build
 
 build.ensure_built(build=False)
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
-launches = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+launches = int(sys.argv[2]) if len(sys.argv) > 2 else (24 if which == "cfg3" else 96)
 dev = torch.device("cuda:0")
 ctx = bitnuc_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 SEED, k = 0xB17C0DE, 31
