@@ -126,7 +126,7 @@ def under_profiler():
     starts): such a process must not start a compiler chain -- every exec in it is the exec-after-GPU-init this pool forbids."""
     if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
         return True
-    return any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ)
+    return "ROCPROFILER_LIBRARY_CTOR" in os.environ  # set by rocprofv3 for the application it starts (/opt/rocm/bin/rocprofv3)
 
 
 LAST_ACTION = {}  # library path -> "as shipped" | "rebuilt on this box" (what ensure_built did in this process; bench.py reports it)
