@@ -597,6 +597,53 @@ class Comm:
     __del__ = close
 
 
+class CommGroup:
+    """All ranks of a communicator in ONE thread (bitnuc_comm_init_all[_devices]): n contexts + communicators, driven together by the
+    _all entry points, which issue every rank's part of an exchange inside one RCCL group and synchronise every stream before they
+    return.  The per-rank entry points refuse these communicators (they would wait for peers this thread has not issued yet)."""
+
+    def __init__(self, n_gpus, devices=None, lib_path=None):
+        self._lib = L.load(lib_path)
+        self.n = int(n_gpus)
+        self._ctxs = (C.c_void_p * self.n)()
+        self._comms = (C.c_void_p * self.n)()
+        devs = (C.c_int * self.n)(*devices) if devices is not None else None
+        err = L.BitnucErr()
+        if self._lib.bitnuc_comm_init_all_devices(self.n, devs, self._ctxs, self._comms, C.byref(err)) != L.OK:
+            self.n = 0
+            _raise(err)
+
+    def encode_sharded_allgather(self, d_seq_shards, shard_len, d_alls, n_chunks=0):
+        """d_seq_shards[r]: rank r's shard (shard_len bases, a multiple of 32, on rank r's device); d_alls[r]: rank r's output of
+        n * shard_len / 32 words.  n_chunks = 0: one grouped ncclAllGather; >= 1: the chunked in-place exchange behind the encode.
+        On InvalidBase the error carries the shard-relative index and, in .value, the rank."""
+        seqs = (C.c_void_p * self.n)(*[_dev_ptr(t) for t in d_seq_shards])
+        alls = (C.c_void_p * self.n)(*[_dev_ptr(t) for t in d_alls])
+        err = L.BitnucErr()
+        if n_chunks:
+            st = self._lib.bitnuc_encode_sharded_allgather_overlapped_all(self.n, self._ctxs, self._comms, seqs, int(shard_len), int(n_chunks), alls, C.byref(err))
+        else:
+            st = self._lib.bitnuc_encode_sharded_allgather_all(self.n, self._ctxs, self._comms, seqs, int(shard_len), alls, C.byref(err))
+        if st != L.OK:
+            try:
+                _raise(err)
+            except NucleotideError as e:
+                e.rank = int(err.value) if st == L.INVALID_BASE else None  # whose shard holds the byte
+                raise
+
+    def close(self):
+        for i in range(getattr(self, "n", 0)):
+            if self._comms[i]:
+                self._lib.bitnuc_comm_destroy(self._comms[i])
+                self._comms[i] = None
+            if self._ctxs[i]:
+                self._lib.bitnuc_ctx_destroy(self._ctxs[i])
+                self._ctxs[i] = None
+        self.n = 0
+
+    __del__ = close
+
+
 def peer_link_probe(src_device, dst_devices, nbytes=256 << 20, reps=3, lib_path=None):
     """xGMI link probe: hipMemcpyPeerAsync from src_device to each of dst_devices, one link at a time and all at once.
     Returns {"gb_s_each": [...], "gb_s_all": x}; raises NucleotideError('Unsupported') with fewer than two devices."""

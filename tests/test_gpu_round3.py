@@ -215,6 +215,19 @@ def test_multi_gpu_sharded_allgather_single_process(oracle, world):
     for r in range(world):
         lib.bitnuc_comm_destroy(comms[r])
         lib.bitnuc_ctx_destroy(ctxs[r])
+    # the same through the Python mirror (bn.CommGroup), on the devices in reverse order (rank r on device world - 1 - r)
+    g = bn.CommGroup(world, devices=list(range(world - 1, -1, -1)))
+    shards_r = [shards[r].to(torch.device("cuda", world - 1 - r)) for r in range(world)]
+    alls_r = [torch.zeros(world * n // 32, dtype=torch.int64, device=torch.device("cuda", world - 1 - r)) for r in range(world)]
+    for r in range(world):
+        torch.cuda.synchronize(r)
+    for chunks in (0, 5):
+        g.encode_sharded_allgather(shards_r, n, alls_r, n_chunks=chunks)
+        for r in range(world):
+            assert torch.equal(alls_r[r].to("cuda:0"), ref), (chunks, r)
+            alls_r[r].zero_()
+            torch.cuda.synchronize(world - 1 - r)
+    g.close()
 
 
 def _rank_worker(rank, world, uid_path, n, mode, q):

@@ -297,3 +297,32 @@ def test_scan3_first_invalid_byte_and_later_bytes(sweep_ctx, oracle, impl):
                 assert np.array_equal(ctx.kmer_hdist_scan(s[:m], kk, q), oracle.kmer_hdist_scan(s[:m], kk, q)), (kk, m)
     finally:
         ctx.set_variant("scan_impl", prev)
+
+
+def test_comm_group_python_mirror(oracle):
+    """bn.CommGroup (bitnuc_comm_init_all_devices + the _all entry points) on the one GPU every box has: a one-rank group through the
+    real RCCL, one-shot and chunked, equals the oracle; an invalid byte comes back with its rank; wider groups are exercised against
+    the stand-in RCCL (tests/test_gpu_multirank_mock.py) and, where two or more GPUs exist, in tests/test_gpu_round3.py."""
+    import torch
+    import bitnuc_amd as bn
+    dev = torch.device("cuda:0")
+    g = bn.CommGroup(1, devices=[0])
+    n = 32 * 70_001
+    seq = torch.from_numpy(oracle.nucgen(n, 3)).to(dev)
+    expect = oracle.encode(seq.cpu().numpy())
+    for chunks in (0, 1, 6):
+        out = torch.zeros(n // 32, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        g.encode_sharded_allgather([seq], n, [out], n_chunks=chunks)
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), expect), chunks
+    seq[12345] = ord("N")
+    torch.cuda.synchronize()
+    with pytest.raises(bn.NucleotideError) as ei:
+        g.encode_sharded_allgather([seq], n, [out], n_chunks=4)
+    assert (ei.value.kind, ei.value.byte, ei.value.index, ei.value.rank) == ("InvalidBase", ord("N"), 12345, 0)
+    with pytest.raises(bn.NucleotideError) as ei:
+        g.encode_sharded_allgather([seq], n - 1, [out])
+    assert ei.value.kind == "InvalidLength"
+    g.close()
+    with pytest.raises(bn.BackendError):
+        bn.CommGroup(2, devices=[0, 99])  # no such device: nothing leaks, a backend error comes back
