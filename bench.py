@@ -16,6 +16,12 @@ value = bases pushed through the codec per second, whole job:
 The two kernels of a step are timed live by HIP events on the launch stream, on every 10th timed step (--event-every; on every step
 the three markers cost 2.5 % of the step itself, profiles/r03_ab_event_every.txt); `config.hip_events` in the line says what was done.
 
+What the line carries beside the contract's keys: `roofline` (the step's dominant kernel; `traffic` = HBM bytes per launch from live
+rocprofv3 PMC passes), `cpu_baseline` (oracle/bitnuc_avx2.c on one core: `value` from the tracked portable build, `native_value` from a
+-march=native build made on this host), `parity_vs_oracle` (EVERY word and base the timed step left on rank 0's GPU against the
+oracle's output for the same seeded stream; a mismatch makes the run exit 3), `config.library_csrc_sha16` (the hash the timed
+library reports for its sources) and, as the LAST key, `configs` (the fraction of every BASELINE config measured in this run).
+
 Process model
   python bench.py --gpus N            (no launcher)  the parent touches no GPU: it starts
         `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process,
