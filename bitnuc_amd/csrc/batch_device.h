@@ -12,9 +12,20 @@
 //     (unaligned, 1..32-byte) pieces in LDS only: encode funnels them out of the staged bytes
 //     (or cuts the tile's 2-bit stream), decode ORs its words into a bit strip whose dwords are
 //     the output's aligned 16-byte chunks;
-//   * word -> sequence lookup: a small pre-kernel finds the owner of every tile's first word
-//     (one binary search per tile, all in parallel), then each lane searches the wave's LDS
-//     window of the next offsets (global fallback if a run of empty sequences overflows it).
+//   * word -> sequence lookup: ONE PAD BYTE PER WORD and one base offset per 64-word tile (the layout plan: bitnuc_batch_plan, or
+//     context scratch re-emitted by plan_emit_kernel for the table-driven entry points); a wave scan of the pad bytes gives every
+//     lane its first base.  No search anywhere.
+//
+// WHAT SHIPS (the product library instantiates only these):
+//   word_offsets_block_sums / _scan_sums / _finish      bitnuc_batch_word_offsets_dev (three-launch exclusive scan)
+//   plan_emit_kernel                                     the layout plan from the offsets table(s), one pass
+//   encode_batch_plan_kernel<1>, decode_batch_plan_kernel<2, 1>     ragged batches (plan and table-driven entry points)
+//   encode_fixed_kernel, decode_fixed_tile_kernel<2>     fixed-length reads (the two lookups are arithmetic)
+// EVIDENCE BUILD ONLY (-DBITNUC_SWEEP_VARIANTS; formulations that lost their A/B, kept so that a result can be re-measured --
+// profiles/NARRATIVE_r01_r03.md 3.5, profiles/README.md): block_owner_kernel + encode_batch2_kernel / decode_batch2_kernel
+// (round 2: tile records by a search pre-kernel, O(1) pad-scatter lookup), decode_batch_kernel and decode_fixed_kernel /
+// decode_fixed_strip_kernel (round 1-2 decode bodies), the U = 2 / 4 and ABL / POLICY instantiations of the plan kernels,
+// decode_batch_plan_lines_kernel (round 4: line- / chunk-owning tiles).
 #pragma once
 #include "device_prims.h"
 

@@ -5,6 +5,16 @@
 //
 // Values follow src/utils/packing/naive.rs:8-18 (pack) and
 // src/utils/functions/hamming/scalar.rs:22-47 (distance of two packed words).
+//
+// WHAT SHIPS (the product library instantiates only these):
+//   kmer_dense_kernel<nt, nt, XCD, 1>                      stride == k batches (config 3)
+//   kmer_batch_kernel<STAGED>                              any other stride, leftovers, unaligned pointers
+//   kmer_slide2_kernel<nt, 4>, kmer_slide_kernel<S>, kmer_slide_any_kernel     every window / small strides -> u64
+//   kmer_scan2_kernel<aligned, nt, nt, 4, COUNT, GEN 1>    config 5 and its fused d <= tau count; kmer_scan_kernel<unaligned> for unaligned pointers
+//   hdist_kernel, nucgen_kernel
+// EVIDENCE BUILD ONLY (-DBITNUC_SWEEP_VARIANTS): kmer_scan_kernel's aligned policies (rounds of 992 windows), kmer_scan2_kernel GEN 0 and
+// its other policies / trip lengths, kmer_scan3_kernel (round 4: a wave owns consecutive rounds), kmer_slide_kernel<1> with rounds per
+// trip, the other dense unrolls / policies -- profiles/NARRATIVE_r01_r03.md 3.3-3.4, profiles/README.md.
 #pragma once
 #include "device_prims.h"
 
