@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--bases", type=int, default=10**9, help="bases per GPU per step (BASELINE configs[1]: 1e9)")
     ap.add_argument("--event-every", type=int, default=10, help="record the per-kernel HIP events on every k-th timed step (1 = every step, the method of rounds 1-2: three event records per step cost 2.5 %% of the step, profiles/r03_ab_event_every.txt); never fewer than 4 sampled steps")
+    ap.add_argument("--separate-allocations", action="store_true", help="allocate the rotating buffers one by one (rounds 1-3) instead of carving them from one allocation (profiles/r04_ab_arena.txt: separate allocations vary by +-4 %% per buffer with where the allocator puts them)")
     ap.add_argument("--rotate", type=int, default=3, help="buffer sets rotated so the 256 MiB Infinity Cache cannot serve a step (>= 2)")
     ap.add_argument("--evidence-build", action="store_true", help="load libbitnuc_hip_sweep.so (every kernel variant) instead of the product library: for --enc-variant / --dec-variant studies only")
     ap.add_argument("--enc-variant", type=int, default=-1)
@@ -209,6 +210,31 @@ def stored_traffic():
             "encode_kernel": round(t["encode_bytes_per_launch"]), "decode_kernel": round(t["decode_bytes_per_launch"])}
 
 
+def carve_buffers(torch, dev, n, nw, R, separate):
+    """The R rotating buffer sets (ASCII in, packed words, ASCII out).  Default: ONE allocation, every buffer at a 2 MiB boundary --
+    how a resident pipeline lays its buffers out, and what makes the codec's per-launch time independent of where an allocator
+    happens to put each buffer (tools/ab_placement.py, tools/ab_arena.py, profiles/r04_ab_arena.txt: inside one allocation the
+    kernels do not care where their buffers sit; nine separate allocations vary by +-4 % per buffer, 1 % on the step).  Returns
+    torch tensors (views of the arena) so that everything downstream is unchanged."""
+    if separate:
+        return ([torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)], [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)],
+                [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)], None)
+    A = 2 << 20
+
+    def up(x):
+        return (x + A - 1) // A * A
+    arena = torch.empty(R * (2 * up(n) + up(8 * nw)) + A, dtype=torch.uint8, device=dev)
+    off = up(arena.data_ptr()) - arena.data_ptr()
+    seqs, words, backs = [], [], []
+    for _ in range(R):
+        seqs.append(arena[off:off + n]); off += up(n)
+    for _ in range(R):
+        words.append(arena[off:off + 8 * nw].view(torch.int64)); off += up(8 * nw)
+    for _ in range(R):
+        backs.append(arena[off:off + n]); off += up(n)
+    return seqs, words, backs, arena
+
+
 def traffic_child(args):
     """The workload profiled by measure_traffic_live: the same two launches as a step, cache-cold rotation."""
     import torch
@@ -218,9 +244,7 @@ def traffic_child(args):
     stream = torch.cuda.current_stream()
     ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
     R = 3
-    seqs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
-    words = [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)]
-    backs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
+    seqs, words, backs, _arena = carve_buffers(torch, dev, n, nw, R, args.separate_allocations)
     for r in range(R):
         ctx.nucgen_dev(seqs[r], n, SEED + r)
     for i in range(2 * R):
@@ -503,9 +527,7 @@ def run_rank(args, real_stdout, traffic):
             ctx.set_variant("decode", args.dec_variant)
         if args.grid_mult >= 0:
             ctx.set_variant("grid_mult", args.grid_mult)
-        seqs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
-        words = [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)]
-        backs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
+        seqs, words, backs, _arena = carve_buffers(torch, dev, n, nw, R, args.separate_allocations)
         for r in range(R):  # rank-disjoint slices of one seeded stream, generated in place on the device
             ctx.nucgen_dev(seqs[r], n, SEED + r, first=rank * n)
         ctx.sync()
@@ -589,6 +611,7 @@ def run_rank(args, real_stdout, traffic):
             "config": {"workload": "BASELINE configs[1]: bulk encode + decode of 10^9 random bases per GPU, device-resident",
                        "bases_per_gpu_per_step": n, "bases_counted_per_step": "encoded + decoded = 2 x bases_per_gpu_per_step x n_gpus",
                        "seed": hex(SEED), "rotating_buffer_sets": R,
+                       "buffers": "separate allocations" if args.separate_allocations else "carved from one allocation at 2 MiB boundaries (profiles/r04_ab_arena.txt)",
                        "hip_events": (f"per-kernel HIP events recorded on every {ev_every}th timed step ({len([e for e in (events or []) if e])} of {args.steps} steps): recording them on every step "
                                       "inserts three markers per step and costs 2.5 % of it") if ev_every > 1 else "per-kernel HIP events recorded on every timed step",
                        "decode_input": "words encoded in the same step (Infinity-Cache warm)" if args.warm_decode else f"words encoded {R - 1} steps earlier (HBM resident, cache cold)",
