@@ -17,7 +17,7 @@ UNITS = ["runtime", "codec", "kmer", "batch", "analysis", "comm"]
 SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
 import glob
 
-DEPS = SOURCES + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]
+DEPS = SOURCES + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "evidence", "*.h")) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]
 CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 
 
@@ -29,11 +29,11 @@ def hipcc_path():
 
 
 def csrc_sha16():
-    """Identity of the sources the library is compiled from (csrc/*.h, csrc/*.hip, include/bitnuc_hip.h): compiled into every
+    """Identity of the sources the library is compiled from (csrc/*.h, csrc/*.hip, csrc/evidence/*.h, include/bitnuc_hip.h): compiled into every
     build as -DBITNUC_CSRC_SHA and returned by bitnuc_version(), so that a binary can be held against the sources beside it."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]:
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "evidence", "*.h"))) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]:
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]

@@ -129,8 +129,9 @@ static int launch_plan_decode(bitnuc_ctx *c, const unsigned long long *d_base, c
     const int tiles_per_wave = knobs(c).plan_tiles;
     const size_t per_block2 = (size_t)kBatchTile * kBatchWaves * (size_t)tiles_per_wave;
     const unsigned grid2 = grid_for(c, (total_words + per_block2 - 1) / per_block2);
-    if constexpr (kEvidenceBuild) {
-        if (knobs(c).plan_dec_lines) { // line-owning tiles (batch_device.h; lost its A/B, profiles/r04_ab_plan_lines.txt): one tile per wave trip, the shipped store policy
+#ifdef BITNUC_SWEEP_VARIANTS
+    {
+        if (knobs(c).plan_dec_lines) { // line-owning tiles (evidence/batch_evidence.h; lost its A/B, profiles/r04_ab_plan_lines.txt): one tile per wave trip, the shipped store policy
             const size_t per_block1 = (size_t)kBatchTile * kBatchWaves;
             if (knobs(c).plan_dec_lines == 2) decode_batch_plan_lines_kernel<2, 16><<<grid_for(c, (total_words + per_block1 - 1) / per_block1), kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out);
             else decode_batch_plan_lines_kernel<2, 128><<<grid_for(c, (total_words + per_block1 - 1) / per_block1), kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out);
@@ -138,6 +139,7 @@ static int launch_plan_decode(bitnuc_ctx *c, const unsigned long long *d_base, c
             return BITNUC_OK;
         }
     }
+#endif
 #define PLAN_DEC(POL, U) decode_batch_plan_kernel<POL, U><<<grid2, kBlock, 0, c->stream>>>(w, d_base, d_P, total_words, d_out)
 #define PLAN_DEC_U(POL) do { if (tiles_per_wave == 1) PLAN_DEC(POL, 1); else if (tiles_per_wave == 2) PLAN_DEC(POL, 2); else PLAN_DEC(POL, 4); } while (0)
     if constexpr (kEvidenceBuild) {
@@ -462,10 +464,10 @@ int bitnuc_decode_fixed_dev(bitnuc_ctx *c, const uint64_t *d_words, size_t read_
     const unsigned long long magic64 = wpr == 1 ? 0ull : ~0ull / wpr + 1;
     if (stride != read_len) decode_fixed_kernel<false><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
     else if (knobs(c).fixed_dec_strip == 2 || !kEvidenceBuild) decode_fixed_tile_kernel<2><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
-    else if constexpr (kEvidenceBuild) {
-        if (knobs(c).fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
-        else decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
-    }
+#ifdef BITNUC_SWEEP_VARIANTS
+    else if (knobs(c).fixed_dec_strip) decode_fixed_strip_kernel<<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, wpr, magic, magic64, total, d_out);
+    else decode_fixed_kernel<true><<<grid, kBlock, 0, c->stream>>>(w, (unsigned)read_len, stride, wpr, magic, magic64, total, d_out);
+#endif
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }

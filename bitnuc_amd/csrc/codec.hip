@@ -115,9 +115,10 @@ hipError_t launch_encode_t(bitnuc_ctx *c, const uint8_t *seq, uint32_t *out32, u
     return hipGetLastError();
 }
 
+constexpr int kQuadFirst = 47, kQuadLast = 62; // encode variants of the evidence build's encode_quad_kernel
+#ifdef BITNUC_SWEEP_VARIANTS
 // encode variants 47..62 (evidence build): encode_quad_kernel (16-byte stores by a register quad transpose, 4 rounds per wave).
 // id - 47: bit 0 = nt loads, bit 1 = nt stores, bit 2 = XCD-contiguous tile order, bit 3 = 256 (not 128) threads per workgroup.
-constexpr int kQuadFirst = 47, kQuadLast = 62;
 template <int BLOCK>
 hipError_t launch_encode_quad_t(bitnuc_ctx *c, int mode, const uint8_t *seq, uint32_t *out32, unsigned long long len, unsigned long long *slot) {
     const unsigned grid = grid_for(c, (len >> 4) / ((unsigned long long)BLOCK * 4) + 1, BLOCK);
@@ -135,6 +136,7 @@ hipError_t launch_encode_quad_t(bitnuc_ctx *c, int mode, const uint8_t *seq, uin
 #undef QUAD
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_encode(bitnuc_ctx *c, const uint8_t *seq, uint64_t *out, unsigned long long len, unsigned long long *slot) {
     uint32_t *o = reinterpret_cast<uint32_t *>(out);
@@ -174,9 +176,10 @@ hipError_t launch_decode_t(bitnuc_ctx *c, const uint32_t *in32, uint8_t *out, un
     return hipGetLastError();
 }
 
+constexpr int kX2First = 47, kX2Last = 54; // decode variants of the evidence build's decode_x2_kernel
+#ifdef BITNUC_SWEEP_VARIANTS
 // decode variants 47..54: decode_x2_kernel (8-byte loads + LDS transpose) for the whole 2 KiB wave tiles, the default
 // decode_kernel for what is left.  id - 47: bit 0 = nt loads, bit 1 = plain (not nt) stores, bit 2 = 2 words in flight per lane.
-constexpr int kX2First = 47, kX2Last = 54;
 template <int UNROLL>
 hipError_t launch_decode_x2_t(bitnuc_ctx *c, int mode, const unsigned long long *w, uint8_t *out, unsigned long long tiles) {
     constexpr int B = 256;
@@ -190,10 +193,12 @@ hipError_t launch_decode_x2_t(bitnuc_ctx *c, int mode, const unsigned long long 
     }
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsigned long long n_bases) {
     const bool in_al = aligned16(ebuf), out_al = aligned16(out);
-    if constexpr (kEvidenceBuild) if (c->dec_variant >= kX2First && c->dec_variant <= kX2Last && out_al) {
+#ifdef BITNUC_SWEEP_VARIANTS
+    if (c->dec_variant >= kX2First && c->dec_variant <= kX2Last && out_al) {
         const unsigned long long tiles = n_bases >> 11; // whole 2 KiB (64-word) wave tiles
         if (tiles) {
             const int mode = c->dec_variant - kX2First;
@@ -205,6 +210,7 @@ hipError_t launch_decode(bitnuc_ctx *c, const uint64_t *ebuf, uint8_t *out, unsi
         if (done == n_bases) return hipSuccess;
         return launch_decode_t<2, 256, false, true, false, false>(c, reinterpret_cast<const uint32_t *>(ebuf) + (done >> 4), out + done, n_bases - done, true);
     }
+#endif
     const uint32_t *i = reinterpret_cast<const uint32_t *>(ebuf);
     int v = c->dec_variant;
     if (v >= kX2First) v = kDefaultDec; // x2 asked for an unaligned output: the default kernel handles any alignment

@@ -132,7 +132,8 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
         kmer_scan2_kernel<true, true, true, 4, false, 1><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, 0u, dist, nullptr, nullptr, nullptr, slot);
         return hipGetLastError();
     }
-    if constexpr (kEvidenceBuild) if (knobs(c).scan_impl >= 2 && knobs(c).scan_impl <= 5 && al) { // line-aligned rounds, a wave owns consecutive rounds and carries the halo planes (kmer_scan3_kernel)
+#ifdef BITNUC_SWEEP_VARIANTS
+    if (knobs(c).scan_impl >= 2 && knobs(c).scan_impl <= 5 && al) { // line-aligned rounds, a wave owns consecutive rounds and carries the halo planes (kmer_scan3_kernel)
         const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
         const int impl = knobs(c).scan_impl;
         const int C = impl == 2 ? 12 : impl == 3 ? 20 : impl == 4 ? 16 : 32;
@@ -144,6 +145,7 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
 #undef SCAN3
         return hipGetLastError();
     }
+#endif
     if ((knobs(c).scan_impl == 1 || knobs(c).scan_impl == 6) && al) { // line-aligned rounds of 1024 windows, round 2-3's plane build (GEN 0): evidence build (6 = that form at the shipped policy)
         const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
         const unsigned grid = grid_for(c, rounds / ((kb / 64) * unroll) + 1, kb);

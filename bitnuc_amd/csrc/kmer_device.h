@@ -12,7 +12,7 @@
 //   kmer_slide2_kernel<nt, 4>, kmer_slide_kernel<S>, kmer_slide_any_kernel     every window / small strides -> u64
 //   kmer_scan2_kernel<aligned, nt, nt, 4, COUNT, GEN 1>    config 5 and its fused d <= tau count; kmer_scan_kernel<unaligned> for unaligned pointers
 //   hdist_kernel, nucgen_kernel
-// EVIDENCE BUILD ONLY (-DBITNUC_SWEEP_VARIANTS): kmer_scan_kernel's aligned policies (rounds of 992 windows), kmer_scan2_kernel GEN 0 and
+// EVIDENCE BUILD ONLY (-DBITNUC_SWEEP_VARIANTS; csrc/evidence/kmer_evidence.h and the other instantiations of the templates below): kmer_scan_kernel's aligned policies (rounds of 992 windows), kmer_scan2_kernel GEN 0 and
 // its other policies / trip lengths, kmer_scan3_kernel (round 4: a wave owns consecutive rounds), kmer_slide_kernel<1> with rounds per
 // trip, the other dense unrolls / policies -- profiles/NARRATIVE_r01_r03.md 3.3-3.4, profiles/README.md.
 #pragma once
@@ -196,6 +196,9 @@ __device__ __forceinline__ void planes8(uint32_t x0, uint32_t x1, uint32_t &bad,
     h8x2 = __builtin_amdgcn_udot4(d1 & 0x02020202u, 0x80402010u, __builtin_amdgcn_udot4(d0 & 0x02020202u, 0x08040201u, 0u, false), false);
 }
 
+// Round 4 (the scan is VALU-issue bound and the chip lowers its clock under such a kernel, DESIGN.md 3.4: every instruction less is time): the
+// plane build without the two v_and per dword -- a second 8-entry v_perm LUT yields the HIGH code bit as a byte of its own (0 / 1), the first
+// LUT's byte keeps only the LOW code bit next to the validity residue, so both v_dot4 gathers take their operand as it is.
 __device__ __forceinline__ void planes8_2lut(uint32_t x0, uint32_t x1, uint32_t &bad, uint32_t &l8, uint32_t &h8) {
     const uint32_t s0 = x0 & 0x07070707u, s1 = x1 & 0x07070707u; // A=1 C=3 T=4 G=7, case bit ignored
     // low code bit | the bits every base shares (0x40; T: 0x50); 0x04 for the four indices no base has
@@ -441,107 +444,8 @@ kmer_scan2_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigne
     }
 }
 
-// ---------------------------------------------------------------------------------
-// scan, round 4: fewer vector instructions per window (the kernel is VALU-issue bound, not HBM-bound)
-// ---------------------------------------------------------------------------------
-// kmer_scan2_kernel spends 10.2 VALU instructions per window (profiles/r02_scan_inner_loop_isa.txt): 7 in the window core (two
-// v_alignbit, two v_xor, v_bitop3, v_bcnt, v_lshl_or) and 3.2 in building the two bit-planes.  Under a continuous queue the chip's
-// power management lowers the clock of exactly such a kernel (profiles/r04_launch_series.txt: 312 us for the first launches after
-// idle, up to 480 us in the dip that follows, 330 us settled), so every instruction less is time.  Two savings, same tiling:
-//   * planes without the two v_and per dword: a second 8-entry v_perm LUT yields the HIGH code bit as a byte of its own (0 / 1), the
-//     first LUT's byte keeps only the LOW code bit next to the validity residue, so both v_dot4 gathers take their operand as it is;
-//   * a wave owns C CONSECUTIVE rounds and carries the planes of the round after its trip into the next trip (they are that trip's
-//     first round): one plane build per round + one per C rounds for the chunk's last halo, instead of five builds per four rounds.
-template <bool NTLD, bool NTST, int U, int C>
-__global__ void __launch_bounds__(kBlock)
-kmer_scan3_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, uint32_t ql, uint32_t qh,
-                  uint8_t *__restrict__ dist, unsigned long long *__restrict__ slot) {
-    static_assert(C % U == 0, "a chunk is whole trips");
-    const unsigned long long nwin = n - k + 1;                        // host guarantees 1 <= k <= 32, n >= k
-    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0; // round r reads bytes [1024 r, 1024 r + 1056)
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
-    const uint32_t km = k == 32 ? ~0u : ((1u << k) - 1u);
-    const uint32_t m63 = lane == 63 ? ~0u : 0u;
-    const u32x4 kAs = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
-
-    const unsigned long long r_begin = wave * C;
-    if (r_begin < rounds) { // wave-uniform
-        const unsigned long long r_end = r_begin + C < rounds ? r_begin + C : rounds;
-        uint32_t cur = 0;
-        const u32x4 vfirst = load_group<NTLD, true>(ref + (r_begin << 10) + 16 * lane); // in flight together with the first trip's loads
-        bool first = true;
-        for (unsigned long long r0 = r_begin; r0 < r_end; r0 += U) {
-            const unsigned m = r_end - r0 < (unsigned long long)U ? (unsigned)(r_end - r0) : (unsigned)U; // rounds of this trip (wave-uniform)
-            // the rounds AFTER each of the trip's rounds: r0 + 1 .. r0 + m.  Inside the chunk they are whole KiB loads (and the next
-            // round to compute); the one at the chunk's end only supplies the 30-base halo: two lanes load, the rest hold 'A's.
-            u32x4 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                v[u] = kAs;
-                const unsigned long long ru = r0 + 1 + u;
-                if ((unsigned)u < m && (ru < r_end || lane < 2)) v[u] = ru < r_end ? load_group<NTLD, true>(ref + (ru << 10) + 16 * lane) : load_group<false, true>(ref + (ru << 10) + 16 * lane);
-            }
-            if (first) { // wave-uniform
-                first = false;
-                uint32_t bad = 0;
-                cur = planes16_2lut(vfirst, bad);
-                if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(ref, (r_begin << 10) + 16 * lane, 16, slot);
-            }
-            uint32_t nx[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                uint32_t bad = 0;
-                nx[u] = planes16_2lut(v[u], bad);
-                // only the rounds this wave owns are validated here (a halo's bytes belong to the next chunk's wave or to the tail)
-                if (__builtin_expect(residue_is_bad(bad) && (unsigned)u < m && r0 + 1 + u < r_end, 0)) rescan_bytes(ref, ((r0 + 1 + u) << 10) + 16 * lane, 16, slot);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if ((unsigned)u >= m) break; // wave-uniform
-                const uint32_t pl = u == 0 ? cur : nx[u - 1], nxt = nx[u];
-                const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0), h1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt, 1);
-                const uint32_t n1 = wave_shl1(pl) | (h0 & m63); // (lane 63 of a wave_shl is 0: see kmer_scan2_kernel)
-                const uint32_t n2 = wave_shl1(n1) | (h1 & m63);
-                const uint32_t Llo = __builtin_amdgcn_perm(n1, pl, 0x05040100u);
-                const uint32_t Hlo = __builtin_amdgcn_perm(n1, pl, 0x07060302u);
-                const uint32_t Lhi = n2 & 0xFFFFu, Hhi = n2 >> 16;
-                uint32_t o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int j = 4 * q + b;
-                        const uint32_t l = j ? __builtin_amdgcn_alignbit(Lhi, Llo, j) : Llo;
-                        const uint32_t h = j ? __builtin_amdgcn_alignbit(Hhi, Hlo, j) : Hlo;
-                        acc |= (uint32_t)__builtin_popcount(((l ^ ql) | (h ^ qh)) & km) << (8 * b);
-                    }
-                    o[q] = acc;
-                }
-                const u32x4 ov = {o[0], o[1], o[2], o[3]};
-                store_group<NTST, true>(dist + ((r0 + u) << 10) + 16 * lane, ov);
-            }
-            cur = nx[m - 1 < (unsigned)U ? m - 1 : 0]; // the planes of round r0 + m: the next trip's first round
-        }
-    }
-
-    // tail: one window per thread, byte loads
-    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i = (rounds << 10) + gt; i < nwin; i += nthreads) {
-        unsigned long long w = 0;
-        bool flagged = false;
-        for (unsigned b = 0; b < k; ++b) {
-            const uint32_t byte = ref[i + b];
-            if (!valid_base(byte) && !flagged) { latch_bad(slot, i + b, byte); flagged = true; }
-            w |= (unsigned long long)code_of(byte) << (2 * b);
-        }
-        const unsigned long long x = (w ^ query) & kmask;
-        dist[i] = (uint8_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);
-    }
-}
+// (round 4's other scan form, kmer_scan3_kernel -- a wave owns C consecutive rounds and carries the halo planes between its trips; fewest
+// instructions, 10-20 % slower, profiles/r04_ab_scan3.txt -- : csrc/evidence/kmer_evidence.h, evidence build only)
 
 // ---------------------------------------------------------------------------------
 // every window of a sequence: as_2bit over seq.windows(k)  (stride == 1, src/lib.rs:170-173)
@@ -823,5 +727,9 @@ hdist_kernel(const unsigned long long *__restrict__ a, const unsigned long long 
         if (draw_last_ticket(ticket)) *result = atomicExch(total, 0u);
     }
 }
+
+#ifdef BITNUC_SWEEP_VARIANTS
+#include "evidence/kmer_evidence.h" // the formulations that lost their A/B: evidence build only
+#endif
 
 } // namespace bitnuc_dev

@@ -6,6 +6,8 @@
 //   analysis.hip  base counts, many-pair hdist, split_packed                                         (analysis_device.h)
 //   comm.hip      RCCL all-gather of the packed words, xGMI link probe
 // Each kernel header is included by exactly one of them; what they share on the device is device_prims.h.
+// csrc/evidence/*.h hold the kernels that lost their A/B: the kernel headers include them only under -DBITNUC_SWEEP_VARIANTS
+// (libbitnuc_hip_sweep.so); the product library never sees them.
 #pragma once
 #include "../../include/bitnuc_hip.h"
 
