@@ -5,6 +5,9 @@
 //   * chunked overlap (SURVEY 8e iii): the shard is encoded piece by piece on the context's stream while a second stream
 //     moves the finished pieces, IN PLACE, with grouped point-to-point ncclSend / ncclRecv -- on MI355X's full mesh of
 //     point-to-point xGMI links that uses all P-1 links of a GPU at once (a ring would be per-link bound).
+// Two ways to hold the ranks: one thread or process per rank (bitnuc_comm_init_rank + the per-rank entry points), or ONE thread
+// for all of them (bitnuc_comm_init_all[_devices] + the _all entry points, which put every rank's part of an exchange into one
+// ncclGroupStart / ncclGroupEnd); the per-rank entry points refuse the second kind of communicator instead of blocking in it.
 // RCCL is bound at run time (dlopen) so that single-GPU users do not need librccl.so.  No kernels here.
 #include "runtime.h"
 

@@ -35,6 +35,13 @@
  *     1024 captured launches over its life (BITNUC_UNSUPPORTED, err.value = 1024 beyond that); replay the
  *     graph on the context's stream, or order it before the sync yourself.  Entry points documented as
  *     synchronous (word offsets, plan build, every host-pointer call, bitnuc_ctx_sync) cannot be captured.
+ *   - The table-driven batch calls (bitnuc_encode_batch_dev / bitnuc_decode_batch_dev) keep their layout plan in context scratch,
+ *     sized by the largest batch seen.  A call that would have to GROW it while the stream is being captured returns
+ *     BITNUC_UNSUPPORTED (err.value = the bytes needed) before anything is touched -- warm up with the largest batch, or use a
+ *     bitnuc_batch_plan; a scratch buffer that a recorded launch was handed stays alive until bitnuc_ctx_destroy (a later,
+ *     larger ordinary call allocates a new one), so replays never write into freed memory.
+ *   - When a sync has two data errors to report -- one kept from an earlier implicit drain (a host-pointer call, or the 2 Mi
+ *     limit above) and one its own drain finds -- it reports the earlier one; the later one is reported by the next sync.
  *
  * Conventions
  *   - plain pointers + sizes, no torch / C++ types in signatures;
@@ -102,7 +109,9 @@ void bitnuc_ctx_destroy(bitnuc_ctx *ctx);
 int bitnuc_ctx_sync(bitnuc_ctx *ctx, bitnuc_err *err);
 /* The context's hipStream_t, for callers that order their own work against it. */
 void *bitnuc_ctx_stream(bitnuc_ctx *ctx);
-/* Library / build identification ("bitnuc_hip <ver> gfx950"). */
+/* Library / build identification: "bitnuc_hip <ver> gfx950 csrc:<16 hex digits>[ sweep]" -- the hex digits are the SHA-256 prefix of the
+ * sources the library was compiled from (csrc/ incl. csrc/evidence/, this header), passed by bitnuc_amd/build.py as -DBITNUC_CSRC_SHA
+ * ("csrc:unknown" for a build without it); " sweep" marks the evidence build (-DBITNUC_SWEEP_VARIANTS). */
 const char *bitnuc_version(void);
 
 /* ---- single-word API (host code, ctx may be NULL; see "Size dispatch" above) ------------------ */

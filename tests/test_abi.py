@@ -85,6 +85,27 @@ def test_a_stale_library_is_refused_and_rebuilt(tmp_path, monkeypatch):
         build.ensure_built(build=False, lib=missing)
 
 
+def test_product_library_holds_no_evidence_kernels():
+    """The kernels that lost their A/B live in bitnuc_amd/csrc/evidence/*.h, which the kernel headers include only under
+    -DBITNUC_SWEEP_VARIANTS: the product library must not contain one of them (the evidence build must contain all of them)."""
+    import glob
+    import subprocess
+    from bitnuc_amd import build
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "bitnuc_amd", "csrc", "evidence", "*.h")):
+        names |= set(re.findall(r"^(\w+_kernel)\(", open(f).read(), flags=re.M))
+    assert {"encode_quad_kernel", "encode_ballot_kernel", "decode_x2_kernel", "encode_batch2_kernel", "decode_batch2_kernel", "block_owner_kernel",
+            "decode_fixed_strip_kernel", "decode_batch_plan_lines_kernel", "kmer_scan3_kernel", "probe_win_shape_kernel"} <= names, names
+    product = subprocess.run(["nm", "-C", build.ensure_built()], capture_output=True, text=True).stdout
+    assert "encode_kernel" in product and "kmer_scan2_kernel" in product
+    leaked = [n for n in names if n + "<" in product or n + "(" in product]
+    assert not leaked, leaked
+    if os.path.exists(build.LIB_SWEEP) and not build.is_stale(build.LIB_SWEEP):
+        sweep = subprocess.run(["nm", "-C", build.LIB_SWEEP], capture_output=True, text=True).stdout
+        missing = [n for n in names if n not in sweep]
+        assert not missing, missing
+
+
 def test_no_oracle_in_product():
     # the product must not route through the oracle or any CPU fallback
     for dirpath, _, files in os.walk(os.path.join(ROOT, "bitnuc_amd")):
