@@ -490,14 +490,14 @@ def test_kmer_batch_errors(ctx, oracle):
     assert np.array_equal(ctx.as_2bit_batch(b"", 0, 1, 5), np.zeros(5, np.uint64))
 
 
-@pytest.mark.parametrize("impl", [1, 6, 0, 2, 3, 4], ids=["rounds1024", "rounds1024-gen0", "rounds992", "chunks12", "chunks20", "chunks16"])
-@pytest.mark.parametrize("unroll", [1, 2, 4])
+# (scan_impl, scan_unroll): 1 = line-aligned rounds of 1024 windows (ships at unroll 4 as GEN 1; other trip lengths use rounds 2-3's plane build),
+# 6 = that plane build at the shipped trip length, 0 = rounds of 992 windows, 2 / 3 / 4 = kmer_scan3_kernel with 12 / 20 / 16 rounds per wave
+SCAN_FORMS = [(1, 4), (1, 2), (1, 1), (6, 4), (0, 4), (0, 2), (0, 1), (2, 4), (3, 4), (4, 4)]
+
+
+@pytest.mark.parametrize("impl,unroll", SCAN_FORMS, ids=[f"impl{i}-unroll{u}" for i, u in SCAN_FORMS])
 @pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 32])
 def test_scan_vs_oracle(ctx, sweep_ctx, oracle, k, unroll, impl):
-    if 2 <= impl <= 5 and unroll != 4:
-        pytest.skip("kmer_scan3_kernel has one trip length")
-    if impl == 6 and unroll != 4:
-        pytest.skip("scan_impl 6 is scan_impl 1's earlier plane build at the shipped trip length; the other trip lengths of impl 1 use it already")
     if (impl, unroll) != (1, 4):
         ctx = sweep_ctx  # the product ships only the form in use; the alternatives live in the evidence build
     prev_impl = ctx.set_variant("scan_impl", impl)
