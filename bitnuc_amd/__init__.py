@@ -7,12 +7,12 @@ Layout
   api.py    host-side mirror of the reference's public API (src/lib.rs:214-220)
   dist.py   one-process-per-GPU sharding helpers (torch.distributed / RCCL)
 """
-from .api import (BackendError, BatchPlan, Comm, CommGroup, Context, NucleotideError, as_2bit, as_2bit_batch, decode,
+from .api import (BackendError, BatchPlan, Comm, CommGroup, Context, NucleotideError, as_2bit, as_2bit_batch, batch_shard_ranges, decode,
                   default_context, encode, encode_alloc, from_2bit, from_2bit_alloc, hdist,
                   hdist_scalar, kmer_hdist_scan, split_packed)
 
 from .sequence import PackedSequence
 
-__all__ = ["PackedSequence", "BatchPlan", "Comm", "CommGroup", "BackendError", "Context", "NucleotideError", "as_2bit", "as_2bit_batch", "decode",
+__all__ = ["PackedSequence", "BatchPlan", "Comm", "CommGroup", "BackendError", "Context", "NucleotideError", "as_2bit", "as_2bit_batch", "batch_shard_ranges", "decode",
            "default_context", "encode", "encode_alloc", "from_2bit", "from_2bit_alloc", "hdist",
            "hdist_scalar", "kmer_hdist_scan", "split_packed"]

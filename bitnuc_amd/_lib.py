@@ -91,6 +91,10 @@ SIGNATURES = {
     "bitnuc_encode_sharded_allgather_overlapped_dev": (C.c_int, [_P, _P, _P, _SZ, C.c_int, _P, _ERR]),
     "bitnuc_encode_sharded_allgather_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, C.POINTER(_P), _ERR]),
     "bitnuc_encode_sharded_allgather_overlapped_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, C.c_int, C.POINTER(_P), _ERR]),
+    "bitnuc_batch_shard_ranges": (C.c_int, [_P, _SZ, C.c_int, _P, _P, _ERR]),
+    "bitnuc_allgatherv_words_dev": (C.c_int, [_P, _P, _P, _P, _ERR]),
+    "bitnuc_allgatherv_words_all": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), _P, C.POINTER(_P), _ERR]),
+    "bitnuc_comm_set_threaded": (C.c_int, [_P, C.c_int]),
     "bitnuc_nucgen_dev": (C.c_int, [_P, _P, _SZ, _U64, _U64, C.c_int, _ERR]),
     "bitnuc_stream_probe_dev": (C.c_int, [_P, C.c_int, _P, _P, _SZ, _ERR]),
     "bitnuc_selftime_small": (C.c_double, [C.c_int, _SZ, _SZ]),

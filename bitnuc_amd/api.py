@@ -72,6 +72,8 @@ def _raise(err):
         raise NucleotideError("InvalidLength", len=int(err.value))
     if st == L.INDEX_OUT_OF_BOUNDS:
         raise NucleotideError("IndexOutOfBounds", index=int(err.index), length=int(err.value))
+    if st == L.INVALID_RANGE:  # decreasing offsets in a ragged batch: err.value = the sequence whose end lies before its start
+        raise NucleotideError("InvalidRange", index=int(err.value))
     if st == L.UNSUPPORTED:
         raise NucleotideError("Unsupported")
     if st == L.BACKEND_ERROR:
@@ -137,8 +139,18 @@ class Context:
         self.close()
 
     # -- tuning --------------------------------------------------------------------
-    def set_variant(self, key, value):
-        return self._lib.bitnuc_ctx_set_variant(self._h, key.encode(), int(value))
+    def set_variant(self, key, value, strict=False):
+        """Previous value, or -2 when this build does not hold `value` (the product refuses every formulation but the shipped one).
+        strict=True raises instead of returning -2 / leaving the knob where it was: an A/B that ignores a refusal times a kernel against
+        itself, so tools/ and the variant tests use require_variant()."""
+        prev = self._lib.bitnuc_ctx_set_variant(self._h, key.encode(), int(value))
+        if strict and int(value) >= 0 and (prev == -2 or self.get(key) != int(value)):
+            raise ValueError(f"bitnuc_ctx_set_variant({key!r}, {value}): refused by this build ({prev}); the knob stays at {self.get(key)}"
+                             + ("" if self.get("sweep_build") == 1 else " -- alternative formulations live in the evidence build (build.ensure_built(sweep=True))"))
+        return prev
+
+    def require_variant(self, key, value):
+        return self.set_variant(key, value, strict=True)
 
     def get(self, key):
         return self._lib.bitnuc_ctx_set_variant(self._h, key.encode(), -1)
@@ -577,6 +589,17 @@ class Comm:
         if self._lib.bitnuc_allgather_words_dev(self._ctx._h, self._h, _dev_ptr(d_local), int(count), _dev_ptr(d_all), C.byref(err)) != L.OK:
             _raise(err)
 
+    def allgatherv_words_dev(self, counts, d_all):
+        """In-place all-gather of UNEQUAL word counts (a ragged batch sharded by whole sequences, dist.batch_shard_ranges): rank r's
+        counts[r] words already sit at d_all + sum(counts[:r]); afterwards every rank holds all of them."""
+        arr = (C.c_size_t * len(counts))(*[int(x) for x in counts])
+        err = L.BitnucErr()
+        if self._lib.bitnuc_allgatherv_words_dev(self._ctx._h, self._h, arr, _dev_ptr(d_all), C.byref(err)) != L.OK:
+            _raise(err)
+
+    def set_threaded(self, threaded=True):
+        return self._lib.bitnuc_comm_set_threaded(self._h, int(bool(threaded)))
+
     def encode_sharded_allgather_dev(self, d_seq_shard, shard_len, d_all):
         err = L.BitnucErr()
         if self._lib.bitnuc_encode_sharded_allgather_dev(self._ctx._h, self._h, _dev_ptr(d_seq_shard), int(shard_len), _dev_ptr(d_all), C.byref(err)) != L.OK:
@@ -631,6 +654,14 @@ class CommGroup:
                 e.rank = int(err.value) if st == L.INVALID_BASE else None  # whose shard holds the byte
                 raise
 
+    def allgatherv_words(self, counts, d_alls):
+        """bitnuc_allgatherv_words_all: every rank's counts[r] words (already at d_alls[r] + sum(counts[:r])) reach every rank's buffer."""
+        arr = (C.c_size_t * self.n)(*[int(x) for x in counts])
+        alls = (C.c_void_p * self.n)(*[_dev_ptr(t) for t in d_alls])
+        err = L.BitnucErr()
+        if self._lib.bitnuc_allgatherv_words_all(self.n, self._ctxs, self._comms, arr, alls, C.byref(err)) != L.OK:
+            _raise(err)
+
     def close(self):
         for i in range(getattr(self, "n", 0)):
             if self._comms[i]:
@@ -642,6 +673,21 @@ class CommGroup:
         self.n = 0
 
     __del__ = close
+
+
+def batch_shard_ranges(offsets, nranks, lib_path=None):
+    """bitnuc_batch_shard_ranges (host arithmetic, no device): the partition of a ragged batch by WHOLE sequences, balanced by word
+    count.  Returns (seq_first[nranks+1], word_first[nranks+1]) as numpy arrays; bitnuc_amd.dist.batch_shard_ranges is the same rule
+    in numpy (tests hold the two against each other)."""
+    lib = L.load(lib_path)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    count = off.size - 1
+    seq_first = np.zeros(nranks + 1, dtype=np.uint64)
+    word_first = np.zeros(nranks + 1, dtype=np.uint64)
+    err = L.BitnucErr()
+    if lib.bitnuc_batch_shard_ranges(_ptr(off), count, int(nranks), _ptr(seq_first), _ptr(word_first), C.byref(err)) != L.OK:
+        _raise(err)
+    return seq_first, word_first
 
 
 def peer_link_probe(src_device, dst_devices, nbytes=256 << 20, reps=3, lib_path=None):

@@ -18,7 +18,9 @@ SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
 import glob
 
 DEPS = SOURCES + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "evidence", "*.h")) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]
-CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+# -amdgpu-mfma-vgpr-form: the matrix-core scan (csrc/scan_mfma_device.h) keeps its accumulator in VGPRs; without it hipcc places it in AGPRs and
+# pays a v_accvgpr_read per result and a v_accvgpr_write per initial value (32 moves per 1024 windows)
+CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def hipcc_path():

@@ -85,6 +85,7 @@ struct bitnuc_comm {
     // for all ranks inside one ncclGroupStart / ncclGroupEnd (the _all entry points).  A per-rank call from that thread would block in
     // its group's end waiting for peers that the same thread has not yet been able to issue: the per-rank entry points refuse it.
     bool single_process = false;
+    bool threaded = false; // bitnuc_comm_set_threaded: the host runs one thread per rank of an init_all communicator after all
     hipStream_t xfer = nullptr;        // the second stream of the chunked overlap (created on first use)
     std::vector<hipEvent_t> piece_done; // piece c encoded (recorded on the context's stream)
     hipEvent_t all_moved = nullptr;     // every piece exchanged (recorded on xfer)
@@ -104,7 +105,7 @@ int comm_overlap_resources(bitnuc_comm *comm, int n_chunks, bitnuc_err *err) {
 }
 
 // see bitnuc_comm::single_process (a communicator of one rank has no peer to wait for)
-bool per_rank_call_would_block(const bitnuc_comm *comm) { return comm->single_process && comm->nranks > 1; }
+bool per_rank_call_would_block(const bitnuc_comm *comm) { return comm->single_process && !comm->threaded && comm->nranks > 1; }
 
 bool gather_by_broadcast() {
     static const bool bcast = [] { const char *e = getenv("BITNUC_GATHER_MODE"); return e && !strcmp(e, "bcast"); }();
@@ -116,7 +117,7 @@ int check_all_args(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uin
     if (n_gpus < 1 || n_gpus > 64 || !ctxs || !comms || !d_seq_shards || !d_alls) return fail(err, BITNUC_UNSUPPORTED);
     for (int i = 0; i < n_gpus; ++i) {
         if (!ctxs[i] || !comms[i]) return fail(err, BITNUC_UNSUPPORTED);
-        if (!comms[i]->single_process || comms[i]->nranks != n_gpus || comms[i]->rank != i || comms[i]->device != ctxs[i]->device) return fail(err, BITNUC_UNSUPPORTED);
+        if (!comms[i]->single_process || comms[i]->threaded || comms[i]->nranks != n_gpus || comms[i]->rank != i || comms[i]->device != ctxs[i]->device) return fail(err, BITNUC_UNSUPPORTED);
     }
     if (shard_len % 32 != 0) return fail(err, BITNUC_INVALID_LENGTH, shard_len);
     if (shard_len)
@@ -218,6 +219,12 @@ void bitnuc_comm_destroy(bitnuc_comm *comm) {
 int bitnuc_comm_nranks(const bitnuc_comm *comm) { return comm ? comm->nranks : 0; }
 int bitnuc_comm_rank(const bitnuc_comm *comm) { return comm ? comm->rank : -1; }
 int bitnuc_comm_single_process(const bitnuc_comm *comm) { return comm ? (int)comm->single_process : -1; }
+int bitnuc_comm_set_threaded(bitnuc_comm *comm, int threaded) {
+    if (!comm) return -1;
+    const int prev = (int)comm->threaded;
+    comm->threaded = threaded != 0;
+    return prev;
+}
 
 int bitnuc_allgather_words_dev(bitnuc_ctx *c, bitnuc_comm *comm, const uint64_t *d_local, size_t count, uint64_t *d_all, bitnuc_err *err) {
     clear_err(err);
@@ -314,7 +321,7 @@ int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_co
     const size_t count = shard_len / 32;
     for (int i = 0; i < n_gpus; ++i) // encode phase: independent, no communication
         if (int st = bitnuc_encode_dev(ctxs[i], d_seq_shards[i], shard_len, d_alls[i] + (size_t)i * count, err)) { (void)sync_all(n_gpus, ctxs, nullptr); return st; }
-    if (int rc = r.GroupStart()) return fail_rccl(err, rc);
+    if (int rc = r.GroupStart()) { (void)sync_all(n_gpus, ctxs, nullptr); return fail_rccl(err, rc); } // the encodes are queued: the caller gets its buffers back synchronised
     int rc = 0;
     for (int i = 0; i < n_gpus && rc == 0; ++i) {
         DeviceGuard g(ctxs[i]->device);
@@ -341,17 +348,11 @@ int bitnuc_encode_sharded_allgather_overlapped_all(int n_gpus, bitnuc_ctx **ctxs
     const bool bcast = gather_by_broadcast();
     const size_t count = shard_len / 32;
     const int P = n_gpus;
-    for (int i = 0; i < P; ++i) {
-        DeviceGuard g(ctxs[i]->device);
-        if (int st = comm_overlap_resources(comms[i], n_chunks, err)) return st;
-        // rank i's transfer stream starts behind what its context's stream already holds (d_alls[i]'s previous readers)
-        HIPCHK(hipEventRecord(comms[i]->all_moved, ctxs[i]->stream));
-        HIPCHK(hipStreamWaitEvent(comms[i]->xfer, comms[i]->all_moved, 0));
-    }
-    // however the loop below ends, every context's stream is made to wait for its transfer stream and is then synchronised, so the
-    // caller owns all buffers again when this returns
+    // however this call ends -- also in the set-up loop below, after earlier ranks' transfer streams were chained -- every context's
+    // stream is made to wait for its transfer stream (where it exists) and is then synchronised, so the caller owns all buffers again
     auto finish = [&](int st_call, bitnuc_err *e_call) {
         for (int i = 0; i < P; ++i) {
+            if (!comms[i]->xfer || !comms[i]->all_moved) continue;
             DeviceGuard g(ctxs[i]->device);
             if (hipEventRecord(comms[i]->all_moved, comms[i]->xfer) == hipSuccess) (void)hipStreamWaitEvent(ctxs[i]->stream, comms[i]->all_moved, 0);
             else (void)hipGetLastError();
@@ -364,6 +365,14 @@ int bitnuc_encode_sharded_allgather_overlapped_all(int n_gpus, bitnuc_ctx **ctxs
     };
     bitnuc_err e;
     memset(&e, 0, sizeof e);
+    for (int i = 0; i < P; ++i) {
+        DeviceGuard g(ctxs[i]->device);
+        if (int st = comm_overlap_resources(comms[i], n_chunks, &e)) return finish(st, &e);
+        // rank i's transfer stream starts behind what its context's stream already holds (d_alls[i]'s previous readers)
+        hipError_t h = hipEventRecord(comms[i]->all_moved, ctxs[i]->stream);
+        if (h == hipSuccess) h = hipStreamWaitEvent(comms[i]->xfer, comms[i]->all_moved, 0);
+        if (h != hipSuccess) { fail_hip(&e, h); return finish(BITNUC_BACKEND_ERROR, &e); }
+    }
     for (int p = 0; p < n_chunks; ++p) {
         const size_t w0 = count * (size_t)p / (size_t)n_chunks, w1 = count * (size_t)(p + 1) / (size_t)n_chunks;
         if (w1 == w0) continue;
@@ -394,6 +403,95 @@ int bitnuc_encode_sharded_allgather_overlapped_all(int n_gpus, bitnuc_ctx **ctxs
         if (rc || rc_end) { fail_rccl(&e, rc ? rc : rc_end); return finish(BITNUC_BACKEND_ERROR, &e); }
     }
     return finish(BITNUC_OK, nullptr);
+}
+
+// ---- a ragged batch across ranks (include/bitnuc_hip.h) --------------------------------------------------------------
+int bitnuc_batch_shard_ranges(const uint64_t *offsets, size_t count, int nranks, size_t *seq_first, uint64_t *word_first, bitnuc_err *err) {
+    clear_err(err);
+    if (nranks < 1 || nranks > 4096 || !seq_first || !word_first || (count && !offsets)) return fail(err, BITNUC_UNSUPPORTED);
+    for (size_t i = 0; i < count; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(err, BITNUC_INVALID_RANGE, i);
+    // W[i] = words before sequence i (every sequence pads its own last word: packing/avx.rs:147-148); two passes, no allocation
+    uint64_t total = 0;
+    for (size_t i = 0; i < count; ++i) total += words_for((size_t)(offsets[i + 1] - offsets[i]));
+    size_t i = 0;
+    uint64_t w = 0; // = W[i]
+    for (int r = 0; r < nranks; ++r) {
+        const uint64_t target = (uint64_t)(((unsigned __int128)total * (unsigned)r) / (unsigned)nranks);
+        while (i < count && w < target) { w += words_for((size_t)(offsets[i + 1] - offsets[i])); ++i; }
+        seq_first[r] = i;
+        word_first[r] = w;
+    }
+    seq_first[nranks] = count;
+    word_first[nranks] = total;
+    return BITNUC_OK;
+}
+
+namespace {
+// rank `me`'s part of the in-place exchange of unequal counts, inside the caller's group
+int allgatherv_issue(RcclApi &r, bitnuc_comm *comm, hipStream_t stream, const size_t *counts, const size_t *first, uint64_t *d_all, bool bcast) {
+    const int P = comm->nranks, me = comm->rank;
+    int rc = 0;
+    for (int s = 0; s < P && rc == 0; ++s) {
+        if (bcast) { if (counts[s]) rc = r.Broadcast(d_all + first[s], d_all + first[s], counts[s], kNcclUint64, s, comm->nccl, stream); }
+        else if (s != me) {
+            if (counts[me]) rc = r.Send(d_all + first[me], counts[me], kNcclUint64, s, comm->nccl, stream);
+            if (rc == 0 && counts[s]) rc = r.Recv(d_all + first[s], counts[s], kNcclUint64, s, comm->nccl, stream);
+        }
+    }
+    return rc;
+}
+} // namespace
+
+int bitnuc_allgatherv_words_dev(bitnuc_ctx *c, bitnuc_comm *comm, const size_t *counts, uint64_t *d_all, bitnuc_err *err) {
+    clear_err(err);
+    if (int st = check_ctx(c, err)) return st;
+    if (!comm || comm->device != c->device || per_rank_call_would_block(comm) || !counts || comm->nranks > 4096) return fail(err, BITNUC_UNSUPPORTED);
+    std::vector<size_t> first((size_t)comm->nranks + 1, 0);
+    for (int s = 0; s < comm->nranks; ++s) first[(size_t)s + 1] = first[(size_t)s] + counts[s];
+    if (first[(size_t)comm->nranks] == 0 || comm->nranks == 1) return BITNUC_OK;
+    if (!d_all || (reinterpret_cast<uintptr_t>(d_all) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    DeviceGuard g(c->device);
+    if (int rc = r.GroupStart()) return fail_rccl(err, rc);
+    const int rc = allgatherv_issue(r, comm, c->stream, counts, first.data(), d_all, gather_by_broadcast());
+    const int rc_end = r.GroupEnd();
+    if (rc) return fail_rccl(err, rc);
+    if (rc_end) return fail_rccl(err, rc_end);
+    return BITNUC_OK;
+}
+
+int bitnuc_allgatherv_words_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const size_t *counts, uint64_t *const *d_alls, bitnuc_err *err) {
+    clear_err(err);
+    if (n_gpus < 1 || n_gpus > 64 || !ctxs || !comms || !counts || !d_alls) return fail(err, BITNUC_UNSUPPORTED);
+    for (int i = 0; i < n_gpus; ++i) {
+        if (!ctxs[i] || !comms[i]) return fail(err, BITNUC_UNSUPPORTED);
+        if (!comms[i]->single_process || comms[i]->threaded || comms[i]->nranks != n_gpus || comms[i]->rank != i || comms[i]->device != ctxs[i]->device) return fail(err, BITNUC_UNSUPPORTED);
+    }
+    std::vector<size_t> first((size_t)n_gpus + 1, 0);
+    for (int s = 0; s < n_gpus; ++s) first[(size_t)s + 1] = first[(size_t)s] + counts[s];
+    if (first[(size_t)n_gpus])
+        for (int i = 0; i < n_gpus; ++i)
+            if (!d_alls[i] || (reinterpret_cast<uintptr_t>(d_alls[i]) & 7)) return fail(err, BITNUC_UNSUPPORTED);
+    RcclApi &r = rccl();
+    if (!r.ok) return fail_rccl(err, -1);
+    int rc = 0, rc_end = 0;
+    if (first[(size_t)n_gpus] && n_gpus > 1) {
+        rc = r.GroupStart();
+        if (rc == 0) {
+            const bool bcast = gather_by_broadcast();
+            for (int i = 0; i < n_gpus && rc == 0; ++i) {
+                DeviceGuard g(ctxs[i]->device);
+                rc = allgatherv_issue(r, comms[i], ctxs[i]->stream, counts, first.data(), d_alls[i], bcast);
+            }
+            rc_end = r.GroupEnd();
+        }
+    }
+    const int st = sync_all(n_gpus, ctxs, err); // every path: the streams are synchronised before the call returns
+    if (rc) return fail_rccl(err, rc);
+    if (rc_end) return fail_rccl(err, rc_end);
+    return st;
 }
 
 // ---- xGMI link probe (measure the per-link rate on the box before quoting a fabric roofline) -----------

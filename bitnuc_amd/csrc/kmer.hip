@@ -4,6 +4,7 @@
 // Kernels: kmer_device.h.
 #include "runtime.h"
 #include "kmer_device.h"
+#include "scan_mfma_device.h"
 #include "host_word.h"
 #include "host_pipe.h"
 
@@ -119,10 +120,61 @@ void query_planes(uint64_t query, size_t k, uint32_t *ql, uint32_t *qh) {
     }
 }
 
+// The query's operand of the matrix-core scan (scan_mfma_device.h: ScanMfmaTable): per window shift rho and K-step, the nibbles that
+// are 1.0 where a channel differs from the query's base (hamming/scalar.rs:33-47 counts the differing 2-bit fields).
+void scan_mfma_table(uint64_t query, size_t k, ScanMfmaTable *t) {
+    uint8_t lo[80], hi[80]; // [16 + i]: channels (A, C) and (G, T) of query position i; zero outside [0, k)
+    memset(lo, 0, sizeof lo);
+    memset(hi, 0, sizeof hi);
+    for (size_t i = 0; i < k; ++i) {
+        const unsigned q = (unsigned)((query >> (2 * i)) & 3);
+        lo[16 + i] = (uint8_t)((q != 0 ? 0x02 : 0) | (q != 1 ? 0x20 : 0));
+        hi[16 + i] = (uint8_t)((q != 2 ? 0x02 : 0) | (q != 3 ? 0x20 : 0));
+    }
+    for (int rho = 0; rho < 16; ++rho)
+        for (int s = 0; s < 6; ++s)
+            for (int i = 0; i < 4; ++i) {
+                const int p0 = 16 * (s >> 1) + 8 * (s & 1) + 4 * (i >> 1); // position of byte 0 of this dword
+                const uint8_t *src = (i & 1) ? hi : lo;
+                uint32_t w = 0;
+                for (int b = 0; b < 4; ++b) w |= (uint32_t)src[16 + p0 + b - rho] << (8 * b);
+                t->w[rho][4 * s + i] = w;
+            }
+}
+
+// grid of the matrix-core scan: resident waves that walk the rounds (each wave builds its constant operand once)
+unsigned scan_mfma_grid(const bitnuc_ctx *c, unsigned long long rounds, int U, bool persist) {
+    const unsigned long long want = rounds / ((kBlock / 64) * (unsigned long long)U) + 1; // one trip per wave (+ 1: the tail loop needs a workgroup even without a whole round)
+    const unsigned long long cap = persist ? (unsigned long long)c->num_cu * (unsigned)knobs(c).scan_mfma_grid : 0x7FFFFFFFull;
+    return (unsigned)(want < cap ? want : cap);
+}
+
 hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist,
                        unsigned long long *slot) {
     uint32_t ql, qh;
     query_planes(query, k, &ql, &qh);
+    if (knobs(c).scan_impl == 7 && aligned16(ref) && aligned16(dist)) { // the contraction on the matrix cores (scan_mfma_device.h)
+        ScanMfmaTable tab;
+        scan_mfma_table(query, k, &tab);
+        const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+        const int U = knobs(c).scan_mfma_unroll, pack = knobs(c).scan_mfma_pack, shift = knobs(c).scan_mfma_shift;
+        const bool persist = knobs(c).scan_mfma_persist != 0, ntld = (knobs(c).scan_mfma_policy & 1) != 0;
+        const unsigned grid = scan_mfma_grid(c, rounds, U, persist);
+#define SCANM(P, UU, PK, SH, PS) kmer_scan_mfma_kernel<P, UU, false, PK, SH, PS><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, 0u, dist, nullptr, nullptr, nullptr, slot, tab)
+#define SCANM_PS(P, UU, PK, SH) do { if (persist) SCANM(P, UU, PK, SH, true); else SCANM(P, UU, PK, SH, false); } while (0)
+#define SCANM_NT(UU, PK, SH) do { if (ntld) SCANM_PS(3, UU, PK, SH); else SCANM_PS(2, UU, PK, SH); } while (0)
+#define SCANM_U(PK, SH) do { if (U == 2) SCANM_NT(2, PK, SH); else SCANM_NT(4, PK, SH); } while (0)
+        if (shift == 0) { if (pack == 0) SCANM_PS(3, 2, 0, 0); else SCANM_PS(3, 2, 1, 0); }
+        else if (shift == 1) { if (pack == 0) SCANM_U(0, 1); else if (pack == 1) SCANM_U(1, 1); else SCANM_U(2, 1); }
+        else if (shift == 2) { if (pack == 0) SCANM_U(0, 2); else if (pack == 1) SCANM_U(1, 2); else SCANM_U(2, 2); }
+        else if (shift == 3) { if (pack == 0) SCANM_U(0, 3); else if (pack == 1) SCANM_U(1, 3); else SCANM_U(2, 3); }
+        else { if (pack == 0) SCANM_U(0, 4); else if (pack == 1) SCANM_U(1, 4); else SCANM_U(2, 4); }
+#undef SCANM_U
+#undef SCANM_NT
+#undef SCANM_PS
+#undef SCANM
+        return hipGetLastError();
+    }
     const int unroll = knobs(c).scan_unroll, kb = knobs(c).kmer_block;
     const bool al = aligned16(ref) && aligned16(dist);
     // the shipped form: line-aligned rounds of 1024 windows, one trip of 4 rounds per wave, two-LUT plane build + scalar halo (GEN 1)
@@ -316,6 +368,22 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
     const unsigned long long want = rounds / ((kBlock / 64) * 4) + 1, cap = (unsigned long long)c->num_cu * 8;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     unsigned long long *res = reinterpret_cast<unsigned long long *>(d_count);
+    if (knobs(c).scan_impl == 7 && aligned16(d_ref)) {
+        ScanMfmaTable tab;
+        scan_mfma_table(query, k, &tab);
+        const int U = knobs(c).scan_mfma_unroll, shift = knobs(c).scan_mfma_shift;
+        const unsigned g = scan_mfma_grid(c, rounds, U, true); // a resident grid: the ticket needs every workgroup to arrive
+        const bool nt = (knobs(c).scan_mfma_policy & 1) != 0;
+#define COUNTM(P, UU, SH) kmer_scan_mfma_kernel<P, UU, true, 0, SH, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot, tab)
+#define COUNTM_NT(UU, SH) do { if (nt) COUNTM(1, UU, SH); else COUNTM(0, UU, SH); } while (0)
+#define COUNTM_U(SH) do { if (U == 2) COUNTM_NT(2, SH); else COUNTM_NT(4, SH); } while (0)
+        if (shift == 0) COUNTM_NT(2, 0); else if (shift == 1) COUNTM_U(1); else if (shift == 2) COUNTM_U(2); else if (shift == 3) COUNTM_U(3); else COUNTM_U(4);
+#undef COUNTM_U
+#undef COUNTM_NT
+#undef COUNTM
+        HIPCHK(hipGetLastError());
+        return BITNUC_OK;
+    }
     if (aligned16(d_ref)) kmer_scan2_kernel<true, true, false, 4, true, 1><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
     else kmer_scan2_kernel<false, false, false, 1, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
     HIPCHK(hipGetLastError());

@@ -49,6 +49,12 @@ struct SweepKnobs {
     int scan_unroll = 4;         // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
     int scan_impl = 1;           // 1 = line-aligned rounds of 1024 windows, two-LUT planes + scalar halo (kmer_scan2_kernel GEN 1: ships), 6 = the same with rounds 2-3's plane build (GEN 0),
                                  // 0 = rounds of 992 windows (kmer_scan_kernel), 2 / 3 / 4 / 5 = kmer_scan3_kernel (a wave owns 12 / 20 / 16 / 32 consecutive rounds: slower, profiles/r04_ab_scan3.txt)
+    int scan_mfma_unroll = 4;    // kmer_scan_mfma_kernel: consecutive 1 KiB rounds per wave trip: 2 or 4
+    int scan_mfma_grid = 4;      // ... persistent form: resident 256-thread workgroups per CU
+    int scan_mfma_policy = 3;    // ... bit 0: nt loads (stores are nt)
+    int scan_mfma_shift = 1;     // ... the shifted operands: 0 = two more global loads, 1 = wave-private LDS strip, 2 = DPP + scalar halo
+    int scan_mfma_persist = 0;   // ... 1 = a resident grid walks the trips with register prefetch, 0 = one trip per wave
+    int scan_mfma_pack = 1;      // ... f32 -> u8: 0 = v_cvt_pk_u8_f32, 1 = 2^23 bias + row scales (copied), 2 = ... (bias by a seventh instruction)
     int hdist_tiled = 0;         // bulk hdist: 1 = grid-stride at tile granularity (16 KiB of each operand per workgroup trip), 0 = at thread granularity
     int hdist_words_impl = 1;    // many-pair / one-query hdist: 1 = coalesced loads + bpermute for whole 256-word tiles, 0 = four contiguous words per lane
     int fixed_stream = 1;        // encode_fixed (back-to-back reads): 1 = cut the tile's 2-bit stream

@@ -321,7 +321,13 @@ constexpr SweepKey kSweepKeys[] = {
     {"kmer_block", &bitnuc_rt::SweepKnobs::kmer_block, 0, 0, 0, {64, 128, 256}},
     {"dense_unroll", &bitnuc_rt::SweepKnobs::dense_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
     {"scan_unroll", &bitnuc_rt::SweepKnobs::scan_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
-    {"scan_impl", &bitnuc_rt::SweepKnobs::scan_impl, 0, 6, 0, {0, 0, 0}},
+    {"scan_impl", &bitnuc_rt::SweepKnobs::scan_impl, 0, 7, 0, {0, 0, 0}},
+    {"scan_mfma_unroll", &bitnuc_rt::SweepKnobs::scan_mfma_unroll, 0, 0, 1ull << 2 | 1ull << 4, {0, 0, 0}},
+    {"scan_mfma_shift", &bitnuc_rt::SweepKnobs::scan_mfma_shift, 0, 4, 0, {0, 0, 0}},
+    {"scan_mfma_persist", &bitnuc_rt::SweepKnobs::scan_mfma_persist, 0, 1, 0, {0, 0, 0}},
+    {"scan_mfma_grid", &bitnuc_rt::SweepKnobs::scan_mfma_grid, 1, 32, 0, {0, 0, 0}},
+    {"scan_mfma_pack", &bitnuc_rt::SweepKnobs::scan_mfma_pack, 0, 2, 0, {0, 0, 0}},
+    {"scan_mfma_policy", &bitnuc_rt::SweepKnobs::scan_mfma_policy, 0, 3, 0, {0, 0, 0}},
     {"hdist_tiled", &bitnuc_rt::SweepKnobs::hdist_tiled, 0, 1, 0, {0, 0, 0}},
     {"hdist_words_impl", &bitnuc_rt::SweepKnobs::hdist_words_impl, 0, 1, 0, {0, 0, 0}},
     {"fixed_stream", &bitnuc_rt::SweepKnobs::fixed_stream, 0, 1, 0, {0, 0, 0}},

@@ -1,0 +1,296 @@
+// scan_mfma_device.h -- BASELINE config 5 (sliding k-mer pack + Hamming distance to a query) as a contraction on the matrix cores.
+//
+// dist[j] = hdist_scalar(as_2bit(ref[j .. j+k]), query, k)   (packing/naive.rs:3-20 o hamming/scalar.rs:11-48)
+//         = sum_i [ref[j+i] != q[i]] = sum_i sum_c onehot(ref[j+i])[c] * (1 - onehot(q[i])[c])
+// is a Toeplitz product of the reference's one-hot code with a constant built from the query: exact in any format that holds 0 and 1.
+// pack / unpack stay integer bit-twiddling (no contraction there); THIS row is one, and kmer_scan2_kernel spends 9.4 vector
+// instructions per window on it (VALU-issue bound, clock-sensitive: DESIGN 3.4).  Here the VALU only builds the one-hot operand
+// (two v_perm per ASCII dword) and packs the result; the 31 compare-and-add steps per window run on the matrix pipe.
+//
+// Instruction: v_mfma_scale_f32_32x32x64_f8f6f4 with fp4 (E2M1) operands -- 32 x 32 outputs, K = 64 nibbles per instruction, 32 cycles
+// per SIMD.  fp4 because a base is then 16 bits (4 channels x 4 bits, 1.0 = 0b0010) = one byte from each of two 8-entry v_perm LUTs
+// keyed on b & 7 (the codec's LUT index); i8 would need four.  Layout (tools/exp/mfma_fp4_probe.hip checks it on the device with
+// exact data): A lane l = row l & 31, K-block l >> 5; B lane l = column l & 31, K-block l >> 5; D lane l register r = column l & 31,
+// row (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+//
+// Tiling: NO lane ever holds anything but its own natural 16 bytes.  A wave round is 1 KiB of windows at a 1 KiB aligned offset
+// (as kmer_scan2_kernel); lane l = (column n = l & 31, half h = l >> 5) loads the 16 bases at 16 l (+ 16 b for b = 1, 2: the next
+// two lanes' bytes, fully coalesced loads that hit the lines the first one brought in) and ends up holding the 16 distances of the
+// windows that start at those 16 bases: D row m <-> (shift rho = (m & 3) + 4 (m >> 3), half a = (m >> 2) & 1), window =
+// 16 (n + 32 a) + rho, so register r of lane (n, h) is window 16 l + r -- one natural dwordx4 store, no transpose anywhere.
+// The price: A is block-diagonal (row half a only meets K-block a), i.e. half of every instruction multiplies zeros; 6 instructions
+// per 1024 windows (3 loads x 2 groups of 8 positions) = 192 matrix cycles per round and SIMD, far below the round's HBM time.
+//
+// Packing the 16 f32 results into 16 bytes costs 2 instructions per 4 windows instead of 4: the accumulator starts at 2^23 (the
+// integer d then sits in the low mantissa bits) and A's rows carry the E8M0 block scale 2^(8 (rho & 3)) for rho & 3 < 3, so three
+// results OR together into bytes 0-2 and a v_perm drops the fourth into byte 3.  Everything is an integer below 2^24: exact.
+// Invalid bytes: checked once per round on the lane's own 16 bytes with the codec's validity residue (device_prims.h); their one-hot
+// is all zero, the call fails with INVALID_BASE anyway.
+#pragma once
+#include "device_prims.h"
+#include "kmer_device.h" // wave_shl1
+
+namespace bitnuc_dev {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// The query's side of the product, built on the host (kmer.hip: scan_mfma_table) and passed BY VALUE in the kernel arguments (1.5 KiB:
+// a hipGraph node keeps its own copy).  w[rho][4 s + i]: K-step s = 2 b + e (load b, 8-position group e), dword i of the lane's 16-byte
+// operand, for the row whose windows start rho bases into the lane's 16.  Byte t of dwords {0, 1} (2, 3) belongs to position
+// 16 b + 8 e + t (+ 4): dword 0 / 2 holds channels A (low nibble) and C, dword 1 / 3 channels G and T; a nibble is 1.0 (0b0010)
+// where the channel differs from the query's base at i = position - rho, 0 where it equals it or i is outside [0, k).
+struct ScanMfmaTable { uint32_t w[16][24]; };
+
+// 8 bases (two ASCII dwords) -> 32 one-hot nibbles in the same order
+__device__ __forceinline__ i32x8 onehot8(uint32_t x0, uint32_t x1) {
+    const uint32_t s0 = x0 & 0x07070707u, s1 = x1 & 0x07070707u; // A=1 C=3 T=4 G=7, case bit ignored
+    i32x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
+    b[0] = (int)__builtin_amdgcn_perm(0u, 0x20000200u, s0);       // A -> 0x02, C -> 0x20
+    b[1] = (int)__builtin_amdgcn_perm(0x02000020u, 0u, s0);       // G -> 0x02, T -> 0x20
+    b[2] = (int)__builtin_amdgcn_perm(0u, 0x20000200u, s1);
+    b[3] = (int)__builtin_amdgcn_perm(0x02000020u, 0u, s1);
+    return b;
+}
+
+// SHIFT: where the two shifted operands (the next two lanes' 16 bytes) come from.
+//   0 = two more global loads at +16 / +32 (round 5's first form: 3 KiB through the vector L1 per KiB; 360 us per 10^9 windows whatever the
+//       VALU count -- with 40 KiB of rounds in flight per CU the 32 KiB L1 does not keep the lines, profiles/r05_ab_scan_mfma_v1_shifted_loads.txt)
+//   1 = a wave-private LDS strip: the trip's U KiB + the 32-byte halo are written once (ds_write_b128), read back at +16 / +32
+//   2 = DPP: wave_shl:1 per dword, lane 63 takes the halo dword from the scalar unit (s_load of the 32 bytes after the round)
+//   3 = the ONE-HOT operands cross the strip instead of the bytes: every 16-byte group is expanded once (4 v_and + 8 v_perm) and
+//       the six operands of a round are six ds_read_b128 -- a third of the expansion work of forms 0-2, which expand every group
+//       three times (the count kernel is VALU-issue bound: each vector instruction per round costs 2 us per 10^9 windows)
+//   4 = as 3, but a lane keeps the operands of its OWN 16 bytes in registers: four ds_read_b128 per round instead of six (the strip
+//       costs 2 x 13 LDS cycles to write and 4 per read, MI355X_MICROARCH.md LDS table; 8 more registers per round of the trip)
+// PACK (how 16 f32 results become 16 bytes): 0 = v_cvt_pk_u8_f32 per window, accumulator starts at inline 0, no scales;
+//   1 = the 2^23 bias + row scales (v_or3 + v_perm per 4 windows), the bias an untied C operand held in 16 registers;
+//   2 = the same, the bias produced by a seventh instruction with constant operands (one nibble x ones, scale 2^23)
+// PERSIST: true = a resident grid walks the trips (a wave builds its constant operand once; the next trip's loads are issued before the
+//   current one is computed); false = one trip per wave, the hardware dispatcher walks the trips (how every streaming kernel of this
+//   library runs fastest), the table loads overlap the trip's data loads.
+// 16 results of a lane (windows 16 l .. 16 l + 15 of the round) -> the count of d <= tau, or 16 distance bytes
+template <bool COUNT, int PACK, bool NTST>
+__device__ __forceinline__ void scan_mfma_emit(const f32x16 &acc, float tauf, uint32_t &hits, uint8_t *dst) {
+    if constexpr (COUNT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hits += (uint32_t)__builtin_popcountll(__ballot(acc[r] <= tauf));
+    } else {
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (PACK == 0) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w = __builtin_amdgcn_cvt_pk_u8_f32(acc[4 * q + j], j, w);
+                o[q] = w;
+            } else {
+                // (__float_as_uint on a copy: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
+                const float d0 = acc[4 * q], d1 = acc[4 * q + 1], d2 = acc[4 * q + 2], d3 = acc[4 * q + 3];
+                o[q] = __builtin_amdgcn_perm(__float_as_uint(d3), __float_as_uint(d0) | __float_as_uint(d1) | __float_as_uint(d2), 0x04020100u);
+            }
+        }
+        store_group<NTST, true>(dst, o);
+    }
+}
+
+template <int U>
+struct ScanTrip {
+    u32x4 v[U][3]; // [round][shift]: shifts 1, 2 only with SHIFT 0
+    u32x4 hv;      // SHIFT 1, 3: the 32 bytes after the trip's last round, lanes 0 and 1
+    uint32_t hw[U][8]; // SHIFT 2: the 32 bytes after each round, wave-uniform
+};
+
+template <int U, int SHIFT, bool NTLD>
+__device__ __forceinline__ void scan_trip_load(const uint8_t *__restrict__ ref, unsigned long long r0, unsigned long long rounds, unsigned lane, ScanTrip<U> &t) {
+    const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U; // valid rounds (wave-uniform)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned long long r = (unsigned)u < m ? r0 + u : r0 + m - 1; // clamp: redundant but in bounds
+        const uint8_t *p = ref + (r << 10) + 16 * lane;
+        t.v[u][0] = load_group<NTLD, true>(p);
+        if constexpr (SHIFT == 0) {
+            t.v[u][1] = load_group<false, true>(p + 16);
+            t.v[u][2] = load_group<false, true>(p + 32);
+        }
+        if constexpr (SHIFT == 2) {
+            const uint32_t *hp = reinterpret_cast<const uint32_t *>(ref + ((r + 1) << 10));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t.hw[u][i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hp[i]);
+        }
+    }
+    if constexpr (SHIFT == 1 || SHIFT >= 3) {
+        t.hv = u32x4{0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+        if (lane < 2) t.hv = load_group<false, true>(ref + ((r0 + m) << 10) + 16 * lane);
+    }
+}
+
+template <int POLICY, int U, bool COUNT, int PACK = 1, int SHIFT = 1, bool PERSIST = false>
+__global__ void __launch_bounds__(kBlock)
+kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
+                      uint8_t *__restrict__ dist, unsigned long long *__restrict__ result, unsigned long long *__restrict__ total /* zero between launches */,
+                      unsigned *__restrict__ ticket, unsigned long long *__restrict__ slot, const ScanMfmaTable tab) {
+    constexpr bool NTLD = (POLICY & 1) != 0, NTST = (POLICY & 2) != 0;
+    constexpr int kPlane = U * 1024 + 32;                    // a trip's bytes (SHIFT 1) or one of its two operand planes (SHIFT 3): U KiB + the halo
+    constexpr bool ONEHOT = SHIFT == 3 || SHIFT == 4, KEEP = SHIFT == 4;
+    constexpr int kStrip = ONEHOT ? 2 * kPlane : kPlane;
+    constexpr bool LDS = SHIFT == 1 || ONEHOT;
+    __shared__ __attribute__((aligned(16))) uint8_t strips[LDS ? kBlock / 64 : 1][LDS ? kStrip : 16];
+    const unsigned long long nwin = n - k + 1;                              // host guarantees 1 <= k <= 32, n >= k
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;       // round r reads bytes [1024 r, 1024 r + 1056)
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    uint8_t *strip = strips[LDS ? wave_in_block() : 0];
+
+    ScanTrip<U> cur;
+    unsigned long long r0 = wave * U;
+    if (r0 < rounds) scan_trip_load<U, SHIFT, NTLD>(ref, r0, rounds, lane, cur); // before the table: its loads overlap these
+
+    // the wave's constant operand: row m = lane & 31 of K-block lane >> 5
+    const unsigned m32 = lane & 31u, rho = (m32 & 3u) + 4u * (m32 >> 3);
+    const uint32_t keep = ((m32 >> 2) & 1u) == (lane >> 5) ? ~0u : 0u; // A is block-diagonal: row half a only meets K-block a
+    i32x8 A[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        A[s] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A[s][i] = (int)(tab.w[rho][4 * s + i] & keep);
+    }
+    constexpr bool BIAS = !COUNT && PACK != 0;
+    const int scale_a = !BIAS ? 127 : 127 + 8 * (int)((m32 & 3u) == 3u ? 0u : (m32 & 3u)); // E8M0: 2^(8 (rho & 3)) for rho & 3 < 3
+    f32x16 c0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c0[i] = BIAS && PACK == 1 ? 8388608.f : 0.f;
+    if constexpr (BIAS && PACK == 1) asm volatile("" : "+v"(c0)); // sixteen registers used as an untied C operand (a splat constant is re-materialised by 16 v_mov per round)
+    const i32x8 bias_a = {lane < 32 ? 2 : 0, 0, 0, 0, 0, 0, 0, 0};                                   // PACK 2: nibble 0 of K-block 0 = 1.0, every row
+    const i32x8 bias_b = {0x22222222, 0x22222222, 0x22222222, 0x22222222, 0, 0, 0, 0};              // ... x ones, scale 2^23
+    const float tauf = (float)tau;
+    const unsigned nsteps = (15u + k + 7u) >> 3; // 8-position K-steps that hold a position some window needs: 15 + k positions (6 for k >= 26, 2 for k = 1)
+    const uint32_t m63 = lane == 63 ? ~0u : 0u;
+    uint32_t hits = 0; // COUNT: wave-uniform until the tail
+
+    while (r0 < rounds) {
+        const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U; // valid rounds in this trip (wave-uniform)
+        ScanTrip<U> nxt;
+        const unsigned long long rn = r0 + nwaves * U;
+        if constexpr (PERSIST) { if (rn < rounds) scan_trip_load<U, SHIFT, NTLD>(ref, rn, rounds, lane, nxt); }
+        if constexpr (SHIFT == 1) {
+            wave_lds_fence(); // the previous trip's readers are done
+#pragma unroll
+            for (int u = 0; u < U; ++u) *reinterpret_cast<u32x4 *>(strip + 1024 * u + 16 * lane) = cur.v[u][0];
+            if (lane < 2) *reinterpret_cast<u32x4 *>(strip + 1024 * m + 16 * lane) = cur.hv; // after the last VALID round (a clamped copy may sit there: in-order LDS, the later write wins)
+            wave_lds_fence();
+        }
+        i32x8 own[KEEP ? U : 1][2];
+        if constexpr (ONEHOT) {
+            wave_lds_fence(); // the previous trip's readers are done
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32x4 x = cur.v[u][0];
+                // validity of the lane's own 16 bytes, while they are in registers: a second LUT on the same index holds the upper-case byte
+                // that index stands for (0xFF for the four indices no base has: their low bits never match), so x ^ t is 0 or the case bit
+                uint32_t bad = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
+                if (__builtin_expect((bad & 0xDFDFDFDFu) != 0u && (unsigned)u < m, 0)) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+                const i32x8 e0 = onehot8(x.x, x.y), e1 = onehot8(x.z, x.w);
+                if constexpr (KEEP) { own[u][0] = e0; own[u][1] = e1; }
+                *reinterpret_cast<u32x4 *>(strip + 1024 * u + 16 * lane) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
+                *reinterpret_cast<u32x4 *>(strip + kPlane + 1024 * u + 16 * lane) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+            }
+            if (lane < 2) { // the halo after the last VALID round (a clamped copy may sit there: in-order LDS, the later write wins); validated by the round that owns it
+                const i32x8 e0 = onehot8(cur.hv.x, cur.hv.y), e1 = onehot8(cur.hv.z, cur.hv.w);
+                *reinterpret_cast<u32x4 *>(strip + 1024 * m + 16 * lane) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
+                *reinterpret_cast<u32x4 *>(strip + kPlane + 1024 * m + 16 * lane) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+            }
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((unsigned)u >= m) break; // wave-uniform
+            const unsigned long long wb = (r0 + u) << 10;
+            if constexpr (ONEHOT) {
+                i32x8 B[6];
+#pragma unroll
+                for (int s6 = 0; s6 < 6; ++s6) {
+                    if (KEEP && s6 < 2) { B[s6] = own[KEEP ? u : 0][s6]; continue; }
+                    if (s6 >= (int)nsteps) { B[s6] = i32x8{0, 0, 0, 0, 0, 0, 0, 0}; continue; } // wave-uniform
+                    const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + (s6 & 1) * kPlane + 1024 * u + 16 * lane + 16 * (s6 >> 1));
+                    B[s6] = i32x8{(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+                }
+                f32x16 acc = c0;
+                if constexpr (BIAS && PACK == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bias_a, bias_b, c0, 4, 4, 0, 127 + 23, 0, 127);
+#pragma unroll
+                for (int s6 = 0; s6 < 6; ++s6)
+                    if (s6 < 2 || s6 < (int)nsteps) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[s6], B[s6], acc, 4, 4, 0, scale_a, 0, 127);
+                scan_mfma_emit<COUNT, PACK, NTST>(acc, tauf, hits, dist + wb + 16 * lane);
+                continue;
+            }
+            u32x4 sh[3];
+            sh[0] = cur.v[u][0];
+            if constexpr (SHIFT == 0) { sh[1] = cur.v[u][1]; sh[2] = cur.v[u][2]; }
+            if constexpr (SHIFT == 1) {
+                sh[1] = *reinterpret_cast<const u32x4 *>(strip + 1024 * u + 16 * lane + 16);
+                sh[2] = *reinterpret_cast<const u32x4 *>(strip + 1024 * u + 16 * lane + 32);
+            }
+            if constexpr (SHIFT == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // lane 63 of a wave_shl is 0 (bound_ctrl): the halo goes in with one v_and_or (kmer_scan2_kernel's idiom)
+                    sh[1][i] = wave_shl1(sh[0][i]) | (cur.hw[u][i] & m63);
+                    sh[2][i] = wave_shl1(sh[1][i]) | (cur.hw[u][4 + i] & m63);
+                }
+            }
+            uint32_t bad = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bad |= __builtin_amdgcn_perm(0x42040453u, 0x41044004u, sh[0][i] & 0x07070707u) ^ (sh[0][i] & 0xD8D8D8D8u);
+            if (__builtin_expect(residue_is_bad(bad), 0)) rescan_bytes(ref, wb + 16 * lane, 16, slot);
+            f32x16 acc = c0;
+            if constexpr (BIAS && PACK == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bias_a, bias_b, c0, 4, 4, 0, 127 + 23, 0, 127);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[2 * b], onehot8(sh[b].x, sh[b].y), acc, 4, 4, 0, scale_a, 0, 127);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[2 * b + 1], onehot8(sh[b].z, sh[b].w), acc, 4, 4, 0, scale_a, 0, 127);
+            }
+            scan_mfma_emit<COUNT, PACK, NTST>(acc, tauf, hits, dist + wb + 16 * lane);
+        }
+        if constexpr (!PERSIST) break;
+        cur = nxt;
+        r0 = rn;
+    }
+
+    // tail: one window per thread, byte loads
+    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    uint32_t tail_hits = 0;
+    for (unsigned long long i = (rounds << 10) + gt; i < nwin; i += nthreads) {
+        unsigned long long w = 0;
+        bool flagged = false;
+        for (unsigned b = 0; b < k; ++b) {
+            const uint32_t byte = ref[i + b];
+            if (!valid_base(byte) && !flagged) { latch_bad(slot, i + b, byte); flagged = true; }
+            w |= (unsigned long long)code_of(byte) << (2 * b);
+        }
+        const unsigned long long x = (w ^ query) & kmask;
+        const uint32_t d = (uint32_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);
+        if constexpr (COUNT) tail_hits += d <= tau ? 1u : 0u;
+        else dist[i] = (uint8_t)d;
+    }
+    if constexpr (COUNT) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tail_hits += __shfl_xor(tail_hits, off);
+        __shared__ uint32_t part[kBlock / 64];
+        if (lane == 0) part[threadIdx.x >> 6] = hits + tail_hits;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long s = 0;
+            for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
+            if (s) add_performed(total, s);
+            if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
+        }
+    }
+}
+
+} // namespace bitnuc_dev

@@ -314,6 +314,32 @@ int bitnuc_encode_sharded_allgather_overlapped_dev(bitnuc_ctx *ctx, bitnuc_comm 
 int bitnuc_encode_sharded_allgather_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, uint64_t *const *d_alls, bitnuc_err *err);
 int bitnuc_encode_sharded_allgather_overlapped_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const uint8_t *const *d_seq_shards, size_t shard_len, int n_chunks, uint64_t *const *d_alls, bitnuc_err *err);
 
+/* ---- a RAGGED BATCH across ranks ("for a batch of independent sequences of unequal length the partition is by whole
+ * sequences with an offsets table; the final word of each sequence is padded independently" -- packing/avx.rs:147-148 is that
+ * padding rule, src/utils/mod.rs:22-25 the per-sequence loop the batch replaces).
+ * bitnuc_batch_shard_ranges: host arithmetic only, no device.  Sequence i holds bases [offsets[i], offsets[i+1]) and packs into
+ * ceil(len / 32) words of its own.  Rank r of nranks gets the run of WHOLE sequences [seq_first[r], seq_first[r+1]), balanced by
+ * word count: seq_first[r] = the first i whose word prefix W[i] >= floor(r * W[count] / nranks) (so a sequence longer than a fair
+ * share stays whole and the ranks it covers get empty runs; seq_first[0] = 0, seq_first[nranks] = count).  word_first[r] =
+ * W[seq_first[r]] = where rank r's words start in the concatenation; word_first[nranks] = the batch's total words.
+ * Each rank then rebases its run's offsets to 0 and encodes it with the batch entry points above (bitnuc_batch_plan_build_dev +
+ * bitnuc_encode_batch_plan_dev) straight into d_all + word_first[rank]; the global word_offsets table is word_first[rank] + the
+ * rank's own table. */
+int bitnuc_batch_shard_ranges(const uint64_t *offsets /* count+1 */, size_t count, int nranks, size_t *seq_first /* nranks+1 */, uint64_t *word_first /* nranks+1 */, bitnuc_err *err);
+/* All-gather of UNEQUAL word counts, in place: counts[r] words of rank r live at d_all + sum(counts[0..r)) on rank r before the
+ * call and on every rank after it (grouped ncclSend / ncclRecv with per-peer counts on the context's stream -- all P-1 links of a
+ * GPU at once; BITNUC_GATHER_MODE=bcast: one grouped in-place ncclBroadcast per non-empty rank).  counts must be the same array
+ * on every rank; a rank with counts[r] == 0 sends nothing.  Asynchronous like every _dev call. */
+int bitnuc_allgatherv_words_dev(bitnuc_ctx *ctx, bitnuc_comm *comm, const size_t *counts /* nranks */, uint64_t *d_all, bitnuc_err *err);
+/* ... for a thread that holds every rank (bitnuc_comm_init_all[_devices]): one group with every rank's sends and receives, then
+ * every stream is synchronised (a data error latched by the encodes queued before it is reported like the other _all forms). */
+int bitnuc_allgatherv_words_all(int n_gpus, bitnuc_ctx **ctxs, bitnuc_comm **comms, const size_t *counts /* n_gpus */, uint64_t *const *d_alls, bitnuc_err *err);
+/* A communicator made by bitnuc_comm_init_all[_devices] is taken to be driven by ONE thread, and the per-rank entry points refuse
+ * it (they would block in RCCL waiting for peers that thread has not issued).  A host that gives every rank of such a communicator
+ * its own thread -- ordinary NCCL usage -- says so here (threaded = 1) and may then use the per-rank entry points; the _all forms
+ * refuse the communicator from then on.  Returns the previous setting, -1 for NULL. */
+int bitnuc_comm_set_threaded(bitnuc_comm *comm, int threaded);
+
 /* xGMI link probe (no reference counterpart; SURVEY section 5 asks for the measured per-link rate before any
  * fabric fraction is quoted): hipMemcpyPeerAsync of `bytes` from src_device to each of dst_devices[0..n), one
  * link at a time (gb_s_each[i], best of reps) and then all n at once (*gb_s_all, the aggregate outbound rate).

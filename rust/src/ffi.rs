@@ -97,6 +97,10 @@ extern "C" {
     pub fn bitnuc_host_pipe_info(ctx: *mut bitnuc_ctx, out: *mut f64, n: c_int, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_encode_sharded_allgather_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, d_seq_shards: *const *const u8, shard_len: usize, d_alls: *const *mut u64, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_encode_sharded_allgather_overlapped_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, d_seq_shards: *const *const u8, shard_len: usize, n_chunks: c_int, d_alls: *const *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_batch_shard_ranges(offsets: *const u64, count: usize, nranks: c_int, seq_first: *mut usize, word_first: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_allgatherv_words_dev(ctx: *mut bitnuc_ctx, comm: *mut bitnuc_comm, counts: *const usize, d_all: *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_allgatherv_words_all(n_gpus: c_int, ctxs: *mut *mut bitnuc_ctx, comms: *mut *mut bitnuc_comm, counts: *const usize, d_alls: *const *mut u64, err: *mut bitnuc_err) -> c_int;
+    pub fn bitnuc_comm_set_threaded(comm: *mut bitnuc_comm, threaded: c_int) -> c_int;
     pub fn bitnuc_nucgen_dev(ctx: *mut bitnuc_ctx, d_out: *mut u8, len: usize, seed: u64, first: u64, flags: c_int, err: *mut bitnuc_err) -> c_int;
     pub fn bitnuc_stream_probe_dev(ctx: *mut bitnuc_ctx, mode: c_int, d_src: *const c_void, d_dst: *mut c_void, bytes: usize, err: *mut bitnuc_err) -> c_int;
     // layout plan of a ragged batch (include/bitnuc_hip.h): built once per offsets table, used by every encode / decode of it

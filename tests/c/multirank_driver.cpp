@@ -9,6 +9,10 @@
 //           oneshot_all | overlap_all   ONE thread holds all P ranks (bitnuc_comm_init_all_devices on device 0 P times -- the mock
 //                                       accepts the duplicate device, RCCL would not) and drives them with the _all entry points;
 //                                       also checks that the per-rank entry points REFUSE such a communicator (they would block)
+//           ragged | ragged_all         a RAGGED BATCH split by whole sequences (SURVEY 8e sentence 2): shard_len = number of sequences, n_chunks = seed of
+//                                       their lengths; every rank encodes its run (bitnuc_batch_shard_ranges -> bitnuc_batch_plan_build_dev ->
+//                                       bitnuc_encode_batch_plan_dev) into its slot and the UNEQUAL word counts are gathered in place
+//                                       (bitnuc_allgatherv_words_dev / _all); expected = ONE context's plan encode of the whole batch
 //     rounds: calls back to back on the SAME buffers with new data each round (in-place reuse: the transfer stream of round r+1
 //             must not run ahead of round r's readers)
 //     bad_rank / bad_offset: plant an invalid byte in that rank's shard in the last round: that rank's sync must report
@@ -129,6 +133,154 @@ void run_single_process(int P, size_t shard_len, int n_chunks, bool overlap, int
     }
 }
 
+
+// ---- ragged batch: whole sequences per rank, in-place gather of unequal word counts ------------------------------------------------
+std::vector<uint64_t> ragged_offsets(size_t nseq, uint64_t seed) {
+    std::vector<uint64_t> off(nseq + 1, 0);
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (size_t i = 0; i < nseq; ++i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        uint64_t len = (x >> 11) % 400;                 // reads of 0..399 bases: empty sequences occur
+        if (x % 7 == 0) len = 0;
+        if (nseq > 8 && i == nseq / 3) len = 200000 + (x % 1000); // one sequence longer than a fair share of any P here
+        off[i + 1] = off[i] + len;
+    }
+    return off;
+}
+
+void run_ragged(int P, size_t nseq, uint64_t seed, bool single_process, int rounds) {
+    int rank = -1;
+    bitnuc_err err;
+    memset(&err, 0, sizeof err);
+    const std::vector<uint64_t> off = ragged_offsets(nseq, seed);
+    const size_t total_bases = (size_t)off[nseq];
+    std::vector<size_t> seq_first((size_t)P + 1);
+    std::vector<uint64_t> word_first((size_t)P + 1);
+    BNOK(bitnuc_batch_shard_ranges(off.data(), nseq, P, seq_first.data(), word_first.data(), &err));
+    const size_t total_words = (size_t)word_first[(size_t)P];
+    std::vector<size_t> counts((size_t)P);
+    int nonempty = 0;
+    for (int r = 0; r < P; ++r) { counts[(size_t)r] = (size_t)(word_first[(size_t)r + 1] - word_first[(size_t)r]); nonempty += counts[(size_t)r] != 0; }
+    // expected per round: one context, the whole batch
+    std::vector<std::vector<uint64_t>> expect((size_t)rounds, std::vector<uint64_t>(total_words + 1));
+    {
+        bitnuc_ctx *c = nullptr;
+        BNOK(bitnuc_ctx_create(0, &c, &err));
+        uint8_t *d_seq = nullptr; uint64_t *d_off = nullptr, *d_words = nullptr;
+        HIPOK(hipMalloc(&d_seq, total_bases + 64)); HIPOK(hipMalloc(&d_off, (nseq + 1) * 8)); HIPOK(hipMalloc(&d_words, total_words * 8 + 64));
+        HIPOK(hipMemcpy(d_off, off.data(), (nseq + 1) * 8, hipMemcpyHostToDevice));
+        bitnuc_batch_plan *plan = nullptr;
+        size_t tw = 0;
+        BNOK(bitnuc_batch_plan_create(c, &plan, &err));
+        BNOK(bitnuc_batch_plan_build_dev(c, plan, d_off, nseq, &tw, &err));
+        if (tw != total_words) complain(-1, "bitnuc_batch_shard_ranges' total " + std::to_string(total_words) + " != the plan's " + std::to_string(tw));
+        for (int r = 0; r < rounds; ++r) {
+            if (total_bases) BNOK(bitnuc_nucgen_dev(c, d_seq, total_bases, kSeed + (uint64_t)r, 0, 2 /* lower-case mix */, &err));
+            BNOK(bitnuc_encode_batch_plan_dev(c, plan, d_seq, d_words, &err));
+            BNOK(bitnuc_ctx_sync(c, &err));
+            HIPOK(hipMemcpy(expect[(size_t)r].data(), d_words, total_words * 8, hipMemcpyDeviceToHost));
+        }
+        bitnuc_batch_plan_destroy(plan);
+        (void)hipFree(d_seq); (void)hipFree(d_off); (void)hipFree(d_words);
+        bitnuc_ctx_destroy(c);
+    }
+    struct RankState { bitnuc_ctx *c = nullptr; bitnuc_comm *comm = nullptr; bitnuc_batch_plan *plan = nullptr; uint8_t *d_seq = nullptr; uint64_t *d_off = nullptr, *d_all = nullptr; size_t nbases = 0, base0 = 0, nloc = 0; };
+    auto setup = [&](RankState &st, int r) {
+        const int rank = r;
+        bitnuc_err err; // (the lambdas run on the ranks' threads: each call reports through its own)
+        memset(&err, 0, sizeof err);
+        const size_t s0 = seq_first[(size_t)r], s1 = seq_first[(size_t)r + 1];
+        st.nloc = s1 - s0; st.base0 = (size_t)off[s0]; st.nbases = (size_t)(off[s1] - off[s0]);
+        std::vector<uint64_t> local(st.nloc + 1);
+        for (size_t i = 0; i <= st.nloc; ++i) local[i] = off[s0 + i] - off[s0]; // the run's offsets rebased to 0
+        HIPOK(hipMalloc(&st.d_seq, st.nbases + 64)); HIPOK(hipMalloc(&st.d_off, (st.nloc + 1) * 8)); HIPOK(hipMalloc(&st.d_all, total_words * 8 + 64));
+        HIPOK(hipMemcpy(st.d_off, local.data(), (st.nloc + 1) * 8, hipMemcpyHostToDevice));
+        HIPOK(hipMemset(st.d_all, 0xEE, total_words * 8 + 64));
+        size_t tw = 0;
+        BNOK(bitnuc_batch_plan_create(st.c, &st.plan, &err));
+        BNOK(bitnuc_batch_plan_build_dev(st.c, st.plan, st.d_off, st.nloc, &tw, &err));
+        if (tw != counts[(size_t)r]) complain(r, "the run's plan holds " + std::to_string(tw) + " words, the split says " + std::to_string(counts[(size_t)r]));
+    };
+    auto encode = [&](RankState &st, int r, int round) {
+        const int rank = r;
+        bitnuc_err err;
+        memset(&err, 0, sizeof err);
+        if (st.nbases) BNOK(bitnuc_nucgen_dev(st.c, st.d_seq, st.nbases, kSeed + (uint64_t)round, (uint64_t)st.base0, 2, &err)); // exactly this rank's bases of the stream
+        BNOK(bitnuc_encode_batch_plan_dev(st.c, st.plan, st.d_seq, st.d_all + word_first[(size_t)r], &err));
+    };
+    auto check = [&](RankState &st, int r, int round) {
+        const int rank = r;
+        std::vector<uint64_t> got(total_words + 8);
+        HIPOK(hipMemcpy(got.data(), st.d_all, total_words * 8 + 64, hipMemcpyDeviceToHost));
+        if (memcmp(got.data(), expect[(size_t)round].data(), total_words * 8) != 0) {
+            size_t w = 0;
+            while (got[w] == expect[(size_t)round][w]) ++w;
+            int owner = 0;
+            while (w >= word_first[(size_t)owner + 1]) ++owner;
+            complain(r, "round " + std::to_string(round) + ": word " + std::to_string(w) + " (slot of rank " + std::to_string(owner) + ") differs from the single-context batch encode");
+        }
+        for (size_t k = 0; k < 8; ++k)
+            if (got[total_words + k] != 0xEEEEEEEEEEEEEEEEull) { complain(r, "wrote past the gathered buffer"); break; }
+    };
+    auto teardown = [&](RankState &st) {
+        bitnuc_batch_plan_destroy(st.plan);
+        (void)hipFree(st.d_seq); (void)hipFree(st.d_off); (void)hipFree(st.d_all);
+    };
+    if (single_process) {
+        std::vector<int> devs((size_t)P, 0);
+        std::vector<bitnuc_ctx *> ctxs((size_t)P, nullptr);
+        std::vector<bitnuc_comm *> comms((size_t)P, nullptr);
+        BNOK(bitnuc_comm_init_all_devices(P, devs.data(), ctxs.data(), comms.data(), &err));
+        std::vector<RankState> st((size_t)P);
+        std::vector<uint64_t *> alls((size_t)P);
+        for (int r = 0; r < P; ++r) { st[(size_t)r].c = ctxs[(size_t)r]; st[(size_t)r].comm = comms[(size_t)r]; setup(st[(size_t)r], r); alls[(size_t)r] = st[(size_t)r].d_all; }
+        if (P > 1 && bitnuc_allgatherv_words_dev(ctxs[0], comms[0], counts.data(), alls[0], &err) != BITNUC_UNSUPPORTED) complain(0, "bitnuc_allgatherv_words_dev accepted a single-process communicator");
+        for (int round = 0; round < rounds; ++round) {
+            for (int r = 0; r < P; ++r) encode(st[(size_t)r], r, round);
+            BNOK(bitnuc_allgatherv_words_all(P, ctxs.data(), comms.data(), counts.data(), alls.data(), &err)); // synchronises every stream
+            for (int r = 0; r < P; ++r) check(st[(size_t)r], r, round);
+        }
+        for (int r = 0; r < P; ++r) { teardown(st[(size_t)r]); bitnuc_comm_destroy(comms[(size_t)r]); bitnuc_ctx_destroy(ctxs[(size_t)r]); }
+    } else {
+        uint8_t id[BITNUC_UNIQUE_ID_BYTES];
+        BNOK(bitnuc_comm_get_unique_id(id, &err));
+        Barrier bar(P);
+        std::vector<std::thread> threads;
+        for (int r = 0; r < P; ++r)
+            threads.emplace_back([&, r] {
+                const int rank = r;
+                bitnuc_err err;
+                memset(&err, 0, sizeof err);
+                RankState st;
+                BNOK(bitnuc_ctx_create(0, &st.c, &err));
+                BNOK(bitnuc_comm_init_rank(st.c, P, r, id, &st.comm, &err));
+                setup(st, r);
+                for (int round = 0; round < rounds; ++round) {
+                    encode(st, r, round);
+                    BNOK(bitnuc_allgatherv_words_dev(st.c, st.comm, counts.data(), st.d_all, &err));
+                    if (round != rounds - 1 && rounds > 2) continue; // no host wait between rounds except where the result is checked
+                    BNOK(bitnuc_ctx_sync(st.c, &err));
+                    check(st, r, round);
+                    bar.wait(); // peers read this rank's slot out of d_all: nobody starts the next round's encode into it before all have checked
+                }
+                bar.wait();
+                teardown(st);
+                bitnuc_comm_destroy(st.comm);
+                bitnuc_ctx_destroy(st.c);
+            });
+        for (auto &t : threads) t.join();
+    }
+    uint64_t sends = 0, recvs = 0;
+    auto totals = reinterpret_cast<void (*)(uint64_t *, uint64_t *)>(dlsym(RTLD_DEFAULT, "mock_rccl_totals"));
+    totals(&sends, &recvs);
+    const bool bcast = getenv("BITNUC_GATHER_MODE") && !strcmp(getenv("BITNUC_GATHER_MODE"), "bcast");
+    const uint64_t want = (uint64_t)rounds * (uint64_t)nonempty * (uint64_t)(P - 1); // every non-empty rank sends its slot to every peer, nobody sends an empty one
+    if (!bcast && (sends != want || recvs != want)) { fprintf(stderr, "schedule: %llu sends / %llu receives, expected %llu each\n", (unsigned long long)sends, (unsigned long long)recvs, (unsigned long long)want); ++g_fail; }
+    if (g_fail.load()) { fprintf(stderr, "FAILED: %d complaint(s)\n", g_fail.load()); _exit(1); }
+    printf("ok ragged P=%d sequences=%zu bases=%zu words=%zu nonempty_ranks=%d mode=%s rounds=%d messages=%llu\n", P, nseq, total_bases, total_words, nonempty,
+           single_process ? "ragged_all" : "ragged", rounds, (unsigned long long)sends);
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
@@ -141,6 +293,17 @@ int main(int argc, char **argv) {
     const int rounds = atoi(argv[5]);
     const int bad_rank = argc > 7 ? atoi(argv[6]) : -1;
     const size_t bad_offset = argc > 7 ? strtoull(argv[7], nullptr, 10) : 0;
+    if (!strncmp(argv[4], "ragged", 6)) {
+        if (P < 1 || P > 16 || rounds < 1) return 2;
+        if (!dlsym(RTLD_DEFAULT, "mock_rccl_totals")) {
+            bitnuc_err e0;
+            uint8_t id0[BITNUC_UNIQUE_ID_BYTES];
+            (void)bitnuc_comm_get_unique_id(id0, &e0); // binds the RCCL stand-in
+        }
+        if (!dlsym(RTLD_DEFAULT, "mock_rccl_totals")) { fprintf(stderr, "this driver must run against tests/c/mock_rccl.cpp (LD_LIBRARY_PATH), not a real RCCL\n"); return 3; }
+        run_ragged(P, shard_len, (uint64_t)n_chunks, single_process, rounds);
+        return 0;
+    }
     if (P < 1 || P > 16 || shard_len % 32 || rounds < 1) return 2;
     const size_t count = shard_len / 32, total_words = count * (size_t)P;
 

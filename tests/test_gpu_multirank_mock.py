@@ -125,3 +125,29 @@ def test_single_process_all_reports_the_rank_of_an_invalid_byte(driver, mode):
 def test_single_process_all_fewer_words_than_pieces(driver):
     out = driver(4, 96, 8, "overlap_all", 2)
     assert "messages=%d" % (2 * 3 * 4 * 3) in out
+
+
+# ---- a ragged batch split by whole sequences + in-place gather of UNEQUAL word counts (SURVEY 8e sentence 2) ------------------------------
+@pytest.mark.parametrize("P", [2, 4, 8])
+@pytest.mark.parametrize("mode", ["ragged", "ragged_all"])
+def test_ragged_batch_whole_sequences_allgatherv(driver, P, mode):
+    """bitnuc_batch_shard_ranges -> per-rank bitnuc_batch_plan + bitnuc_encode_batch_plan_dev into the rank's slot ->
+    bitnuc_allgatherv_words_dev (threads, one per rank) / bitnuc_allgatherv_words_all (one thread): every rank's buffer == ONE context's
+    plan encode of the whole batch (which tests/test_gpu_parity.py pins to the oracle's per-sequence loop).  3000 reads of 0..399 bases
+    with empty sequences and one 200 000-base sequence (longer than a fair share: some rank is left with no sequence at P = 8); a rank
+    with an empty slot sends nothing: messages == rounds x non-empty ranks x (P - 1)."""
+    out = driver(P, 3000, 11, mode, 2)
+    assert "nonempty_ranks=" in out
+    driver(P, 5, 3, mode, 1)  # fewer sequences than ranks at P = 8
+
+
+@pytest.mark.parametrize("mode", ["ragged", "ragged_all"])
+def test_ragged_batch_slow_fabric_and_broadcast_exchange(driver, mode):
+    driver(4, 3000, 5, mode, 3, MOCK_RCCL_DELAY_US="2000")
+    driver(4, 3000, 5, mode, 2, BITNUC_GATHER_MODE="bcast")
+
+
+def test_ragged_batch_back_to_back_rounds(driver):
+    """Five rounds on the same buffers, new data each round, no host wait in between (per-rank form): round r+1's encode into a rank's slot
+    is ordered behind round r's sends from it by the context's stream."""
+    driver(4, 2000, 9, "ragged", 5)

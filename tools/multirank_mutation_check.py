@@ -34,7 +34,7 @@ MUT = {
     "E": ("            if (h == hipSuccess) h = hipStreamWaitEvent(comms[i]->xfer, comms[i]->piece_done[(size_t)p], 0);\n", ""),
     "F": ("            if (hipEventRecord(comms[i]->all_moved, comms[i]->xfer) == hipSuccess) (void)hipStreamWaitEvent(ctxs[i]->stream, comms[i]->all_moved, 0);", "            if (false) {}"),
     "G": ("uint64_t *theirs = d_alls[i] + (size_t)s * count + w0;", "uint64_t *theirs = d_alls[i] + (size_t)s * count + w0 + (s == 1 && p == 2 ? 1 : 0);"),
-    "H": ("bool per_rank_call_would_block(const bitnuc_comm *comm) { return comm->single_process && comm->nranks > 1; }", "bool per_rank_call_would_block(const bitnuc_comm *) { return false; }"),
+    "H": ("bool per_rank_call_would_block(const bitnuc_comm *comm) { return comm->single_process && !comm->threaded && comm->nranks > 1; }", "bool per_rank_call_would_block(const bitnuc_comm *) { return false; }"),
 }
 PER_RANK, ALL_RANKS = "ABCD", "EFGH"
 ODD, BIG = 32 * 100_003, 32 * 4_000_003
