@@ -30,14 +30,74 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: libbitnuc_hip.so cannot be built (there is no CPU fallback)")
 
 
-def csrc_sha16():
-    """Identity of the sources the library is compiled from (csrc/*.h, csrc/*.hip, csrc/evidence/*.h, include/bitnuc_hip.h): compiled into every
-    build as -DBITNUC_CSRC_SHA and returned by bitnuc_version(), so that a binary can be held against the sources beside it."""
+def code_only(text):
+    """C / C++ / HIP source text without what the compiler does not see: // and /* */ comments removed (string and character
+    literals kept intact), runs of blanks collapsed, blank lines dropped.  Line structure is kept (preprocessor directives end at
+    a newline), so moving code between lines still counts as a change -- only comments, indentation and blank lines do not."""
+    lines, cur, i, n = [], [], 0, len(text)  # cur: the pieces of the current line; blanks outside literals collapse as they arrive
+
+    def blank():
+        if cur and cur[-1] != " ":
+            cur.append(" ")
+
+    def newline():
+        while cur and cur[-1] == " ":
+            cur.pop()
+        if cur:
+            lines.append("".join(cur))
+        cur.clear()
+    while i < n:
+        c = text[i]
+        if c == "/" and i + 1 < n and text[i + 1] == "/":
+            j = text.find("\n", i)
+            while j != -1 and j > 0 and text[j - 1] == "\\":  # a line comment that ends in a backslash continues on the next line
+                j = text.find("\n", j + 1)
+            i = n if j == -1 else j
+        elif c == "/" and i + 1 < n and text[i + 1] == "*":
+            j = text.find("*/", i + 2)
+            blank()
+            i = n if j == -1 else j + 2
+        elif c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            cur.append(text[i:j + 1])  # a literal is code, blanks and all
+            i = j + 1
+        elif c == "\n":
+            newline()
+            i += 1
+        elif c in " \t\r\f\v":
+            blank()
+            i += 1
+        else:
+            cur.append(c)
+            i += 1
+    newline()
+    return "\n".join(lines)
+
+
+def identity_flags(extra_flags=(), sweep=False):
+    """The part of the command line that changes the code: folded into csrc_sha16 so that a library built with other flags (an ablation
+    -D, another optimisation level) is not taken for 'the sources' library' (ADVICE r4)."""
+    return sorted(CXXFLAGS + list(extra_flags) + (["-DBITNUC_SWEEP_VARIANTS"] if sweep else []))
+
+
+def csrc_sha16(extra_flags=(), sweep=None):
+    """Identity of what the library is compiled from: the CODE of csrc/*.h, csrc/*.hip, csrc/evidence/*.h and include/bitnuc_hip.h
+    (comments, indentation and blank lines do not count: code_only) + the compiler flags that change code (identity_flags; the
+    product and the evidence build share one identity: -DBITNUC_SWEEP_VARIANTS is reported by bitnuc_version() on its own).  Compiled
+    into every build as -DBITNUC_CSRC_SHA and returned by bitnuc_version(), so that a binary can be held against the sources beside
+    it -- and an edit to a comment leaves both the library and the profiles keyed by this hash (profiles/hbm_traffic.json) current."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "evidence", "*.h"))) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]:
-        h.update(os.path.basename(path).encode())
-        h.update(open(path, "rb").read())
+    try:
+        for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "evidence", "*.h"))) + [os.path.join(HERE, "..", "include", "bitnuc_hip.h")]:
+            h.update(os.path.basename(path).encode())
+            h.update(code_only(open(path, "r", encoding="utf-8", errors="surrogateescape").read()).encode("utf-8", errors="surrogateescape"))
+    except FileNotFoundError as e:
+        raise RuntimeError(f"bitnuc_amd: the library's identity needs the sources beside it, and {e.filename} is missing (a library built elsewhere -- a CMake or "
+                           "cargo build without -DBITNUC_CSRC_SHA -- is accepted with BITNUC_ALLOW_STALE_LIB=1)") from None
+    h.update(" ".join(identity_flags(extra_flags)).encode())
     return h.hexdigest()[:16]
 
 
@@ -75,7 +135,8 @@ def build_library(force=False, verbose=True, extra_flags=(), sweep=False, jobs=N
     if not force and not is_stale(lib):
         return lib
     hipcc = hipcc_path()
-    flags = CXXFLAGS + list(extra_flags) + (["-DBITNUC_SWEEP_VARIANTS"] if sweep else []) + [f'-DBITNUC_CSRC_SHA="{csrc_sha16()}"']
+    # (an experiment's flags are part of ITS identity: such a library never passes for the product's)
+    flags = CXXFLAGS + list(extra_flags) + (["-DBITNUC_SWEEP_VARIANTS"] if sweep else []) + [f'-DBITNUC_CSRC_SHA="{csrc_sha16(extra_flags)}"']
     if jobs is None:
         jobs = max(1, min(len(UNITS), len(os.sched_getaffinity(0))))
     tmp = f"{lib}.tmp.{os.getpid()}"  # other processes (bench ranks) only ever see a complete library

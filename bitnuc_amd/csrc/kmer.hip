@@ -153,10 +153,18 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
                        unsigned long long *slot) {
     uint32_t ql, qh;
     query_planes(query, k, &ql, &qh);
-    if (knobs(c).scan_impl == 7 && aligned16(ref) && aligned16(dist)) { // the contraction on the matrix cores (scan_mfma_device.h)
+    const bool al = aligned16(ref) && aligned16(dist);
+    if (knobs(c).scan_impl == 7 && al) { // the contraction on the matrix cores (scan_mfma_device.h): ships since round 5
         ScanMfmaTable tab;
         scan_mfma_table(query, k, &tab);
         const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+        if constexpr (!kEvidenceBuild) {
+            // the shipped form: one trip of 4 rounds per wave (the dispatcher walks the trips), one-hot operands through a wave-private
+            // LDS strip with the lane's own kept in registers, 2^23 bias + row scales for the byte pack, nt loads and stores
+            kmer_scan_mfma_kernel<3, 4, false, 1, 4, false><<<scan_mfma_grid(c, rounds, 4, false), kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, 0u, dist, nullptr, nullptr, nullptr, slot, tab);
+            return hipGetLastError();
+        }
+#ifdef BITNUC_SWEEP_VARIANTS
         const int U = knobs(c).scan_mfma_unroll, pack = knobs(c).scan_mfma_pack, shift = knobs(c).scan_mfma_shift;
         const bool persist = knobs(c).scan_mfma_persist != 0, ntld = (knobs(c).scan_mfma_policy & 1) != 0;
         const unsigned grid = scan_mfma_grid(c, rounds, U, persist);
@@ -174,16 +182,9 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
 #undef SCANM_PS
 #undef SCANM
         return hipGetLastError();
+#endif
     }
     const int unroll = knobs(c).scan_unroll, kb = knobs(c).kmer_block;
-    const bool al = aligned16(ref) && aligned16(dist);
-    // the shipped form: line-aligned rounds of 1024 windows, one trip of 4 rounds per wave, two-LUT plane build + scalar halo (GEN 1)
-    if (al && (!kEvidenceBuild || (knobs(c).scan_impl == 1 && unroll == 4 && knobs(c).scan_policy == 3 && kb == kBlock))) {
-        const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
-        const unsigned grid = grid_for(c, rounds / ((kBlock / 64) * 4) + 1, kBlock);
-        kmer_scan2_kernel<true, true, true, 4, false, 1><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, 0u, dist, nullptr, nullptr, nullptr, slot);
-        return hipGetLastError();
-    }
 #ifdef BITNUC_SWEEP_VARIANTS
     if (knobs(c).scan_impl >= 2 && knobs(c).scan_impl <= 5 && al) { // line-aligned rounds, a wave owns consecutive rounds and carries the halo planes (kmer_scan3_kernel)
         const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
@@ -195,6 +196,15 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
 #define SCAN3(CC) kmer_scan3_kernel<true, true, 4, CC><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, dist, slot)
         if (C == 12) SCAN3(12); else if (C == 20) SCAN3(20); else if (C == 16) SCAN3(16); else SCAN3(32);
 #undef SCAN3
+        return hipGetLastError();
+    }
+#endif
+#ifdef BITNUC_SWEEP_VARIANTS
+    // rounds 2-4's bit-plane scan (v_alignbit + v_bcnt per window: VALU-issue bound, profiles/r05_ab_scan_mfma*.txt): evidence build
+    if (al && knobs(c).scan_impl == 1 && unroll == 4 && knobs(c).scan_policy == 3 && kb == kBlock) { // GEN 1 (two-LUT planes + scalar halo), what round 4 shipped
+        const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+        const unsigned grid = grid_for(c, rounds / ((kBlock / 64) * 4) + 1, kBlock);
+        kmer_scan2_kernel<true, true, true, 4, false, 1><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, ql, qh, 0u, dist, nullptr, nullptr, nullptr, slot);
         return hipGetLastError();
     }
 #endif
@@ -371,8 +381,14 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
     if (knobs(c).scan_impl == 7 && aligned16(d_ref)) {
         ScanMfmaTable tab;
         scan_mfma_table(query, k, &tab);
+        if constexpr (!kEvidenceBuild) { // the shipped form: a resident grid (one arrival per workgroup at the ticket), next trip's loads issued before the current one is computed
+            kmer_scan_mfma_kernel<1, 4, true, 0, 4, true><<<scan_mfma_grid(c, rounds, 4, true), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot, tab);
+            HIPCHK(hipGetLastError());
+            return BITNUC_OK;
+        }
+#ifdef BITNUC_SWEEP_VARIANTS
         const int U = knobs(c).scan_mfma_unroll, shift = knobs(c).scan_mfma_shift;
-        const unsigned g = scan_mfma_grid(c, rounds, U, true); // a resident grid: the ticket needs every workgroup to arrive
+        const unsigned g = scan_mfma_grid(c, rounds, U, true);
         const bool nt = (knobs(c).scan_mfma_policy & 1) != 0;
 #define COUNTM(P, UU, SH) kmer_scan_mfma_kernel<P, UU, true, 0, SH, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot, tab)
 #define COUNTM_NT(UU, SH) do { if (nt) COUNTM(1, UU, SH); else COUNTM(0, UU, SH); } while (0)
@@ -383,9 +399,17 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
 #undef COUNTM
         HIPCHK(hipGetLastError());
         return BITNUC_OK;
+#endif
     }
-    if (aligned16(d_ref)) kmer_scan2_kernel<true, true, false, 4, true, 1><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
-    else kmer_scan2_kernel<false, false, false, 1, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
+#ifdef BITNUC_SWEEP_VARIANTS
+    if (aligned16(d_ref)) { // round 4's fused count on the bit-plane scan (0.33 ms per 10^9 windows against the matrix-core form's 0.20): evidence build
+        kmer_scan2_kernel<true, true, false, 4, true, 1><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
+        HIPCHK(hipGetLastError());
+        return BITNUC_OK;
+    }
+#endif
+    // unaligned reference pointer: the bit-plane scan with unaligned 16-byte loads
+    kmer_scan2_kernel<false, false, false, 1, true><<<grid, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, ql, qh, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot);
     HIPCHK(hipGetLastError());
     return BITNUC_OK;
 }

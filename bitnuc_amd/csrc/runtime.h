@@ -47,12 +47,15 @@ struct SweepKnobs {
     int kmer_block = 256;        // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;        // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;         // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
-    int scan_impl = 1;           // 1 = line-aligned rounds of 1024 windows, two-LUT planes + scalar halo (kmer_scan2_kernel GEN 1: ships), 6 = the same with rounds 2-3's plane build (GEN 0),
-                                 // 0 = rounds of 992 windows (kmer_scan_kernel), 2 / 3 / 4 / 5 = kmer_scan3_kernel (a wave owns 12 / 20 / 16 / 32 consecutive rounds: slower, profiles/r04_ab_scan3.txt)
+    int scan_impl = 7;           // 7 = the one-hot contraction on the matrix cores (kmer_scan_mfma_kernel: ships since round 5, profiles/r05_ab_scan_mfma*.txt);
+                                 // the bit-plane forms (v_alignbit + v_bcnt per window, VALU-issue bound): 1 = line-aligned rounds of 1024 windows, two-LUT planes + scalar halo
+                                 // (kmer_scan2_kernel GEN 1: shipped in round 4), 6 = the same with rounds 2-3's plane build (GEN 0), 0 = rounds of 992 windows (kmer_scan_kernel),
+                                 // 2 / 3 / 4 / 5 = kmer_scan3_kernel (a wave owns 12 / 20 / 16 / 32 consecutive rounds: slower, profiles/r04_ab_scan3.txt)
     int scan_mfma_unroll = 4;    // kmer_scan_mfma_kernel: consecutive 1 KiB rounds per wave trip: 2 or 4
     int scan_mfma_grid = 4;      // ... persistent form: resident 256-thread workgroups per CU
     int scan_mfma_policy = 3;    // ... bit 0: nt loads (stores are nt)
-    int scan_mfma_shift = 1;     // ... the shifted operands: 0 = two more global loads, 1 = wave-private LDS strip, 2 = DPP + scalar halo
+    int scan_mfma_shift = 4;     // ... the shifted operands: 0 = two more global loads, 1 = the bytes through a wave-private LDS strip, 2 = DPP + scalar halo,
+                                 //     3 = the one-hot operands through the strip, 4 = ... with the lane's own operands kept in registers (ships)
     int scan_mfma_persist = 0;   // ... 1 = a resident grid walks the trips with register prefetch, 0 = one trip per wave
     int scan_mfma_pack = 1;      // ... f32 -> u8: 0 = v_cvt_pk_u8_f32, 1 = 2^23 bias + row scales (copied), 2 = ... (bias by a seventh instruction)
     int hdist_tiled = 0;         // bulk hdist: 1 = grid-stride at tile granularity (16 KiB of each operand per workgroup trip), 0 = at thread granularity

@@ -166,7 +166,6 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
     const i32x8 bias_a = {lane < 32 ? 2 : 0, 0, 0, 0, 0, 0, 0, 0};                                   // PACK 2: nibble 0 of K-block 0 = 1.0, every row
     const i32x8 bias_b = {0x22222222, 0x22222222, 0x22222222, 0x22222222, 0, 0, 0, 0};              // ... x ones, scale 2^23
     const float tauf = (float)tau;
-    const unsigned nsteps = (15u + k + 7u) >> 3; // 8-position K-steps that hold a position some window needs: 15 + k positions (6 for k >= 26, 2 for k = 1)
     const uint32_t m63 = lane == 63 ? ~0u : 0u;
     uint32_t hits = 0; // COUNT: wave-uniform until the tail
 
@@ -215,15 +214,13 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
 #pragma unroll
                 for (int s6 = 0; s6 < 6; ++s6) {
                     if (KEEP && s6 < 2) { B[s6] = own[KEEP ? u : 0][s6]; continue; }
-                    if (s6 >= (int)nsteps) { B[s6] = i32x8{0, 0, 0, 0, 0, 0, 0, 0}; continue; } // wave-uniform
                     const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + (s6 & 1) * kPlane + 1024 * u + 16 * lane + 16 * (s6 >> 1));
                     B[s6] = i32x8{(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
                 }
                 f32x16 acc = c0;
                 if constexpr (BIAS && PACK == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bias_a, bias_b, c0, 4, 4, 0, 127 + 23, 0, 127);
 #pragma unroll
-                for (int s6 = 0; s6 < 6; ++s6)
-                    if (s6 < 2 || s6 < (int)nsteps) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[s6], B[s6], acc, 4, 4, 0, scale_a, 0, 127);
+                for (int s6 = 0; s6 < 6; ++s6) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[s6], B[s6], acc, 4, 4, 0, scale_a, 0, 127);
                 scan_mfma_emit<COUNT, PACK, NTST>(acc, tauf, hits, dist + wb + 16 * lane);
                 continue;
             }

@@ -148,7 +148,9 @@ std::vector<uint64_t> ragged_offsets(size_t nseq, uint64_t seed) {
     return off;
 }
 
-void run_ragged(int P, size_t nseq, uint64_t seed, bool single_process, int rounds) {
+// threaded_all: the communicators come from bitnuc_comm_init_all_devices but every rank gets its own thread (ordinary NCCL usage): after
+// bitnuc_comm_set_threaded(comm, 1) the per-rank entry points accept them and the _all forms refuse them
+void run_ragged(int P, size_t nseq, uint64_t seed, bool single_process, int rounds, bool threaded_all = false) {
     int rank = -1;
     bitnuc_err err;
     memset(&err, 0, sizeof err);
@@ -244,6 +246,16 @@ void run_ragged(int P, size_t nseq, uint64_t seed, bool single_process, int roun
     } else {
         uint8_t id[BITNUC_UNIQUE_ID_BYTES];
         BNOK(bitnuc_comm_get_unique_id(id, &err));
+        std::vector<bitnuc_ctx *> all_ctxs((size_t)P, nullptr);
+        std::vector<bitnuc_comm *> all_comms((size_t)P, nullptr);
+        if (threaded_all) {
+            std::vector<int> devs((size_t)P, 0);
+            BNOK(bitnuc_comm_init_all_devices(P, devs.data(), all_ctxs.data(), all_comms.data(), &err));
+            for (int r = 0; r < P; ++r)
+                if (bitnuc_comm_set_threaded(all_comms[(size_t)r], 1) != 0 || bitnuc_comm_set_threaded(all_comms[(size_t)r], 1) != 1) complain(r, "bitnuc_comm_set_threaded does not return the previous setting");
+            std::vector<uint64_t *> none((size_t)P, nullptr);
+            if (P > 1 && bitnuc_allgatherv_words_all(P, all_ctxs.data(), all_comms.data(), counts.data(), none.data(), &err) != BITNUC_UNSUPPORTED) complain(-1, "_all form accepted communicators that were declared thread-per-rank");
+        }
         Barrier bar(P);
         std::vector<std::thread> threads;
         for (int r = 0; r < P; ++r)
@@ -252,8 +264,11 @@ void run_ragged(int P, size_t nseq, uint64_t seed, bool single_process, int roun
                 bitnuc_err err;
                 memset(&err, 0, sizeof err);
                 RankState st;
-                BNOK(bitnuc_ctx_create(0, &st.c, &err));
-                BNOK(bitnuc_comm_init_rank(st.c, P, r, id, &st.comm, &err));
+                if (threaded_all) { st.c = all_ctxs[(size_t)r]; st.comm = all_comms[(size_t)r]; }
+                else {
+                    BNOK(bitnuc_ctx_create(0, &st.c, &err));
+                    BNOK(bitnuc_comm_init_rank(st.c, P, r, id, &st.comm, &err));
+                }
                 setup(st, r);
                 for (int round = 0; round < rounds; ++round) {
                     encode(st, r, round);
@@ -278,7 +293,7 @@ void run_ragged(int P, size_t nseq, uint64_t seed, bool single_process, int roun
     if (!bcast && (sends != want || recvs != want)) { fprintf(stderr, "schedule: %llu sends / %llu receives, expected %llu each\n", (unsigned long long)sends, (unsigned long long)recvs, (unsigned long long)want); ++g_fail; }
     if (g_fail.load()) { fprintf(stderr, "FAILED: %d complaint(s)\n", g_fail.load()); _exit(1); }
     printf("ok ragged P=%d sequences=%zu bases=%zu words=%zu nonempty_ranks=%d mode=%s rounds=%d messages=%llu\n", P, nseq, total_bases, total_words, nonempty,
-           single_process ? "ragged_all" : "ragged", rounds, (unsigned long long)sends);
+           single_process ? "ragged_all" : threaded_all ? "ragged_threaded" : "ragged", rounds, (unsigned long long)sends);
 }
 
 } // namespace
@@ -301,7 +316,7 @@ int main(int argc, char **argv) {
             (void)bitnuc_comm_get_unique_id(id0, &e0); // binds the RCCL stand-in
         }
         if (!dlsym(RTLD_DEFAULT, "mock_rccl_totals")) { fprintf(stderr, "this driver must run against tests/c/mock_rccl.cpp (LD_LIBRARY_PATH), not a real RCCL\n"); return 3; }
-        run_ragged(P, shard_len, (uint64_t)n_chunks, single_process, rounds);
+        run_ragged(P, shard_len, (uint64_t)n_chunks, single_process, rounds, !strcmp(argv[4], "ragged_threaded"));
         return 0;
     }
     if (P < 1 || P > 16 || shard_len % 32 || rounds < 1) return 2;

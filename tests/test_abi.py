@@ -85,6 +85,45 @@ def test_a_stale_library_is_refused_and_rebuilt(tmp_path, monkeypatch):
         build.ensure_built(build=False, lib=missing)
 
 
+def test_identity_ignores_comments_and_blank_lines_but_not_code(tmp_path, monkeypatch):
+    """csrc_sha16 hashes the CODE (build.code_only): a planted comment, re-indentation or blank line leaves the library current (and
+    profiles/hbm_traffic.json valid); a planted `+ 0`, a changed string literal or another code-changing compiler flag does not."""
+    import shutil
+    from bitnuc_amd import build
+    work = tmp_path / "pkg"
+    shutil.copytree(build.CSRC, work / "bitnuc_amd" / "csrc")
+    shutil.copytree(os.path.join(ROOT, "include"), work / "include")
+    monkeypatch.setattr(build, "CSRC", str(work / "bitnuc_amd" / "csrc"))
+    monkeypatch.setattr(build, "HERE", str(work / "bitnuc_amd"))
+    base = build.csrc_sha16()
+    assert base == build.library_sha16(build.LIB) or build.is_stale(build.LIB)  # (the copy hashes like the tree it was copied from)
+    f = work / "bitnuc_amd" / "csrc" / "device_prims.h"
+    orig = f.read_text()
+    marker = "    return (bad & 0xFCFCFCFCu) != 0u;" if "    return (bad & 0xFCFCFCFCu) != 0u;" in orig else None
+    anchor = "__device__ __forceinline__ bool residue_is_bad(uint32_t bad) { return (bad & 0xFCFCFCFCu) != 0u; }"
+    assert anchor in orig
+    for harmless in (orig.replace(anchor, anchor + "  // a remark"), orig.replace(anchor, "/* a block\n   comment */\n" + anchor),
+                     orig.replace(anchor, "\n\n    " + anchor.replace("{ return", "{   return")), "// leading comment\n" + orig):
+        f.write_text(harmless)
+        assert build.csrc_sha16() == base
+    for change in (orig.replace("(bad & 0xFCFCFCFCu) != 0u", "(bad & 0xFCFCFCFCu) + 0 != 0u"), orig.replace("0xFCFCFCFCu", "0xFCFCFCFDu")):
+        assert change != orig
+        f.write_text(change)
+        assert build.csrc_sha16() != base
+    f.write_text(orig)
+    g = work / "bitnuc_amd" / "csrc" / "runtime.hip"
+    text = g.read_text()
+    assert '"bitnuc_hip ' in text
+    g.write_text(text.replace('"bitnuc_hip ', '"bitnuc_hip  ', 1))  # inside a string literal: code
+    assert build.csrc_sha16() != base
+    g.write_text(text)
+    assert build.csrc_sha16() == base
+    assert build.csrc_sha16(extra_flags=["-DSOME_ABLATION=1"]) != base  # a library built with other flags is not the sources' library
+    # literals survive the comment stripper
+    assert build.code_only('a = "// no /* comment */"; // c\nb = \'"\'; /* x */ c') == 'a = "// no /* comment */";\nb = \'"\'; c'
+    del marker
+
+
 def test_product_library_holds_no_evidence_kernels():
     """The kernels that lost their A/B live in bitnuc_amd/csrc/evidence/*.h, which the kernel headers include only under
     -DBITNUC_SWEEP_VARIANTS: the product library must not contain one of them (the evidence build must contain all of them)."""
@@ -98,6 +137,9 @@ def test_product_library_holds_no_evidence_kernels():
             "decode_fixed_strip_kernel", "decode_batch_plan_lines_kernel", "kmer_scan3_kernel", "probe_win_shape_kernel"} <= names, names
     product = subprocess.run(["nm", "-C", build.ensure_built()], capture_output=True, text=True).stdout
     assert "encode_kernel" in product and "kmer_scan2_kernel" in product
+    # the matrix-core scan ships in exactly two instantiations (distance bytes: one trip per wave; fused count: resident grid); its other
+    # operand / pack / trip forms are evidence
+    assert set(re.findall(r"kmer_scan_mfma_kernel<([^>]*)>", product)) == {"3, 4, false, 1, 4, false", "1, 4, true, 0, 4, true"}
     leaked = [n for n in names if n + "<" in product or n + "(" in product]
     assert not leaked, leaked
     if os.path.exists(build.LIB_SWEEP) and not build.is_stale(build.LIB_SWEEP):

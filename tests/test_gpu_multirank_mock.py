@@ -147,6 +147,13 @@ def test_ragged_batch_slow_fabric_and_broadcast_exchange(driver, mode):
     driver(4, 3000, 5, mode, 2, BITNUC_GATHER_MODE="bcast")
 
 
+def test_init_all_communicators_driven_by_one_thread_per_rank(driver):
+    """bitnuc_comm_set_threaded: communicators made by bitnuc_comm_init_all_devices whose ranks each get their own host thread (ordinary
+    NCCL usage) -- the per-rank entry points accept them after the declaration, the _all forms refuse them."""
+    driver(4, 3000, 7, "ragged_threaded", 2)
+    driver(8, 300, 2, "ragged_threaded", 1)
+
+
 def test_ragged_batch_back_to_back_rounds(driver):
     """Five rounds on the same buffers, new data each round, no host wait in between (per-rank form): round r+1's encode into a rank's slot
     is ordered behind round r's sends from it by the context's stream."""

@@ -156,7 +156,8 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     assert all(ctx.set_variant("decode", v) == -2 for v in range(47, 56)) and ctx.get("decode") == 22  # decode_x2_kernel: evidence build
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
-                                 ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 1, (0, 2, 6)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
+                                 ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 7, (0, 1, 2, 6)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
+                                 ("scan_mfma_shift", 4, (0, 1, 2, 3)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2,)), ("scan_mfma_persist", 0, (1,)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,)),
                                  ("batch_dense", 1, (0,)), ("batch_slide", 1, (0,)), ("batch_host_plan", 1, (0,)), ("fixed_stream", 1, (0,)), ("owner_est", 3, (0, 1, 2)),
                                  ("plan_enc_block", 256, (64, 128)), ("kmer_block", 256, (64, 128)), ("hdist_tiled", 0, (1,)), ("hdist_words_impl", 1, (0,)),
@@ -490,27 +491,85 @@ def test_kmer_batch_errors(ctx, oracle):
     assert np.array_equal(ctx.as_2bit_batch(b"", 0, 1, 5), np.zeros(5, np.uint64))
 
 
-# (scan_impl, scan_unroll): 1 = line-aligned rounds of 1024 windows (ships at unroll 4 as GEN 1; other trip lengths use rounds 2-3's plane build),
-# 6 = that plane build at the shipped trip length, 0 = rounds of 992 windows, 2 / 3 / 4 = kmer_scan3_kernel with 12 / 20 / 16 rounds per wave
-SCAN_FORMS = [(1, 4), (1, 2), (1, 1), (6, 4), (0, 4), (0, 2), (0, 1), (2, 4), (3, 4), (4, 4)]
+# Forms of the config-5 scan.  "ships" runs on the PRODUCT library: the one-hot contraction on the matrix cores (scan_impl 7: one-hot operands
+# through a wave-private LDS strip, the lane's own kept in registers, one trip of 4 rounds per wave).  The others live in the evidence build: the
+# matrix-core form's alternatives (shift: 0 global re-loads, 1 bytes through the strip, 2 DPP, 3 all six operands through the strip; pack: 0
+# v_cvt_pk_u8, 2 bias by a seventh instruction; trips of 2 rounds; a resident grid) and rounds 1-4's bit-plane forms (scan_impl, scan_unroll):
+# 1 = line-aligned rounds of 1024 windows (GEN 1 at unroll 4: shipped in round 4), 6 = rounds 2-3's plane build, 0 = rounds of 992 windows,
+# 2 / 3 / 4 = kmer_scan3_kernel with 12 / 20 / 16 rounds per wave.
+SCAN_FORMS = [("ships", {})] + \
+    [(f"mfma-shift{sh}-pack{pk}-U{u}-persist{ps}", dict(scan_mfma_shift=sh, scan_mfma_pack=pk, scan_mfma_unroll=u, scan_mfma_persist=ps))
+     for sh, pk, u, ps in ((4, 1, 4, 1), (4, 0, 2, 0), (4, 2, 4, 0), (3, 1, 4, 0), (3, 0, 2, 1), (1, 1, 4, 0), (1, 2, 2, 1), (2, 1, 4, 0), (2, 0, 2, 1), (0, 1, 2, 1), (0, 0, 2, 0))] + \
+    [(f"bitplane-impl{i}-unroll{u}", dict(scan_impl=i, scan_unroll=u)) for i, u in ((1, 4), (1, 2), (1, 1), (6, 4), (0, 4), (0, 2), (0, 1), (2, 4), (3, 4), (4, 4))]
+SCAN_DEFAULTS = dict(scan_impl=7, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0)
 
 
-@pytest.mark.parametrize("impl,unroll", SCAN_FORMS, ids=[f"impl{i}-unroll{u}" for i, u in SCAN_FORMS])
+@pytest.mark.parametrize("form", SCAN_FORMS, ids=[name for name, _ in SCAN_FORMS])
 @pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 32])
-def test_scan_vs_oracle(ctx, sweep_ctx, oracle, k, unroll, impl):
-    if (impl, unroll) != (1, 4):
+def test_scan_vs_oracle(ctx, sweep_ctx, oracle, k, form):
+    name, knobs = form
+    if knobs:
         ctx = sweep_ctx  # the product ships only the form in use; the alternatives live in the evidence build
-    prev_impl = ctx.set_variant("scan_impl", impl)
-    ctx.set_variant("scan_unroll", unroll)
-    # (12 / 16 / 20 rounds per wave: sizes around one and two chunks as well)
-    for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 1057, 2015, 2016, 2017, 2047, 2048, 2079, 2080, 2081, 4127, 4128, 4129, 5000, 5152,
-              12 * 1024 + 31, 12 * 1024 + 32, 12 * 1024 + 33, 16 * 1024 + 31, 16 * 1024 + 32, 16 * 1024 + 33, 17 * 1024 + 32, 20 * 1024 + 32, 20 * 1024 + 33, 24 * 1024 + 33, 32 * 1024 + 31, 32 * 1024 + 32, 32 * 1024 + 33, 33 * 1024 + 40, 64 * 1024 + 32, 65 * 1024 + 100, 200003]:
-        s = rand_seq(n)
-        q = int(RNG.integers(0, 1 << 62)) | (int(RNG.integers(0, 4)) << 62)
-        got = ctx.kmer_hdist_scan(s, k, q)
-        assert np.array_equal(got, oracle.kmer_hdist_scan(s, k, q)), (k, n)
-    ctx.set_variant("scan_unroll", 4)
-    ctx.set_variant("scan_impl", prev_impl)
+        for key, v in {**SCAN_DEFAULTS, **knobs}.items():
+            ctx.require_variant(key, v)
+    else:
+        assert ctx.get("sweep_build") == 0 and ctx.get("scan_impl") == 7
+    try:
+        # (12 / 16 / 20 rounds per wave: sizes around one and two chunks as well; 4 rounds per trip: around 4 KiB + the 32-byte halo)
+        for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 1057, 2015, 2016, 2017, 2047, 2048, 2079, 2080, 2081, 3103, 3104, 3105, 4127, 4128, 4129, 5000, 5152, 5153,
+                  12 * 1024 + 31, 12 * 1024 + 32, 12 * 1024 + 33, 16 * 1024 + 31, 16 * 1024 + 32, 16 * 1024 + 33, 17 * 1024 + 32, 20 * 1024 + 32, 20 * 1024 + 33, 24 * 1024 + 33, 32 * 1024 + 31, 32 * 1024 + 32, 32 * 1024 + 33, 33 * 1024 + 40, 64 * 1024 + 32, 65 * 1024 + 100, 200003]:
+            s = rand_seq(n)
+            q = int(RNG.integers(0, 1 << 62)) | (int(RNG.integers(0, 4)) << 62)
+            got = ctx.kmer_hdist_scan(s, k, q)
+            assert np.array_equal(got, oracle.kmer_hdist_scan(s, k, q)), (k, n)
+    finally:
+        if knobs:
+            for key, v in SCAN_DEFAULTS.items():
+                ctx.require_variant(key, v)
+
+
+@pytest.mark.parametrize("form", [f for f in SCAN_FORMS if f[0] == "ships" or f[0].startswith("mfma")][:9], ids=[name for name, _ in SCAN_FORMS if name == "ships" or name.startswith("mfma")][:9])
+def test_scan_matrix_core_forms_first_invalid_byte_and_count(ctx, sweep_ctx, oracle, form):
+    """kmer_scan_mfma_kernel: the first invalid byte wins at round, trip and strip boundaries and inside the halo (a later invalid byte never
+    does, a byte after the last window is never examined: hamming/scalar.rs:11-48 over naive.rs:3-20 per window); bytes past the last window are
+    not written; the fused count (bitnuc_kmer_hdist_count_dev) of every form equals the count over the oracle's distance bytes."""
+    import bitnuc_amd as bn
+    import torch
+    name, knobs = form
+    if knobs:
+        ctx = sweep_ctx
+        for key, v in {**SCAN_DEFAULTS, **knobs}.items():
+            ctx.require_variant(key, v)
+    try:
+        rng = np.random.default_rng(505)
+        n = 9 * 1024 + 77
+        s = ALPHA8[rng.integers(0, 8, size=n)].copy()
+        k, q = 31, 0x0123456789ABCDEF & ((1 << 62) - 1)
+        for pos in (0, 15, 16, 1023, 1024, 1025, 1039, 1040, 1055, 1056, 2047, 2048, 4095, 4096, 4097, 4 * 1024 + 31, 4 * 1024 + 32, 8 * 1024 - 1, 8 * 1024, 8 * 1024 + 33, n - k - 1, n - 1):
+            t = s.copy()
+            t[pos] = ord("N")
+            if pos + 9 < n:
+                t[pos + 9] = ord("X")  # a later invalid byte never wins
+            with pytest.raises(bn.NucleotideError) as ei:
+                ctx.kmer_hdist_scan(t, k, q)
+            assert (ei.value.byte, ei.value.index) == (ord("N"), pos), pos
+        dev = torch.device("cuda:0")
+        for m in (k, 1056, 1057, 4128, 4129, n):
+            tt = torch.from_numpy(s[:m]).to(dev)
+            d = torch.full((m + 64,), 0xEE, dtype=torch.uint8, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            ctx.kmer_hdist_scan_dev(tt, m, k, q, d)
+            ctx.kmer_hdist_count_dev(tt, m, k, q, 22, cnt)
+            ctx.sync()
+            want = oracle.kmer_hdist_scan(s[:m], k, q)
+            got = d.cpu().numpy()
+            assert np.array_equal(got[:m - k + 1], want) and bool((got[m - k + 1:] == 0xEE).all()), m
+            assert int(cnt.item()) == int((want <= 22).sum()), m
+    finally:
+        if knobs:
+            for key, v in SCAN_DEFAULTS.items():
+                ctx.require_variant(key, v)
 
 
 def test_scan_fused_threshold_count(ctx, oracle):
