@@ -210,6 +210,40 @@ def stored_traffic():
             "encode_kernel": round(t["encode_bytes_per_launch"]), "decode_kernel": round(t["decode_bytes_per_launch"])}
 
 
+def generator_words(torch, first_word, count, seed, dev):
+    """Closed form of the packed words of the seeded stream (bitnuc_nucgen_dev: base(i) is 2-bit field i % 32 of
+    splitmix64(seed + (i / 32 + 1) * 0x9E3779B97F4A7C15), so the generator's words ARE the packed words of upper-case input):
+    words [first_word, first_word + count) as int64, computed with torch integer arithmetic -- independent of the library."""
+    idx = torch.arange(first_word + 1, first_word + count + 1, dtype=torch.int64, device=dev)
+    z = idx * (-7046029254386353131) + seed  # 0x9E3779B97F4A7C15 as i64, wraps mod 2^64
+
+    def lsr(x, sh):
+        return (x >> sh) & ((1 << (64 - sh)) - 1)
+    z = (z ^ lsr(z, 30)) * (-4658895280553007687)   # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * (-7723592293110705685)   # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+def all_slots_check(torch, full, lw, world, slot_first_word, seed, rehearse=False, chunk=1 << 22):
+    """Config 4's result held against what it must be, EVERY slot of the gathered buffer (not this rank's own, not one run against
+    another): slot s = the lw packed words of rank s's shard = the generator's closed form from word slot_first_word(s) on
+    (rehearsal without a GPU: arange(lw) + s).  Returns {"all_slots_ok": bool, "first_bad_slot": s or None}."""
+    for s_ in range(world):
+        part = full[s_ * lw:(s_ + 1) * lw]
+        if rehearse:
+            good = bool(torch.equal(part, torch.arange(lw, dtype=part.dtype, device=part.device) + s_))
+        else:
+            good = True
+            for a in range(0, lw, chunk):
+                b = min(lw, a + chunk)
+                if not torch.equal(part[a:b], generator_words(torch, slot_first_word(s_) + a, b - a, seed, part.device)):
+                    good = False
+                    break
+        if not good:
+            return {"all_slots_ok": False, "first_bad_slot": s_}
+    return {"all_slots_ok": True, "first_bad_slot": None}
+
+
 def carve_buffers(torch, dev, n, nw, R, separate):
     """The R rotating buffer sets (ASCII in, packed words, ASCII out).  Default: ONE allocation, every buffer at a 2 MiB boundary --
     how a resident pipeline lays its buffers out, and what makes the codec's per-launch time independent of where an allocator
@@ -698,9 +732,22 @@ def run_rank(args, real_stdout, traffic):
             fence()
             ag = (time.perf_counter() - t) / reps
             ok = bool(torch.equal(full[rank * lw:(rank + 1) * lw], local))
+            # every slot against the closed form of the seeded stream (rank s's shard starts at base s * n, word s * n / 32)
+            closed_form = rehearse or n % 32 == 0
+
+            def slots(buf, words_per_slot):
+                if not closed_form:
+                    return {"all_slots_ok": None, "reason": "--bases is not a multiple of 32: the shards do not start at word boundaries of the seeded stream"}
+                return all_slots_check(torch, buf, words_per_slot, world, lambda s_: s_ * (n // 32), SEED, rehearse=rehearse)
+            if os.environ.get("BITNUC_BENCH_PLANT_BAD_SLOT") and world > 1:  # test hook: a wrong word in a PEER's slot must fail the run
+                peer = (rank + 1) % world
+                full[peer * lw + lw // 2] ^= 1
+            chk = slots(full, lw)
             del full
+            if chk["all_slots_ok"] is False:
+                state["rc"] = 3  # the gather delivered something else than the shards' packed words: not a measurement
             extra["allgather_packed"] = {"ms": round(ag * 1e3, 3), "bytes_received_per_gpu": lw * 8 * (world - 1),
-                                         "gb_s_per_gpu": round(lw * 8 * (world - 1) / ag / 1e9, 2), "own_slot_ok": ok, "backend": control_backend,
+                                         "gb_s_per_gpu": round(lw * 8 * (world - 1) / ag / 1e9, 2), "own_slot_ok": ok, **chk, "backend": control_backend,
                                          "note": "all-gather of the packed u64 buffer (RCCL over xGMI when backend is nccl); fabric-bound, outside the timed step"}
             if on_gpu_collectives:
                 # encode + concatenation end to end, one shot vs chunked overlap (8 pieces: the
@@ -718,15 +765,18 @@ def run_rank(args, real_stdout, traffic):
                     for _ in range(reps):
                         full = fn()
                     fence()
-                    return round((time.perf_counter() - t) / reps * 1e3, 3), bool(torch.equal(full, ref_full))
+                    chk2 = slots(full, nw)
+                    if chk2["all_slots_ok"] is False:
+                        state["rc"] = 3
+                    return round((time.perf_counter() - t) / reps * 1e3, 3), bool(torch.equal(full, ref_full)) and chk2["all_slots_ok"] is not False, chk2["all_slots_ok"]
                 e2e = {}
-                e2e["one_shot_ms"], e2e["one_shot_ok"] = timed_e2e(one_shot)
+                e2e["one_shot_ms"], e2e["one_shot_ok"], e2e["one_shot_all_slots_ok"] = timed_e2e(one_shot)
                 # the chunked in-place exchange rides on batched point-to-point operations: newer than the plain all-gather above, so it
                 # is a SOFT block -- a thread with a bounded wait; if it never returns the line says so and the headline stands
                 ov = bounded("encode_allgather_end_to_end.overlap8", lambda: timed_e2e(lambda: encode_allgather_overlapped(enc_chunk, nw, 8, words[0], group=ctl)),
                              min(args.dist_timeout, 150.0), state, torch, dev)
                 if isinstance(ov, tuple):
-                    e2e["overlap8_ms"], e2e["overlap8_ok"] = ov
+                    e2e["overlap8_ms"], e2e["overlap8_ok"], e2e["overlap8_all_slots_ok"] = ov
                 else:
                     e2e["overlap8"] = ov
                 e2e["note"] = ("encode of this rank's 10^9-base shard + all-gather of the packed words; fabric-bound, so it cannot scale like the step; "
@@ -871,6 +921,14 @@ def c_abi_allgather_block(args, ctx, torch, dist, rank, world, seq, n, state):
                 dist.barrier()
                 res[name + "_ms"] = round((time.perf_counter() - t) / reps * 1e3, 3)
             res["overlap_equals_one_shot"] = bool(torch.equal(one, two))
+            # ... and both against the closed form of the seeded stream, every rank's slot (rank s's shard = words s * n / 32 ...)
+            if n % 32 == 0:
+                for name, buf in (("one_shot", one), ("overlap8", two)):
+                    chk = all_slots_check(torch, buf, cnt, world, lambda s_: s_ * (n // 32), SEED)
+                    res[name + "_all_slots_ok"] = chk["all_slots_ok"]
+                    if not chk["all_slots_ok"]:
+                        res[name + "_first_bad_slot"] = chk["first_bad_slot"]
+                        state["rc"] = 3
             res["gb_s_per_gpu_one_shot"] = round(cnt * 8 * (world - 1) / (res["one_shot_ms"] * 1e-3) / 1e9, 2) if world > 1 else None
             comm.close()
             res["note"] = ("encode of this rank's shard + concatenation through the C ABI: ncclAllGather in place (one_shot) and 8 pieces moved in place by "

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def run(*flags, timeout=240):
-    env = dict(os.environ)
+def run(*flags, timeout=240, **env_extra):
+    env = dict(os.environ, **env_extra)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
@@ -32,8 +32,19 @@ def test_self_launch_two_ranks_prints_one_line():
     assert line["config"]["control_backend"] == "gloo" and line["rccl_ok"] is None
     # the N>1 line carries config 4's side measurements
     assert line["allgather_packed"]["own_slot_ok"] is True
+    assert line["allgather_packed"]["all_slots_ok"] is True  # EVERY rank's slot of the gathered buffer against what it must hold
     assert "encode_allgather_end_to_end" in line
     assert "stalled" not in line and "collective_error" not in line
+
+
+def test_a_wrong_word_in_a_peer_slot_fails_the_run():
+    """Config 4's check is literal: the gathered buffer is compared slot by slot with what every rank's shard must pack to (here, without a
+    GPU, arange + rank), so a gather that delivered garbage into a PEER's slot is caught -- the line says so and the run exits 3."""
+    rc, lines, err = run("--gpus", "2", "--rehearse-cpu", "--backend", "gloo", "--steps", "3", "--warmup", "1", BITNUC_BENCH_PLANT_BAD_SLOT="1")
+    assert rc != 0 and "exitcode: 3" in err, (rc, err[-2000:])  # the rank exits 3 (as for parity_vs_oracle); the launcher folds a failed rank into its own non-zero code
+    line = json.loads(lines[0])
+    assert line["allgather_packed"]["own_slot_ok"] is True and line["allgather_packed"]["all_slots_ok"] is False
+    assert line["allgather_packed"]["first_bad_slot"] == 1  # rank 0 prints the line: the wrong word sits in its peer's slot
 
 
 def test_stalled_collective_is_reported_and_fails():

@@ -210,3 +210,90 @@ def test_scan3_first_invalid_byte_and_later_bytes(sweep_ctx, oracle, impl):
                 assert np.array_equal(ctx.kmer_hdist_scan(s[:m], kk, q), oracle.kmer_hdist_scan(s[:m], kk, q)), (kk, m)
     finally:
         ctx.set_variant("scan_impl", prev)
+
+
+# ---- SURVEY 8e's other shards on the HIP path: scan (with its halo), decode and the dense k-mer batch, shard by shard ------------------------
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_scan_decode_and_kmer_batch_shards_concatenate_on_the_hip_path(oracle, world):
+    """"Decode, k-mer batch and scan shard the same way (scan needs a 30-base halo per shard)" -- run on the kernels, not only in dist.py's
+    arithmetic: every rank's slice goes through its OWN Context (own stream) on device 0, writing its part of one output in place;
+    concatenation == the unsharded launch == the oracle.  Sizes: one where a shard is shorter than a 1 056-byte round (the whole shard is the
+    kernels' tail path) and one where shard boundaries fall in the middle of rounds and the last shard ends ragged.  No collective anywhere
+    (window idiom: src/lib.rs:170-173; per-word independence of decode: unpacking/avx.rs:137-141; no carry between words: packing/avx.rs:138-145)."""
+    import torch
+    import bitnuc_amd
+    from bitnuc_amd.dist import scan_shard_range, shard_range
+    dev = torch.device("cuda:0")
+    ranks = [bitnuc_amd.Context(0) for _ in range(world)]
+    whole = bitnuc_amd.Context(0)
+    for c in ranks + [whole]:
+        c.set_variant("force_gpu", 1)
+    try:
+        k, q = 31, 0x2B1B4E1B1B1B1B1B & ((1 << 62) - 1)
+        for n in (world * 700 + 30, 100003, 3 * 10**6 + 77):
+            seq = oracle.nucgen(n, SEED + n, flags=2)  # lower-case mix
+            t = torch.from_numpy(seq).to(dev)
+            # -- scan: rank r reads bases [first, first + count + k - 1) and writes windows [first, first + count)
+            want = oracle.kmer_hdist_scan(seq, k, q)
+            d_sh = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+            d_one = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            covered = 0
+            for r, c in enumerate(ranks):
+                first, count, nread = scan_shard_range(n, k, r, world)
+                assert first == covered and first % 32 == 0
+                covered += count
+                if count:
+                    c.kmer_hdist_scan_dev(t.data_ptr() + first, nread, k, q, d_sh.data_ptr() + first)
+            whole.kmer_hdist_scan_dev(t, n, k, q, d_one)
+            for c in ranks + [whole]:
+                c.sync()
+            assert covered == n - k + 1
+            got = d_sh.cpu().numpy()
+            assert np.array_equal(got[:covered], want) and bool((got[covered:] == 0xEE).all()), (world, n)
+            assert torch.equal(d_sh, d_one), (world, n)
+            # -- decode: words [a / 32, ceil(b / 32)) -> bases [a, b)
+            words = oracle.encode(seq)
+            w = torch.from_numpy(words.view(np.int64).copy()).to(dev)
+            b_sh = torch.full((n + 16,), 0xEE, dtype=torch.uint8, device=dev)
+            b_one = torch.full((n + 16,), 0xEE, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            for r, c in enumerate(ranks):
+                a, b = shard_range(n, r, world)
+                if b > a:
+                    c.decode_dev(w.data_ptr() + 8 * (a // 32), (b - a + 31) // 32, b - a, b_sh.data_ptr() + a)
+            whole.decode_dev(w, words.size, n, b_one)
+            for c in ranks + [whole]:
+                c.sync()
+            assert torch.equal(b_sh, b_one) and np.array_equal(b_sh.cpu().numpy()[:n], oracle.decode(words, n)) and bool((b_sh[n:] == 0xEE).all()), (world, n)
+            # -- dense k-mer batch (stride == k): the k-mers split into contiguous runs
+            count = n // k
+            want_k = oracle.as_2bit_batch(seq, k, k, count)
+            o_sh = torch.full((count + 2,), -1, dtype=torch.int64, device=dev)
+            o_one = torch.full((count + 2,), -1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            for r, c in enumerate(ranks):
+                a, b = shard_range(count, r, world)  # k-mer indices
+                if b > a:
+                    c.as_2bit_batch_dev(t.data_ptr() + a * k, k, k, b - a, o_sh.data_ptr() + 8 * a)
+            whole.as_2bit_batch_dev(t, k, k, count, o_one)
+            for c in ranks + [whole]:
+                c.sync()
+            assert torch.equal(o_sh, o_one) and np.array_equal(o_sh.cpu().numpy()[:count].view(np.uint64), want_k) and int(o_sh[count]) == -1, (world, n)
+        # an invalid byte in the scan's halo region belongs to BOTH neighbouring shards' reads: the lower rank reports it at its own offset
+        n = 100003
+        seq = oracle.nucgen(n, SEED, flags=0).copy()
+        first1, count1, _ = scan_shard_range(n, k, 1, world)
+        seq[first1 + 5] = ord("N")  # inside rank 0's halo and rank 1's first window
+        t = torch.from_numpy(seq).to(dev)
+        d = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for r in (0, 1):
+            first, count, nread = scan_shard_range(n, k, r, world)
+            ranks[r].kmer_hdist_scan_dev(t.data_ptr() + first, nread, k, q, d.data_ptr() + first)
+            with pytest.raises(bitnuc_amd.NucleotideError) as ei:
+                ranks[r].sync()
+            assert (ei.value.byte, ei.value.index) == (ord("N"), first1 + 5 - first), r  # shard-relative, like the sharded encode
+    finally:
+        for c in ranks + [whole]:
+            c.close()
