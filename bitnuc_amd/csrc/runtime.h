@@ -93,8 +93,7 @@ struct bitnuc_ctx {
     unsigned long long *d_cap = nullptr, *h_cap = nullptr; // launches recorded into a hipGraph: persistent, examined and re-armed by every drain
     unsigned long long cap_base[bitnuc_rt::kCapturedSlots];
     int n_cap = 0;
-    bool have_deferred = false; // an error found by an implicit drain, reported at next sync
-    bitnuc_err deferred;
+    std::vector<bitnuc_err> deferred; // data errors found by implicit drains (host-pointer calls start from an empty ring), oldest first: one per bitnuc_ctx_sync
     // ---- scratch ----
     uint8_t *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};

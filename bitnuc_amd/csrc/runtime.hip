@@ -90,8 +90,10 @@ int drain_scope(bitnuc_ctx *c, bitnuc_err *err, int scope) {
     return found.status;
 }
 
+// A FIFO, not one slot: error A, a host-pointer call (its implicit drain defers A), error B, another host-pointer call (defers B): the next
+// two syncs report A, then B (B used to be dropped).  Bounded: a caller that never syncs keeps the 64 oldest.
 void defer(bitnuc_ctx *c, const bitnuc_err &e) {
-    if (!c->have_deferred) { c->have_deferred = true; c->deferred = e; }
+    if (c->deferred.size() < 64) c->deferred.push_back(e);
 }
 
 } // namespace
@@ -288,11 +290,10 @@ int bitnuc_ctx_sync(bitnuc_ctx *c, bitnuc_err *err) {
     bitnuc_err e;
     int st = drain_scope(c, &e, kDrainAll);
     if (st == BITNUC_BACKEND_ERROR) { if (err) *err = e; return st; }
-    if (c->have_deferred) { // an earlier implicit drain saw an error first: it is this sync's; what this drain found waits for the next one
-        const bitnuc_err first = c->deferred;
-        c->have_deferred = false;
+    if (!c->deferred.empty()) { // earlier implicit drains saw errors first: the oldest is this sync's; what this drain found queues up behind them
         if (st != BITNUC_OK) defer(c, e);
-        e = first;
+        e = c->deferred.front();
+        c->deferred.erase(c->deferred.begin());
         st = e.status;
     }
     if (err) *err = e;

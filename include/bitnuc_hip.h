@@ -40,8 +40,9 @@
  *     BITNUC_UNSUPPORTED (err.value = the bytes needed) before anything is touched -- warm up with the largest batch, or use a
  *     bitnuc_batch_plan; a scratch buffer that a recorded launch was handed stays alive until bitnuc_ctx_destroy (a later,
  *     larger ordinary call allocates a new one), so replays never write into freed memory.
- *   - When a sync has two data errors to report -- one kept from an earlier implicit drain (a host-pointer call, or the 2 Mi
- *     limit above) and one its own drain finds -- it reports the earlier one; the later one is reported by the next sync.
+ *   - Data errors found by implicit drains (a host-pointer call starts from an empty slot ring, and so does the 2 Mi limit above) are
+ *     kept in launch order, oldest first, one per bitnuc_ctx_sync: with errors A and B kept from two such drains and a third one, C,
+ *     that only the sync's own drain finds, three syncs report A, B, C (at most 64 are kept between syncs).
  *
  * Conventions
  *   - plain pointers + sizes, no torch / C++ types in signatures;

@@ -381,6 +381,24 @@ def test_two_data_errors_across_an_implicit_drain_are_both_reported(oracle):
         c.sync()
     assert (e2.value.byte, e2.value.index) == (ord("x"), 2_999_999)
     c.sync()
+    # A, host-pointer call (defers A), B, ANOTHER host-pointer call (its drain finds B while A is still deferred), then a third
+    # error C that only the sync's own drain sees: three syncs report A, B, C in that order -- the deferred errors are a FIFO
+    c.encode_dev(a, n, words)
+    assert np.array_equal(c.encode_array(host), w)
+    c.encode_dev(b, n, words)
+    assert np.array_equal(c.decode_array(w, host.size), host)
+    b2 = a.clone()
+    b2[1234] = ord("A")
+    b2[77] = ord("!")
+    torch.cuda.synchronize()
+    c.encode_dev(b2, n, words)
+    seen = []
+    for _ in range(3):
+        with pytest.raises(bn.NucleotideError) as ei:
+            c.sync()
+        seen.append((ei.value.byte, ei.value.index))
+    assert seen == [(ord("N"), 1234), (ord("x"), 2_999_999), (ord("!"), 77)], seen
+    c.sync()
     c.close()
 
 

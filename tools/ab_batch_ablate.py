@@ -40,7 +40,7 @@ names = {0: "full", 1: "no window loads", 2: "no scatter/scan", 3: "no window, n
 res = {}
 for rnd in range(7):
     for a in names:
-        ctx.set_variant("batch_abl", a)
+        ctx.require_variant("batch_abl", a)
         e = once(lambda: ctx.encode_batch_dev(seq, off, wo, count, total, words)) if a in (0, 1, 2, 3, 8, 9, 11) else None
         d = once(lambda: ctx.decode_batch_dev(words, wo, off, count, total, back))
         if rnd >= 2:
@@ -48,7 +48,7 @@ for rnd in range(7):
             if e is not None:
                 res[a][0].append(e)
             res[a][1].append(d)
-ctx.set_variant("batch_abl", 0)
+ctx.require_variant("batch_abl", 0)
 fe = statistics.median(once(lambda: ctx.encode_fixed_dev(seq, L, L, count, words)) for _ in range(7))
 fd = statistics.median(once(lambda: ctx.decode_fixed_dev(words, L, L, count, back)) for _ in range(7))
 try:

@@ -33,7 +33,7 @@ res = {}
 for rnd in range(6):
     for u, c in ctxs.items():
         for mult in (1, 2, 3):
-            c.set_variant("reduce_mult", mult)
+            c.require_variant("reduce_mult", mult)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c.base_counts_dev(words[0], n // 32, n, counts)
             a.record(stream)

@@ -30,7 +30,7 @@ for L in [int(x) for x in sys.argv[1:]] or [16, 31, 32, 36, 100, 150, 151, 160, 
     res = {0: [], 1: [], 2: []}
     for rnd in range(9):
         for mode in (0, 1, 2):
-            ctx.set_variant("fixed_dec_strip", mode)
+            ctx.require_variant("fixed_dec_strip", mode)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
             ev[0].record(stream)
             for i in range(6):
@@ -40,7 +40,7 @@ for L in [int(x) for x in sys.argv[1:]] or [16, 31, 32, 36, 100, 150, 151, 160, 
             res[mode].append(statistics.mean(ev[i].elapsed_time(ev[i + 1]) for i in range(2, 6)))
     ctx.sync()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], seq[: count * L])
-    ctx.set_variant("fixed_dec_strip", 2)
+    ctx.require_variant("fixed_dec_strip", 2)
     alg = count * L + 8 * count * wpr
     m0, m1, m2 = statistics.median(res[0]), statistics.median(res[1]), statistics.median(res[2])
     print(f"L={L}: byte scatter {m0:.4f} ms ({alg / m0 / 1e6:.0f} GB/s) | bit strip {m1:.4f} ms ({alg / m1 / 1e6:.0f} GB/s) | shared tile body {m2:.4f} ms ({alg / m2 / 1e6:.0f} GB/s)", flush=True)

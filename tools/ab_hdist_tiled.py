@@ -9,10 +9,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bitnuc_amd
+from bitnuc_amd import build
 
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
-ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=build.ensure_built(sweep=True))  # the selectors below exist in the evidence build only
 n = 10**9
 nw = n // 32
 seq = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -27,8 +28,8 @@ res = {}
 for rnd in range(5):
     for tiled in (0, 1):
         for mult in (1, 2, 4, 8, 16):
-            ctx.set_variant("hdist_tiled", tiled)
-            ctx.set_variant("hdist_mult", mult)
+            ctx.require_variant("hdist_tiled", tiled)
+            ctx.require_variant("hdist_mult", mult)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ctx.hdist_dev(words[0], nw, words[1], nw, n, res1)
             a.record(stream)

@@ -9,10 +9,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bitnuc_amd
+from bitnuc_amd import build
 
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
-ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=build.ensure_built(sweep=True))  # the selectors below exist in the evidence build only
 n = 10**9
 nw = n // 32
 seq = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -26,7 +27,7 @@ res = {}
 refs = {}
 for rnd in range(6):
     for impl in (0, 1):
-        ctx.set_variant("hdist_words_impl", impl)
+        ctx.require_variant("hdist_words_impl", impl)
         for name, fn, alg in (("query", lambda i: ctx.hdist_query_dev(0x1234567890ABCDEF, words[i & 1], nw, 32, outs[i & 1]), 9 * nw),
                               ("pairs", lambda i: ctx.hdist_pairs_dev(words[i & 1], words[2], nw, 32, outs[i & 1]), 17 * nw)):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

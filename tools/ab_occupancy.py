@@ -18,8 +18,8 @@ stream = torch.cuda.current_stream()
 ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=_b.ensure_built(sweep=True))
 ENC = int(sys.argv[1]) if len(sys.argv) > 1 else 39   # evidence-build encode variant (39 = shipped; 15 / 32 = 8 groups in flight per lane)
 DEC = int(sys.argv[2]) if len(sys.argv) > 2 else 22
-ctx.set_variant("encode", ENC)
-ctx.set_variant("decode", DEC)
+ctx.require_variant("encode", ENC)
+ctx.require_variant("decode", DEC)
 n = 10**9
 nw = n // 32
 R = 3
@@ -34,7 +34,7 @@ res = {}
 SET = [0, 5 * 1024, 10 * 1024, 16 * 1024, 20 * 1024, 32 * 1024, 40 * 1024, 64 * 1024]
 for rnd in range(4):
     for lds in SET:
-        ctx.set_variant("dyn_lds", lds)
+        ctx.require_variant("dyn_lds", lds)
         evs = []
         for i in range(12):
             r = i % R
@@ -49,7 +49,7 @@ for rnd in range(4):
         if rnd:
             res.setdefault(lds, []).append((evs[3][0].elapsed_time(evs[-1][2]) / (len(evs) - 3),
                                             statistics.mean(e[0].elapsed_time(e[1]) for e in evs[3:]), statistics.mean(e[1].elapsed_time(e[2]) for e in evs[3:])))
-ctx.set_variant("dyn_lds", 0)
+ctx.require_variant("dyn_lds", 0)
 ctx.sync()
 assert torch.equal(seqs[0], backs[0])
 print(f"encode variant {ENC}, decode variant {DEC}")

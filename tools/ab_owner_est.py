@@ -8,11 +8,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bitnuc_amd
+from bitnuc_amd import build
 
 mode = int(sys.argv[1])
 dev = torch.device("cuda:0")
-ctx = bitnuc_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-ctx.set_variant("owner_est", mode)
+ctx = bitnuc_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream, lib_path=build.ensure_built(sweep=True))  # the selectors below exist in the evidence build only
+ctx.require_variant("owner_est", mode)
 N = 10**9
 seq = torch.empty(N, dtype=torch.uint8, device=dev)
 ctx.nucgen_dev(seq, N, 1)

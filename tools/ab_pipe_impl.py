@@ -41,15 +41,15 @@ CASES = {
 }
 UNITS = {"encode 1e9 bases": n, "decode 1e9 bases": n, "as_2bit_batch 3.2e7 dense 31-mers": nk, "kmer_hdist_scan 1e9 bases": n - k + 1}
 res = {}
-ctx.set_variant("pipe_impl", 0)
+ctx.require_variant("pipe_impl", 0)
 ctx.encode_into(seq, words[0])
 for name, fn in CASES.items():
     for impl in (0, 1):  # warm-up + first touch of every output array
-        ctx.set_variant("pipe_impl", impl)
+        ctx.require_variant("pipe_impl", impl)
         fn(impl)
     for rnd in range(5):
         for impl in (0, 1):
-            ctx.set_variant("pipe_impl", impl)
+            ctx.require_variant("pipe_impl", impl)
             t = time.perf_counter()
             fn(impl)
             res.setdefault((name, impl), []).append(time.perf_counter() - t)

@@ -62,13 +62,13 @@ def alt():
 
 for rnd in range(7):
     for e in edges:
-        ctx.set_variant("plan_tiles", e[0])
-        ctx.set_variant("plan_store", e[1])
+        ctx.require_variant("plan_tiles", e[0])
+        ctx.require_variant("plan_store", e[1])
         t = once(lambda: plan.decode_dev(words, alt()))
         if rnd >= 2:
             res[("e", e)].append(t)
-    ctx.set_variant("plan_store", 2)
-    ctx.set_variant("plan_tiles", 1)
+    ctx.require_variant("plan_store", 2)
+    ctx.require_variant("plan_tiles", 1)
     t = once(lambda: ctx.decode_fixed_dev(words, L, L, count, alt()))
     u = once(lambda: ctx.decode_dev(bw if flip[0] else bw2, N // 32, N, alt()))
     if rnd >= 2:

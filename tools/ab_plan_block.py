@@ -9,10 +9,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bitnuc_amd
+from bitnuc_amd import build
 
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
-ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream)
+ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=build.ensure_built(sweep=True))  # the selectors below exist in the evidence build only
 N = 10**9
 seq = torch.empty(N, dtype=torch.uint8, device=dev)
 ctx.nucgen_dev(seq, N, 0xB17C0DE)
@@ -48,11 +49,11 @@ for L in [int(a) for a in sys.argv[1:]] or [150]:
     res = {b: [] for b in BLOCKS}
     for rnd in range(8):
         for b in BLOCKS:
-            ctx.set_variant("plan_enc_block", b)
+            ctx.require_variant("plan_enc_block", b)
             t = once(run)
             if rnd >= 2:
                 res[b].append(t)
-    ctx.set_variant("plan_enc_block", 256)
+    ctx.require_variant("plan_enc_block", 256)
     alg = L * count + 8 * total
     print(f"L={L}: " + " | ".join(f"{b} threads {statistics.median(res[b]):.4f} ms {alg/statistics.median(res[b])/1e6:6.0f} GB/s" for b in BLOCKS), flush=True)
     plan.close()

@@ -59,7 +59,7 @@ for b in BLOCKS[1:]:
 ok = {}
 for rnd in range(7):
     for abl in NAMES:
-        ctx.set_variant("plan_enc_abl", abl)
+        ctx.require_variant("plan_enc_abl", abl)
         t = once(run)
         if rnd == 0:
             outs[0].zero_()
@@ -69,13 +69,13 @@ for rnd in range(7):
             ok[abl] = bool(torch.equal(outs[0][:total], ref[:total]))
         if rnd >= 2:
             res[abl].append(t)
-    ctx.set_variant("plan_enc_abl", 0)
+    ctx.require_variant("plan_enc_abl", 0)
     for b in BLOCKS[1:]:
-        ctx.set_variant("plan_enc_block", b)
+        ctx.require_variant("plan_enc_block", b)
         t = once(run)
         if rnd >= 2:
             res[("block", b)].append(t)
-    ctx.set_variant("plan_enc_block", 256)
+    ctx.require_variant("plan_enc_block", 256)
     u = once(lambda: ctx.encode_dev(seq, N, bws[flip.__setitem__(0, flip[0] ^ 1) or flip[0]]))
     if rnd >= 2:
         res["bulk"].append(u)

@@ -44,7 +44,7 @@ for L in [int(a) for a in sys.argv[1:]] or [150]:
     outs = [torch.empty(total + 64, dtype=torch.int64, device=dev) for _ in range(2)]
     ref = torch.empty(total + 64, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
-    ctx.set_variant("plan_enc_tiles", 1)
+    ctx.require_variant("plan_enc_tiles", 1)
     plan.encode_dev(seq, ref)
     ctx.sync()
     flip = [0]
@@ -58,7 +58,7 @@ for L in [int(a) for a in sys.argv[1:]] or [150]:
     ok = {}
     for rnd in range(7):
         for s in SETTINGS:
-            ctx.set_variant("plan_enc_tiles", s)
+            ctx.require_variant("plan_enc_tiles", s)
             t = once(lambda: plan.encode_dev(seq, alt()))
             if rnd == 0:
                 outs[0].zero_()
@@ -71,7 +71,7 @@ for L in [int(a) for a in sys.argv[1:]] or [150]:
         u = once(lambda: ctx.encode_dev(seq, N, bws[flip.__setitem__(0, flip[0] ^ 1) or flip[0]]))
         if rnd >= 2:
             res["bulk"].append(u)
-    ctx.set_variant("plan_enc_tiles", 1)
+    ctx.require_variant("plan_enc_tiles", 1)
     alg = L * count + 8 * total
     print(f"L={L}: plan encode of {count} reads, {alg/1e9:.4f} GB algorithmic")
     for s in SETTINGS:

@@ -52,20 +52,20 @@ def case(name, off, count, shift=0):
     same = True
     for rnd in range(8):
         for impl in (0, 1, 2):
-            ctx.set_variant("plan_dec_lines", impl)
+            ctx.require_variant("plan_dec_lines", impl)
             t = once(run)
             if rnd >= 2:
                 res[impl].append(t)
         if rnd == 0:  # both buffers now hold impl 1's result in [.. flip ..]; compare each form with the input once
             for impl in (0, 1, 2):
-                ctx.set_variant("plan_dec_lines", impl)
+                ctx.require_variant("plan_dec_lines", impl)
                 outs[0].fill_(0xEE)
                 plan.decode_dev(words, outs[0])
                 ctx.sync()
                 first = int(off[0].item())
                 ok = torch.equal(outs[0][first:nbytes], seq[first:nbytes]) and bool((outs[0][:first] == 0xEE).all()) and bool((outs[0][nbytes:] == 0xEE).all())
                 same = same and ok
-    ctx.set_variant("plan_dec_lines", 0)
+    ctx.require_variant("plan_dec_lines", 0)
     alg = (nbytes - int(off[0].item())) + 8 * total
     m0, m1, m2 = statistics.median(res[0]), statistics.median(res[1]), statistics.median(res[2])
     print(f"{name:28s} {alg/1e9:.4f} GB  word tiles {m0:.4f} ms {alg/m0/1e6:6.0f} GB/s | line-owning {m1:.4f} ms {alg/m1/1e6:6.0f} GB/s {100*(m0/m1-1):+5.1f} % | chunk-owning {m2:.4f} ms {alg/m2/1e6:6.0f} GB/s {100*(m0/m2-1):+5.1f} %  "

@@ -68,7 +68,7 @@ if "batch" in what:
     prod.sync()
     ref = ws[0].clone()
     alg = L * count + 8 * total
-    evid.set_variant("batch_tables_impl", 0)
+    evid.require_variant("batch_tables_impl", 0)
     table(f"encode, {count} reads of {L} bases ({alg / 1e9:.3f} GB algorithmic; tables not counted)", {
         "plan kernel (plan built once)": lambda i: plan.encode_dev(seq, ws[i & 1]),
         "tables: plan_emit_kernel + plan kernel (product)": lambda i: prod.encode_batch_dev(seq, off, wo, count, total, ws[i & 1]),
@@ -95,16 +95,16 @@ if "windows" in what:
     for impl in (0, 1):
         for u in (1, 2, 4):
             def fn(i, impl=impl, u=u):
-                evid.set_variant("slide_impl", impl)
-                evid.set_variant("slide_rounds", u)
-                evid.set_variant("slide2_rounds", u)
+                evid.require_variant("slide_impl", impl)
+                evid.require_variant("slide_rounds", u)
+                evid.require_variant("slide2_rounds", u)
                 evid.as_2bit_batch_dev(seq, k, 1, nwin, outs[i & 1])
             cases[f"{'line-aligned, computed in place' if impl else 'strip kernel (rounds of 992)'}, {u} round(s) per trip"] = fn
     table(f"every {k}-base window of 10^9 bases ({alg / 1e9:.3f} GB algorithmic)", cases, alg)
-    evid.set_variant("slide_impl", 0)
-    evid.set_variant("slide_rounds", 1)
+    evid.require_variant("slide_impl", 0)
+    evid.require_variant("slide_rounds", 1)
     evid.as_2bit_batch_dev(seq, k, 1, nwin, outs[0])
-    evid.set_variant("slide_impl", 1)
+    evid.require_variant("slide_impl", 1)
     evid.as_2bit_batch_dev(seq, k, 1, nwin, outs[1])
     evid.sync()
     print("  outputs:", "same" if torch.equal(outs[0], outs[1]) else "MISMATCH")

@@ -53,9 +53,9 @@ res = {c: [] for c in configs}
 res["count"] = []
 for rnd in range(6):
     for c in configs:
-        ctx.set_variant("scan_impl", c[0])
-        ctx.set_variant("scan_policy", c[1])
-        ctx.set_variant("scan_unroll", c[2])
+        ctx.require_variant("scan_impl", c[0])
+        ctx.require_variant("scan_policy", c[1])
+        ctx.require_variant("scan_unroll", c[2])
         t = burst(scan)
         if rnd:
             res[c].append(t)

@@ -32,7 +32,7 @@ NAMES = {1: "scan2 GEN1 (2 LUTs, scalar halo: ships)", 6: "scan2 GEN0 (rounds 2-
 ok = True
 outs = {}
 for impl in IMPLS:
-    ctx.set_variant("scan_impl", impl)
+    ctx.require_variant("scan_impl", impl)
     d = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
     ctx.kmer_hdist_scan_dev(ref, n, k, q, d)
     ctx.sync()
@@ -47,7 +47,7 @@ for kk in (1, 16, 17, 31, 32):
     qq = (0x2B1B4E1B1B1B1B1B ^ (kk * 0x9E3779B97F4A7C15)) & ((1 << 64) - 1)
     res = []
     for impl in IMPLS:
-        ctx.set_variant("scan_impl", impl)
+        ctx.require_variant("scan_impl", impl)
         d = torch.zeros(small, dtype=torch.uint8, device=dev)
         ctx.kmer_hdist_scan_dev(ref, small, kk, qq, d)
         ctx.sync()
@@ -89,7 +89,7 @@ def queue(N=64):
 res = {i: [] for i in IMPLS}
 for rnd in range(7):
     for impl in IMPLS:
-        ctx.set_variant("scan_impl", impl)
+        ctx.require_variant("scan_impl", impl)
         t = burst()
         if rnd:
             res[impl].append(t)
@@ -99,11 +99,11 @@ for impl in IMPLS:
     print(f"bursts  {NAMES[impl]:40s} {m*1e3:7.1f} us  {alg/m/1e6:6.0f} GB/s  {alg/m/8e7:5.1f} % of 8 TB/s", flush=True)
 for rep in range(2):
     for impl in IMPLS:
-        ctx.set_variant("scan_impl", impl)
+        ctx.require_variant("scan_impl", impl)
         import time
         time.sleep(0.3)
         mean, settled, worst = queue()
         print(f"queue{rep} {NAMES[impl]:40s} mean of 64 {mean:6.1f} us ({alg/mean/8e4:4.1f} %)  last 16 {settled:6.1f} us ({alg/settled/8e4:4.1f} %)  slowest {worst:6.1f} us", flush=True)
-ctx.set_variant("scan_impl", 1)
+ctx.require_variant("scan_impl", 1)
 print("all outputs equal" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)

@@ -15,7 +15,7 @@ stream = torch.cuda.current_stream()
 from bitnuc_amd import build as _build
 
 ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=_build.ensure_built(sweep=True))  # the evidence build holds the alternatives
-ctx.set_variant("slide_impl", 0)  # this tool is about the STRIP kernel (rounds of 992); tools/ab_r03.py compares it with the line-aligned one
+ctx.require_variant("slide_impl", 0)  # this tool is about the STRIP kernel (rounds of 992); tools/ab_r03.py compares it with the line-aligned one
 N, k = 10**9, 31
 stride = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 seq = torch.empty(N, dtype=torch.uint8, device=dev)
@@ -51,8 +51,8 @@ def run():
 
 for rnd in range(5):
     for s in SET:
-        ctx.set_variant("slide_rounds", s[0])
-        ctx.set_variant("grid_mult", s[1])
+        ctx.require_variant("slide_rounds", s[0])
+        ctx.require_variant("grid_mult", s[1])
         t = once(run)
         if rnd == 0:
             outs[0].zero_()
@@ -62,9 +62,9 @@ for rnd in range(5):
             ok[s] = bool(torch.equal(outs[0], ref))
         if rnd >= 1:
             res[s].append(t)
-ctx.set_variant("slide_rounds", 1)
-ctx.set_variant("slide_impl", 1)
-ctx.set_variant("grid_mult", 0)
+ctx.require_variant("slide_rounds", 1)
+ctx.require_variant("slide_impl", 1)
+ctx.require_variant("grid_mult", 0)
 alg = (N - k + 1) + 8 * nwin if stride == 1 else N + 8 * nwin
 print(f"stride {stride}: {nwin} windows, {alg/1e9:.3f} GB algorithmic")
 for s in SET:

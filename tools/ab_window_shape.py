@@ -48,8 +48,8 @@ cases["fill probe (plain), 8 GB"] = (lambda i: ctx.stream_probe_dev(2, None, out
 for pol in (3, 1):
     for u in (1, 2, 4):
         def real(i, u=u, pol=pol):
-            ctx.set_variant("slide2_rounds", u)
-            ctx.set_variant("dense_policy", pol)
+            ctx.require_variant("slide2_rounds", u)
+            ctx.require_variant("dense_policy", pol)
             ctx.as_2bit_batch_dev(seq, 31, 1, N - 30, outs[i & 1])
         cases[f"kmer_slide2_kernel, {'nt' if pol & 2 else 'plain'} stores, {u} round(s)/trip"] = (real, N + 8 * (N - 30))
 res = {k: [] for k in cases}

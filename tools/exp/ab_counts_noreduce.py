@@ -16,7 +16,7 @@ for rnd in range(6):
   for mult in (2, 4, 8, 16):
     for k0, c in ctxs.items():
         k = f"{k0} x{mult}"
-        c.set_variant("reduce_mult", mult)
+        c.require_variant("reduce_mult", mult)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c.base_counts_dev(words[0], n // 32, n, counts)
         a.record(stream)

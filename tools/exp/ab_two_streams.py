@@ -19,7 +19,7 @@ sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
 cA = bitnuc_amd.Context(0, stream=sA.cuda_stream)
 cB = bitnuc_amd.Context(0, stream=sB.cuda_stream)
 for c in (cA, cB):
-    c.set_variant("force_gpu", 1)
+    c.require_variant("force_gpu", 1)
 seqs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]
 words = [torch.empty(nw, dtype=torch.int64, device=dev) for _ in range(R)]
 backs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(R)]

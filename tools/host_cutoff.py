@@ -35,8 +35,8 @@ for n in (1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18, 3 << 17, 1 << 19, 3 << 18
     reps = max(5, min(200, (1 << 24) // n))
     row = []
     for force in (0, 1):
-        ctx.set_variant("force_gpu", force)
-        ctx.set_variant("host_cutoff", 1 << 30)
+        ctx.require_variant("force_gpu", force)
+        ctx.require_variant("host_cutoff", 1 << 30)
         row.append((t(lambda: ctx.encode_into(seq, w), reps), t(lambda: ctx.decode_into(w, n, back), reps)))
     assert np.array_equal(back, seq)
     print(f"{n:9d} | {row[0][0]:14.1f} | {row[1][0]:13.1f} | {row[0][1]:14.1f} | {row[1][1]:13.1f}", flush=True)

@@ -46,7 +46,7 @@ ref = bases(n)
 dist = np.zeros(n - k + 1, dtype=np.uint8)
 rows = []
 for pipe in (1, 0):
-    ctx.set_variant("host_pipeline", pipe)
+    ctx.require_variant("host_pipeline", pipe)
     t1 = timed(lambda: lib.bitnuc_as_2bit_batch(ctx._h, ptr(km), k, k, cnt, ptr(out), C.byref(err)))
     chk1 = int(out[::99991].sum())
     t2 = timed(lambda: lib.bitnuc_as_2bit_batch(ctx._h, ptr(wsrc), k, 1, nwin_n - k + 1, ptr(wout), C.byref(err)))

@@ -74,7 +74,8 @@ def main():
     # ---- BASELINE configs 3 and 5 alone at full size (tools/run_cfg35.py under the same three passes) ----
     side = {}
     CFG = {"cfg3": ("kmer_dense_kernel", 10**8 * 39, "10^8 dense 31-mers: 39 B per k-mer (31 read + 8 written)"),
-           "cfg5": ("kmer_scan2_kernel", 2 * (10**9 - 30), "10^9-base scan: 2 B per window (1 read + 1 written)")}
+           "cfg5": ("kmer_scan", 2 * (10**9 - 30), "10^9-base scan: 2 B per window (1 read + 1 written)"),  # kmer_scan_mfma_kernel since round 5, kmer_scan2_kernel before
+           "cfg5count": ("kmer_scan", 10**9 - 30, "10^9-base scan, fused d <= tau count: 1 B per window (read only)")}
     for cfg, (kname, alg, what) in CFG.items():
         tpath = glob.glob(os.path.join(src, cfg + "_trace", "**", "trace_kernel_stats.csv"), recursive=True)
         if not tpath:

@@ -20,7 +20,7 @@ for r in range(3):
     ctx.nucgen_dev(seqs[r], n, 7 + r)
 ctx.sync()
 for v in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "39,14,50,62,56").split(",")]:
-    ctx.set_variant("encode", v)
+    ctx.require_variant("encode", v)
     for i in range(6):
         ctx.encode_dev(seqs[i % 3], n, words[i % 3])
     ctx.sync()

@@ -18,9 +18,9 @@ ctx.nucgen_dev(seq, n, 3)
 outs = [torch.empty(n - k + 1, dtype=torch.int64, device=dev) for _ in range(2)]
 ctx.sync()
 for impl, u in ((0, 1), (1, 4)):
-    ctx.set_variant("slide_impl", impl)
-    ctx.set_variant("slide_rounds", 1)
-    ctx.set_variant("slide2_rounds", u)
+    ctx.require_variant("slide_impl", impl)
+    ctx.require_variant("slide_rounds", 1)
+    ctx.require_variant("slide2_rounds", u)
     for i in range(6):
         ctx.as_2bit_batch_dev(seq, k, 1, n - k + 1, outs[i & 1])
     ctx.sync()

@@ -41,9 +41,9 @@ def main():
     for rnd in range(args.rounds):
         for v in variants:
             for g in grids:
-                ctx.set_variant("encode", v)
-                ctx.set_variant("decode", v)
-                ctx.set_variant("grid_mult", g)
+                ctx.require_variant("encode", v)
+                ctx.require_variant("decode", v)
+                ctx.require_variant("grid_mult", g)
                 r = it % R
                 it += 1
                 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

@@ -34,7 +34,7 @@ mults = (0, 4, 8, 12, 16)
 rows = {}
 for rnd in range(5):
     for mult in mults:
-        ctx.set_variant("grid_mult", mult)
+        ctx.require_variant("grid_mult", mult)
         for name, fn in ops:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
             ev[0].record(stream)

@@ -39,17 +39,17 @@ def burst(fn, reps=8):
 rows = []
 for rnd in range(5):
     for g in (64, 128, 256):  # threads per workgroup (grid: one item per wave)
-        ctx.set_variant("grid_mult", 0)
-        ctx.set_variant("kmer_block", g)
+        ctx.require_variant("grid_mult", 0)
+        ctx.require_variant("kmer_block", g)
         for pol in (3,):
-            ctx.set_variant("scan_policy", pol)
+            ctx.require_variant("scan_policy", pol)
             for un in (2, 4):
-                ctx.set_variant("scan_unroll", un)
+                ctx.require_variant("scan_unroll", un)
                 ms = burst(lambda i: ctx.kmer_hdist_scan_dev(ref[i % 2], n, k, 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1), dist[i % 2]))
                 rows.append(("scan", g, pol * 10 + un, ms))
-            ctx.set_variant("dense_policy", pol)
+            ctx.require_variant("dense_policy", pol)
             for un in (1, 2):
-                ctx.set_variant("dense_unroll", un)
+                ctx.require_variant("dense_unroll", un)
                 ms = burst(lambda i: ctx.as_2bit_batch_dev(kseq, k, k, count, kout[i % 2]))
                 rows.append(("dense", g, pol * 10 + un, ms))
 ctx.sync()

@@ -44,9 +44,9 @@ def main():
         for g in [int(x) for x in args.grids.split(",")]:
             for ev in encs:
                 for dv in decs:
-                    ctx.set_variant("encode", ev)
-                    ctx.set_variant("decode", dv)
-                    ctx.set_variant("grid_mult", g)
+                    ctx.require_variant("encode", ev)
+                    ctx.require_variant("decode", dv)
+                    ctx.require_variant("grid_mult", g)
                     evs = []
                     for i in range(args.burst):
                         r = i % R

@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 rows = {}
 for rnd in range(7):
     for mult in (1, 2, 3, 4, 8):
-        ctx.set_variant("reduce_mult", mult)
+        ctx.require_variant("reduce_mult", mult)
         for name, fn in (("base_counts", lambda i: ctx.base_counts_dev(w[i & 1], nw, n, cnt)),
                          ("hdist", lambda i: ctx.hdist_dev(w[i & 1], nw, w[2 + (i & 1)], nw, n, res))):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)]

@@ -34,7 +34,7 @@ mults = tuple(int(x) for x in sys.argv[2:]) or (0, 2, 4, 8, 16, 32)
 rows = {}
 for rnd in range(7):
     for mult in mults:
-        ctx.set_variant(KEY, mult)
+        ctx.require_variant(KEY, mult)
         for name, _, fn in ops:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
             ev[0].record(stream)
