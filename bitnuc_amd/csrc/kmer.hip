@@ -176,7 +176,8 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
         else if (shift == 1) { if (pack == 0) SCANM_U(0, 1); else if (pack == 1) SCANM_U(1, 1); else SCANM_U(2, 1); }
         else if (shift == 2) { if (pack == 0) SCANM_U(0, 2); else if (pack == 1) SCANM_U(1, 2); else SCANM_U(2, 2); }
         else if (shift == 3) { if (pack == 0) SCANM_U(0, 3); else if (pack == 1) SCANM_U(1, 3); else SCANM_U(2, 3); }
-        else { if (pack == 0) SCANM_U(0, 4); else if (pack == 1) SCANM_U(1, 4); else SCANM_U(2, 4); }
+        else if (shift == 4) { if (pack == 0) SCANM_U(0, 4); else if (pack == 1) SCANM_U(1, 4); else SCANM_U(2, 4); }
+        else { if (pack == 0) SCANM_U(0, 5); else SCANM_U(1, 5); }
 #undef SCANM_U
 #undef SCANM_NT
 #undef SCANM_PS
@@ -388,12 +389,17 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
         }
 #ifdef BITNUC_SWEEP_VARIANTS
         const int U = knobs(c).scan_mfma_unroll, shift = knobs(c).scan_mfma_shift;
-        const unsigned g = scan_mfma_grid(c, rounds, U, true);
+        const bool persist = knobs(c).scan_mfma_count_persist != 0; // 0: one trip per wave, every workgroup arrives at the ticket (two atomics per workgroup)
+        const unsigned g = scan_mfma_grid(c, rounds, U, persist);
         const bool nt = (knobs(c).scan_mfma_policy & 1) != 0;
-#define COUNTM(P, UU, SH) kmer_scan_mfma_kernel<P, UU, true, 0, SH, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot, tab)
-#define COUNTM_NT(UU, SH) do { if (nt) COUNTM(1, UU, SH); else COUNTM(0, UU, SH); } while (0)
+        static_assert(kScanPartials == 1024, "runtime.hip allocates 1024 partial accumulators behind d_acc[8]");
+#define COUNTM(P, UU, SH, PS) kmer_scan_mfma_kernel<P, UU, true, 0, SH, PS><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, nullptr, res, PS ? c->d_acc + 5 : c->d_acc + 8, c->d_tickets + 2, slot, tab)
+#define COUNTM_PS(P, UU, SH) do { if (persist) COUNTM(P, UU, SH, true); else COUNTM(P, UU, SH, false); } while (0)
+#define COUNTM_NT(UU, SH) do { if (nt) COUNTM_PS(1, UU, SH); else COUNTM_PS(0, UU, SH); } while (0)
 #define COUNTM_U(SH) do { if (U == 2) COUNTM_NT(2, SH); else COUNTM_NT(4, SH); } while (0)
-        if (shift == 0) COUNTM_NT(2, 0); else if (shift == 1) COUNTM_U(1); else if (shift == 2) COUNTM_U(2); else if (shift == 3) COUNTM_U(3); else COUNTM_U(4);
+        if (shift == 0) COUNTM(1, 2, 0, true); else if (shift == 1) COUNTM_U(1); else if (shift == 2) COUNTM_U(2); else if (shift == 3) COUNTM_U(3); else if (shift == 4) COUNTM_U(4); else COUNTM_U(5);
+#undef COUNTM_PS
+        if (!persist && shift != 0) scan_count_finish_kernel<<<1, kScanPartials, 0, c->stream>>>(c->d_acc + 8, res);
 #undef COUNTM_U
 #undef COUNTM_NT
 #undef COUNTM

@@ -233,8 +233,8 @@ int bitnuc_ctx_create_on_stream(int device, void *hip_stream, bitnuc_ctx **out, 
     if (const char *e = getenv("BITNUC_HOST_CUTOFF")) { const long long v = atoll(e); if (v >= 0) c->host_cutoff = c->host_cutoff_decode = (size_t)v; }
     c->hdist_blocks = (unsigned)c->num_cu;     // 1 per CU: 74.3 us for two 250 MB operands where 2 per CU take 77.2 and 4 per CU 84.4 (profiles/r03_ab_hdist_grid.txt)
     c->reduce_blocks = (unsigned)c->num_cu * 2; // a resident grid of 2 workgroups of 256 threads per CU (profiles/r01_sweep13_reduce_grid.txt: the tail of atomics + ticket grows with the grid)
-    if (rc == hipSuccess) rc = hipMalloc(&c->d_acc, 64);
-    if (rc == hipSuccess) rc = hipMemset(c->d_acc, 0, 64);
+    if (rc == hipSuccess) rc = hipMalloc(&c->d_acc, 64 + 8 * 1024); // [0..7] the single-launch reductions' accumulators, [8..8+1024) the fused count's partials (scan_mfma_device.h kScanPartials)
+    if (rc == hipSuccess) rc = hipMemset(c->d_acc, 0, 64 + 8 * 1024);
     if (rc == hipSuccess) rc = hipMalloc(&c->d_tickets, 64);
     if (rc == hipSuccess) rc = hipMemset(c->d_tickets, 0, 64);
     if (rc == hipSuccess) rc = hipStreamSynchronize(c->stream); // the slot block's memset
@@ -324,7 +324,8 @@ constexpr SweepKey kSweepKeys[] = {
     {"scan_unroll", &bitnuc_rt::SweepKnobs::scan_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
     {"scan_impl", &bitnuc_rt::SweepKnobs::scan_impl, 0, 7, 0, {0, 0, 0}},
     {"scan_mfma_unroll", &bitnuc_rt::SweepKnobs::scan_mfma_unroll, 0, 0, 1ull << 2 | 1ull << 4, {0, 0, 0}},
-    {"scan_mfma_shift", &bitnuc_rt::SweepKnobs::scan_mfma_shift, 0, 4, 0, {0, 0, 0}},
+    {"scan_mfma_shift", &bitnuc_rt::SweepKnobs::scan_mfma_shift, 0, 5, 0, {0, 0, 0}},
+    {"scan_mfma_count_persist", &bitnuc_rt::SweepKnobs::scan_mfma_count_persist, 0, 1, 0, {0, 0, 0}},
     {"scan_mfma_persist", &bitnuc_rt::SweepKnobs::scan_mfma_persist, 0, 1, 0, {0, 0, 0}},
     {"scan_mfma_grid", &bitnuc_rt::SweepKnobs::scan_mfma_grid, 1, 32, 0, {0, 0, 0}},
     {"scan_mfma_pack", &bitnuc_rt::SweepKnobs::scan_mfma_pack, 0, 2, 0, {0, 0, 0}},

@@ -32,6 +32,8 @@
 
 namespace bitnuc_dev {
 
+constexpr int kScanPartials = 1024; // accumulators of the one-trip-per-wave fused count (context-owned, zero between calls)
+
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -63,6 +65,11 @@ __device__ __forceinline__ i32x8 onehot8(uint32_t x0, uint32_t x1) {
 //       three times (the count kernel is VALU-issue bound: each vector instruction per round costs 2 us per 10^9 windows)
 //   4 = as 3, but a lane keeps the operands of its OWN 16 bytes in registers: four ds_read_b128 per round instead of six (the strip
 //       costs 2 x 13 LDS cycles to write and 4 per read, MI355X_MICROARCH.md LDS table; 8 more registers per round of the trip)
+//   5 = as 3 with the trip SOFTWARE-PIPELINED: rounds 0 and 1 are expanded up front, round u + 2 is expanded -- and round u - 1's results
+//       are packed / counted -- in the same basic block as round u's six dependent MFMAs, so that the wave's vector work sits in the 24
+//       issue cycles each 32-cycle MFMA leaves free instead of waiting for the chain to end (profiles/r05_pmc_scan_mfma.txt: in form 4
+//       the vector ALUs are busy 59 % of the time and a wave waits 61 % of its cycles).  Whole trips only; a trip cut short by the end
+//       of the input runs form 4's code.  One branch per trip for invalid bytes (after the trip), none inside it.
 // PACK (how 16 f32 results become 16 bytes): 0 = v_cvt_pk_u8_f32 per window, accumulator starts at inline 0, no scales;
 //   1 = the 2^23 bias + row scales (v_or3 + v_perm per 4 windows), the bias an untied C operand held in 16 registers;
 //   2 = the same, the bias produced by a seventh instruction with constant operands (one nibble x ones, scale 2^23)
@@ -126,13 +133,15 @@ __device__ __forceinline__ void scan_trip_load(const uint8_t *__restrict__ ref, 
 }
 
 template <int POLICY, int U, bool COUNT, int PACK = 1, int SHIFT = 1, bool PERSIST = false>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) // >= 4 waves per SIMD (the strip already limits a CU to 16-20 waves): at most 128 registers
 kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
                       uint8_t *__restrict__ dist, unsigned long long *__restrict__ result, unsigned long long *__restrict__ total /* zero between launches */,
                       unsigned *__restrict__ ticket, unsigned long long *__restrict__ slot, const ScanMfmaTable tab) {
     constexpr bool NTLD = (POLICY & 1) != 0, NTST = (POLICY & 2) != 0;
     constexpr int kPlane = U * 1024 + 32;                    // a trip's bytes (SHIFT 1) or one of its two operand planes (SHIFT 3): U KiB + the halo
-    constexpr bool ONEHOT = SHIFT == 3 || SHIFT == 4, KEEP = SHIFT == 4;
+    constexpr bool PIPE = SHIFT == 5;
+    constexpr bool ONEHOT = SHIFT == 3 || SHIFT == 4 || PIPE, KEEP = SHIFT == 4; // (the pipelined form reads all six operands back: its registers go to the second accumulator)
+    static_assert(!PIPE || U >= 2, "the pipelined trip expands two rounds ahead");
     constexpr int kStrip = ONEHOT ? 2 * kPlane : kPlane;
     constexpr bool LDS = SHIFT == 1 || ONEHOT;
     __shared__ __attribute__((aligned(16))) uint8_t strips[LDS ? kBlock / 64 : 1][LDS ? kStrip : 16];
@@ -182,6 +191,64 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
             wave_lds_fence();
         }
         i32x8 own[KEEP ? U : 1][2];
+        if constexpr (PIPE) {
+            if (m == (unsigned)U) { // a whole trip: the static schedule (wave-uniform branch)
+                uint32_t badr[U];
+                auto fill = [&](int u) { // round u of the trip: validity residue, one-hot operands of the lane's 16 bytes -> registers + both planes of the strip
+                    const u32x4 x = cur.v[u][0];
+                    uint32_t bad = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
+                    badr[u] = bad;
+                    const i32x8 e0 = onehot8(x.x, x.y), e1 = onehot8(x.z, x.w);
+                    *reinterpret_cast<u32x4 *>(strip + 1024 * u + 16 * lane) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
+                    *reinterpret_cast<u32x4 *>(strip + kPlane + 1024 * u + 16 * lane) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+                };
+                auto fill_halo = [&]() {
+                    if (lane < 2) {
+                        const i32x8 e0 = onehot8(cur.hv.x, cur.hv.y), e1 = onehot8(cur.hv.z, cur.hv.w);
+                        *reinterpret_cast<u32x4 *>(strip + 1024 * U + 16 * lane) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
+                        *reinterpret_cast<u32x4 *>(strip + kPlane + 1024 * U + 16 * lane) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+                    }
+                };
+                wave_lds_fence(); // the previous trip's readers are done
+                fill(0);
+                fill(1);
+                if constexpr (U == 2) fill_halo();
+                f32x16 prev = c0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    wave_lds_fence(); // round u + 1's operands (or the halo) are in the strip
+                    i32x8 B[6];
+#pragma unroll
+                    for (int s6 = 0; s6 < 6; ++s6) {
+                        const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + (s6 & 1) * kPlane + 1024 * u + 16 * lane + 16 * (s6 >> 1));
+                        B[s6] = i32x8{(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+                    }
+                    if (u + 2 < U) fill(u + 2);          // (compile-time after unrolling)
+                    else if (u + 2 == U) fill_halo();
+                    f32x16 acc = c0;
+                    if constexpr (BIAS && PACK == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bias_a, bias_b, c0, 4, 4, 0, 127 + 23, 0, 127);
+#pragma unroll
+                    for (int s6 = 0; s6 < 6; ++s6) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[s6], B[s6], acc, 4, 4, 0, scale_a, 0, 127);
+                    if (u > 0) scan_mfma_emit<COUNT, PACK, NTST>(prev, tauf, hits, dist + ((r0 + u - 1) << 10) + 16 * lane); // the previous round's results, beside this round's chain
+                    prev = acc;
+                }
+                scan_mfma_emit<COUNT, PACK, NTST>(prev, tauf, hits, dist + ((r0 + U - 1) << 10) + 16 * lane);
+                uint32_t any = 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) any |= badr[u];
+                if (__builtin_expect((any & 0xDFDFDFDFu) != 0u, 0)) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if ((badr[u] & 0xDFDFDFDFu) != 0u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+                }
+                if constexpr (!PERSIST) break;
+                cur = nxt;
+                r0 = rn;
+                continue;
+            }
+        }
         if constexpr (ONEHOT) {
             wave_lds_fence(); // the previous trip's readers are done
 #pragma unroll
@@ -284,9 +351,33 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
         if (threadIdx.x == 0) {
             unsigned long long s = 0;
             for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
-            if (s) add_performed(total, s);
-            if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
+            if constexpr (PERSIST) { // a resident grid: one arrival per workgroup at ONE accumulator + ticket, the last one publishes (device_prims.h)
+                if (s) add_performed(total, s);
+                if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
+            } else {
+                // one trip per wave = tens of thousands of workgroups: two returning atomics each on one address serialise at ~6 ns apiece
+                // (0.77 ms per 10^9 windows, profiles/r05_ab_scan_mfma_v5*.txt).  Here a workgroup adds its count, fire-and-forget, to one of
+                // kScanPartials accumulators; scan_count_finish_kernel -- the next launch on the stream -- sums them, zeroes them, publishes.
+                if (s) atomicAdd(total + (blockIdx.x & (kScanPartials - 1)), s);
+            }
         }
+    }
+}
+
+// the second launch of the one-trip-per-wave fused count: sum + re-arm the partial accumulators (stream order makes the first launch's atomics visible)
+__global__ void __launch_bounds__(kScanPartials)
+scan_count_finish_kernel(unsigned long long *__restrict__ partials, unsigned long long *__restrict__ result) {
+    __shared__ unsigned long long part[kScanPartials / 64];
+    unsigned long long v = partials[threadIdx.x];
+    partials[threadIdx.x] = 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int i = 0; i < kScanPartials / 64; ++i) s += part[i];
+        *result = s;
     }
 }
 

@@ -157,7 +157,7 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
                                  ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 7, (0, 1, 2, 6)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
-                                 ("scan_mfma_shift", 4, (0, 1, 2, 3)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2,)), ("scan_mfma_persist", 0, (1,)),
+                                 ("scan_mfma_shift", 4, (0, 1, 2, 3, 5)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2,)), ("scan_mfma_persist", 0, (1,)), ("scan_mfma_count_persist", 1, (0,)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,)),
                                  ("batch_dense", 1, (0,)), ("batch_slide", 1, (0,)), ("batch_host_plan", 1, (0,)), ("fixed_stream", 1, (0,)), ("owner_est", 3, (0, 1, 2)),
                                  ("plan_enc_block", 256, (64, 128)), ("kmer_block", 256, (64, 128)), ("hdist_tiled", 0, (1,)), ("hdist_words_impl", 1, (0,)),
@@ -493,15 +493,15 @@ def test_kmer_batch_errors(ctx, oracle):
 
 # Forms of the config-5 scan.  "ships" runs on the PRODUCT library: the one-hot contraction on the matrix cores (scan_impl 7: one-hot operands
 # through a wave-private LDS strip, the lane's own kept in registers, one trip of 4 rounds per wave).  The others live in the evidence build: the
-# matrix-core form's alternatives (shift: 0 global re-loads, 1 bytes through the strip, 2 DPP, 3 all six operands through the strip; pack: 0
+# matrix-core form's alternatives (shift: 0 global re-loads, 1 bytes through the strip, 2 DPP, 3 all six operands through the strip, 5 the software-pipelined trip; pack: 0
 # v_cvt_pk_u8, 2 bias by a seventh instruction; trips of 2 rounds; a resident grid) and rounds 1-4's bit-plane forms (scan_impl, scan_unroll):
 # 1 = line-aligned rounds of 1024 windows (GEN 1 at unroll 4: shipped in round 4), 6 = rounds 2-3's plane build, 0 = rounds of 992 windows,
 # 2 / 3 / 4 = kmer_scan3_kernel with 12 / 20 / 16 rounds per wave.
 SCAN_FORMS = [("ships", {})] + \
     [(f"mfma-shift{sh}-pack{pk}-U{u}-persist{ps}", dict(scan_mfma_shift=sh, scan_mfma_pack=pk, scan_mfma_unroll=u, scan_mfma_persist=ps))
-     for sh, pk, u, ps in ((4, 1, 4, 1), (4, 0, 2, 0), (4, 2, 4, 0), (3, 1, 4, 0), (3, 0, 2, 1), (1, 1, 4, 0), (1, 2, 2, 1), (2, 1, 4, 0), (2, 0, 2, 1), (0, 1, 2, 1), (0, 0, 2, 0))] + \
+     for sh, pk, u, ps in ((4, 1, 4, 1), (4, 0, 2, 0), (4, 2, 4, 0), (5, 0, 4, 0), (5, 1, 2, 1), (3, 1, 4, 0), (3, 0, 2, 1), (1, 1, 4, 0), (1, 2, 2, 1), (2, 1, 4, 0), (2, 0, 2, 1), (0, 1, 2, 1), (0, 0, 2, 0))] + \
     [(f"bitplane-impl{i}-unroll{u}", dict(scan_impl=i, scan_unroll=u)) for i, u in ((1, 4), (1, 2), (1, 1), (6, 4), (0, 4), (0, 2), (0, 1), (2, 4), (3, 4), (4, 4))]
-SCAN_DEFAULTS = dict(scan_impl=7, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0)
+SCAN_DEFAULTS = dict(scan_impl=7, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1)
 
 
 @pytest.mark.parametrize("form", SCAN_FORMS, ids=[name for name, _ in SCAN_FORMS])
@@ -528,7 +528,7 @@ def test_scan_vs_oracle(ctx, sweep_ctx, oracle, k, form):
                 ctx.require_variant(key, v)
 
 
-@pytest.mark.parametrize("form", [f for f in SCAN_FORMS if f[0] == "ships" or f[0].startswith("mfma")][:9], ids=[name for name, _ in SCAN_FORMS if name == "ships" or name.startswith("mfma")][:9])
+@pytest.mark.parametrize("form", [f for f in SCAN_FORMS if f[0] == "ships" or f[0].startswith("mfma")][:11], ids=[name for name, _ in SCAN_FORMS if name == "ships" or name.startswith("mfma")][:11])
 def test_scan_matrix_core_forms_first_invalid_byte_and_count(ctx, sweep_ctx, oracle, form):
     """kmer_scan_mfma_kernel: the first invalid byte wins at round, trip and strip boundaries and inside the halo (a later invalid byte never
     does, a byte after the last window is never examined: hamming/scalar.rs:11-48 over naive.rs:3-20 per window); bytes past the last window are
@@ -540,6 +540,7 @@ def test_scan_matrix_core_forms_first_invalid_byte_and_count(ctx, sweep_ctx, ora
         ctx = sweep_ctx
         for key, v in {**SCAN_DEFAULTS, **knobs}.items():
             ctx.require_variant(key, v)
+        ctx.require_variant("scan_mfma_count_persist", knobs["scan_mfma_persist"] ^ 1)  # the fused count's two grid forms (resident + ticket / one trip per wave + finishing launch)
     try:
         rng = np.random.default_rng(505)
         n = 9 * 1024 + 77

@@ -38,7 +38,7 @@ def setv(key, value):
 ok = True
 # ---- against the oracle, through the device entry point ----
 setv("scan_impl", 7)
-COMBOS = [(sh, ps, U, pack) for sh in (4, 3, 1, 2) for ps in (0, 1) for U in (2, 4) for pack in (0, 1, 2)] + [(0, 1, 2, 0), (0, 0, 2, 1)]
+COMBOS = [(sh, ps, U, pack) for sh in (5, 4, 3, 1, 2) for ps in (0, 1) for U in (2, 4) for pack in (0, 1, 2) if not (sh == 5 and pack == 2)] + [(0, 1, 2, 0), (0, 0, 2, 1)]
 for sh, ps, U, pack in COMBOS:
     setv("scan_mfma_shift", sh)
     setv("scan_mfma_persist", ps)
@@ -67,7 +67,7 @@ for sh, ps, U, pack in COMBOS:
 # first invalid byte
 n = 50000
 s = ALPHA8[rng.integers(0, 8, size=n)].copy()
-for sh, ps, pos in [(sh, ps, pos) for sh in (4, 3, 1, 2) for ps in (0, 1) for pos in (0, 15, 16, 1023, 1024, 1040, 1055, 1056, 4095, 4096, 4097, 30000, 49600, 49999)]:
+for sh, ps, pos in [(sh, ps, pos) for sh in (5, 4, 3, 1, 2) for ps in (0, 1) for pos in (0, 15, 16, 1023, 1024, 1040, 1055, 1056, 4095, 4096, 4097, 30000, 49600, 49999)]:
     setv("scan_mfma_shift", sh)
     setv("scan_mfma_persist", ps)
     tt = s.copy()
@@ -83,9 +83,10 @@ for sh, ps, pos in [(sh, ps, pos) for sh in (4, 3, 1, 2) for ps in (0, 1) for po
             print(f"invalid byte at {pos}: reported {(e.byte, e.index)}")
             ok = False
 # fused count
-for sh, U in ((4, 2), (4, 4), (3, 2), (3, 4), (1, 2), (1, 4), (2, 2), (2, 4), (0, 2)):
+for sh, U in ((5, 2), (5, 4), (4, 2), (4, 4), (3, 2), (3, 4), (1, 2), (1, 4), (2, 2), (2, 4), (0, 2)):
   setv("scan_mfma_shift", sh)
   setv("scan_mfma_unroll", U)
+  setv("scan_mfma_count_persist", (sh + U) % 2)  # both grid forms of the fused count get their share of the sizes
   cnt = torch.zeros(1, dtype=torch.int64, device=dev)
   for n in (31, 1056, 2081, 4129, 16 * 1024 + 31, 100003, 1 << 20):
     s = ALPHA8[rng.integers(0, 8, size=n)]
@@ -116,7 +117,7 @@ setv("scan_impl", 1)
 base = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
 ctx.kmer_hdist_scan_dev(ref, n, k, q, base)
 ctx.sync()
-for sh, ps, U, pack in ((4, 0, 4, 1), (4, 1, 2, 0), (3, 0, 4, 1), (3, 1, 2, 0), (1, 0, 4, 1), (1, 1, 4, 0), (2, 0, 4, 1), (2, 1, 2, 2), (0, 1, 2, 1)):
+for sh, ps, U, pack in ((5, 0, 4, 1), (5, 1, 4, 0), (5, 0, 2, 1), (4, 0, 4, 1), (4, 1, 2, 0), (3, 0, 4, 1), (3, 1, 2, 0), (1, 0, 4, 1), (1, 1, 4, 0), (2, 0, 4, 1), (2, 1, 2, 2), (0, 1, 2, 1)):
     setv("scan_impl", 7)
     setv("scan_mfma_shift", sh)
     setv("scan_mfma_persist", ps)
@@ -137,21 +138,16 @@ for impl in (1, 7):
 del base
 
 FORMS = [("bit-plane scan2 GEN1 (ships r04)", dict(scan_impl=1))]
-CENTRE = dict(shift=3, persist=0, U=4, pack=1, pol=3, grid=4)
+CENTRE = dict(shift=4, persist=0, U=4, pack=1, pol=3, grid=4, cp=1)
 seen = set()
-for key, values in (("shift", (3, 4, 1, 2)), ("persist", (0, 1)), ("U", (4, 2)), ("pack", (1, 0, 2)), ("pol", (3, 2)), ("grid", (4, 5, 6, 3))):
-    for v in values:
-        for ps in (0, 1):
-            f = dict(CENTRE, persist=ps)
-            f[key] = v
-            if key == "grid" and not f["persist"]:
-                continue
-            tup = tuple(sorted(f.items()))
-            if tup in seen or (quick and f != CENTRE):
-                continue
-            seen.add(tup)
-            FORMS.append((f"mfma shift{f['shift']} persist{f['persist']} U{f['U']} pack{f['pack']} pol{f['pol']} grid{f['grid']}",
-                          dict(scan_impl=7, scan_mfma_shift=f["shift"], scan_mfma_persist=f["persist"], scan_mfma_unroll=f["U"], scan_mfma_pack=f["pack"], scan_mfma_policy=f["pol"], scan_mfma_grid=f["grid"])))
+for f in [CENTRE] + [dict(CENTRE, **d) for d in (dict(shift=5), dict(shift=5, pack=0), dict(shift=5, U=2), dict(shift=5, persist=1), dict(shift=5, cp=0), dict(shift=5, pack=0, cp=0), dict(shift=5, U=2, cp=0),
+                                                   dict(cp=0), dict(U=2, cp=0), dict(shift=3), dict(shift=1), dict(pack=0), dict(persist=1))]:
+    tup = tuple(sorted(f.items()))
+    if tup in seen or (quick and f != CENTRE):
+        continue
+    seen.add(tup)
+    FORMS.append((f"mfma shift{f['shift']} persist{f['persist']} U{f['U']} pack{f['pack']} countpersist{f['cp']}",
+                  dict(scan_impl=7, scan_mfma_shift=f["shift"], scan_mfma_persist=f["persist"], scan_mfma_unroll=f["U"], scan_mfma_pack=f["pack"], scan_mfma_policy=f["pol"], scan_mfma_grid=f["grid"], scan_mfma_count_persist=f["cp"])))
 FORMS.append(("mfma shift0 (global re-loads) persist1 U2 pack1", dict(scan_impl=7, scan_mfma_shift=0, scan_mfma_persist=1, scan_mfma_unroll=2, scan_mfma_pack=1, scan_mfma_policy=3, scan_mfma_grid=4)))
 flip = [0]
 
@@ -205,7 +201,7 @@ for what, fn, bytes_ in (("scan", scan, alg), ("count", count, alg // 2)):
         m = statistics.median(res[name])
         print(f"{what:5s} bursts {name:52s} {m*1e3:7.1f} us  {bytes_/m/1e6:6.0f} GB/s  {bytes_/m/8e7:5.1f} % of 8 TB/s", flush=True)
     for rep in range(2):
-        for name, form in FORMS[:1] + [f for f in FORMS[1:] if f[1]["scan_mfma_unroll"] == 4 and f[1]["scan_mfma_grid"] == 4 and f[1]["scan_mfma_policy"] == 3 and f[1]["scan_mfma_pack"] == 1]:
+        for name, form in FORMS[:1] + [f for f in FORMS[1:] if f[1]["scan_mfma_shift"] in (4, 5) and f[1]["scan_mfma_persist"] == 0]:
             use(form)
             torch.cuda.synchronize()
             time.sleep(1.0)  # from idle

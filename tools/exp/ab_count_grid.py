@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Fused count (bitnuc_kmer_hdist_count_dev) of the matrix-core scan: a resident grid with one accumulator + ticket (scan_mfma_count_persist 1)
+against one trip per wave with spread partial accumulators + a finishing launch (0), trips of 4 and 2 rounds -- evidence build; counts checked
+against the distance bytes.  Bursts of 8 and a 96-launch queue from an idle chip."""
+import os
+import statistics
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+import bitnuc_amd
+from bitnuc_amd import build
+
+dev = torch.device("cuda:0")
+stream = torch.cuda.current_stream()
+ctx = bitnuc_amd.Context(0, stream=stream.cuda_stream, lib_path=build.ensure_built(sweep=True))
+n, k = 10**9, 31
+q = 0x1B1B1B1B1B1B1B1B & ((1 << 62) - 1)
+ref = torch.empty(n, dtype=torch.uint8, device=dev)
+ctx.nucgen_dev(ref, n, 0xB17C0DE)
+d = torch.empty(n, dtype=torch.uint8, device=dev)
+ctx.kmer_hdist_scan_dev(ref, n, k, q, d)
+ctx.sync()
+cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+FORMS = [(sh, U, cp) for sh in (4, 3) for U in (4, 2) for cp in (1, 0)]
+ok = True
+for tau in (18, 8, 31):
+    want = int((d[:n - k + 1] <= tau).sum().item())
+    for sh, U, cp in FORMS:
+        for key, v in (("scan_mfma_shift", sh), ("scan_mfma_unroll", U), ("scan_mfma_count_persist", cp)):
+            ctx.require_variant(key, v)
+        for _ in range(2):  # twice: the accumulators must be zero again after a call
+            ctx.kmer_hdist_count_dev(ref, n, k, q, tau, cnt)
+            ctx.sync()
+            if int(cnt.item()) != want:
+                print(f"MISMATCH shift {sh} U {U} count_persist {cp} tau {tau}: {int(cnt.item())} != {want}")
+                ok = False
+print("counts:", "ok" if ok else "FAILED", flush=True)
+
+
+def burst(B=8):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.kmer_hdist_count_dev(ref, n, k, q, 18, cnt)
+    a.record(stream)
+    for _ in range(B):
+        ctx.kmer_hdist_count_dev(ref, n, k, q, 18, cnt)
+    b.record(stream)
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / B
+
+
+def queue(N=96):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
+    torch.cuda.synchronize()
+    time.sleep(1.0)
+    ev[0].record(stream)
+    for i in range(N):
+        ctx.kmer_hdist_count_dev(ref, n, k, q, 18, cnt)
+        ev[i + 1].record(stream)
+    torch.cuda.synchronize()
+    us = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(N)]
+    return sum(us) / N, sum(us[-16:]) / 16, max(us[1:])
+
+
+res = {f: [] for f in FORMS}
+for rnd in range(6):
+    for f in FORMS:
+        for key, v in zip(("scan_mfma_shift", "scan_mfma_unroll", "scan_mfma_count_persist"), f):
+            ctx.require_variant(key, v)
+        t = burst()
+        if rnd:
+            res[f].append(t)
+for f in FORMS:
+    m = statistics.median(res[f])
+    for key, v in zip(("scan_mfma_shift", "scan_mfma_unroll", "scan_mfma_count_persist"), f):
+        ctx.require_variant(key, v)
+    mean, settled, worst = queue()
+    print(f"shift {f[0]} U {f[1]} {'resident grid + ticket   ' if f[2] else 'one trip per wave + finish'}: bursts {m*1e3:6.1f} us ({(n-k+1)/m/8e7:4.1f} % of 8 TB/s)   from idle: mean of 96 {mean:6.1f} us, last 16 {settled:6.1f} us, slowest {worst:6.1f} us", flush=True)
+sys.exit(0 if ok else 1)
