@@ -142,6 +142,27 @@ void scan_mfma_table(uint64_t query, size_t k, ScanMfmaTable *t) {
             }
 }
 
+// ... and of the fused count's own tiling (CountMfmaTable): row m of K-block h only depends on delta = m - 8 h
+void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t) {
+    uint8_t lo[128], hi[128]; // [32 + i]
+    memset(lo, 0, sizeof lo);
+    memset(hi, 0, sizeof hi);
+    for (size_t i = 0; i < k; ++i) {
+        const unsigned q = (unsigned)((query >> (2 * i)) & 3);
+        lo[32 + i] = (uint8_t)((q != 0 ? 0x02 : 0) | (q != 1 ? 0x20 : 0));
+        hi[32 + i] = (uint8_t)((q != 2 ? 0x02 : 0) | (q != 3 ? 0x20 : 0));
+    }
+    for (int d = -8; d < 32; ++d)
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i) {
+                const int p0 = 16 * j + 4 * (i >> 1); // position of byte 0 of this dword, relative to 32 n + 8 h
+                const uint8_t *src = (i & 1) ? hi : lo;
+                uint32_t w = 0;
+                for (int b = 0; b < 4; ++b) w |= (uint32_t)src[32 + p0 + b - d] << (8 * b);
+                t->w[d + 8][4 * j + i] = w;
+            }
+}
+
 // grid of the matrix-core scan: resident waves that walk the rounds (each wave builds its constant operand once)
 unsigned scan_mfma_grid(const bitnuc_ctx *c, unsigned long long rounds, int U, bool persist) {
     const unsigned long long want = rounds / ((kBlock / 64) * (unsigned long long)U) + 1; // one trip per wave (+ 1: the tail loop needs a workgroup even without a whole round)
@@ -380,14 +401,27 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     unsigned long long *res = reinterpret_cast<unsigned long long *>(d_count);
     if (knobs(c).scan_impl == 7 && aligned16(d_ref)) {
-        ScanMfmaTable tab;
-        scan_mfma_table(query, k, &tab);
-        if constexpr (!kEvidenceBuild) { // the shipped form: a resident grid (one arrival per workgroup at the ticket), next trip's loads issued before the current one is computed
-            kmer_scan_mfma_kernel<1, 4, true, 0, 4, true><<<scan_mfma_grid(c, rounds, 4, true), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, nullptr, res, c->d_acc + 5, c->d_tickets + 2, slot, tab);
+        if constexpr (!kEvidenceBuild) {
+            // the shipped form: the count's own tiling (segments of 32 windows x 32 shifts: 4 MFMAs per 1024 windows, nothing multiplies zeros), a
+            // resident grid (one arrival per workgroup at the ticket), the next trip's loads issued before the current one is computed
+            CountMfmaTable ct;
+            count_mfma_table(query, k, &ct);
+            kmer_count_mfma_kernel<4, true><<<scan_mfma_grid(c, rounds, 4, true), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
             HIPCHK(hipGetLastError());
             return BITNUC_OK;
         }
 #ifdef BITNUC_SWEEP_VARIANTS
+        ScanMfmaTable tab;
+        scan_mfma_table(query, k, &tab);
+        if (knobs(c).scan_mfma_count_form == 1) { // the count's own tiling: segments of 32 windows, 4 MFMAs per 1024 windows
+            CountMfmaTable ct;
+            count_mfma_table(query, k, &ct);
+            const unsigned g = scan_mfma_grid(c, rounds, knobs(c).scan_mfma_unroll, true);
+            if (knobs(c).scan_mfma_unroll == 2) kmer_count_mfma_kernel<2, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
+            else kmer_count_mfma_kernel<4, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
+            HIPCHK(hipGetLastError());
+            return BITNUC_OK;
+        }
         const int U = knobs(c).scan_mfma_unroll, shift = knobs(c).scan_mfma_shift;
         const bool persist = knobs(c).scan_mfma_count_persist != 0; // 0: one trip per wave, every workgroup arrives at the ticket (two atomics per workgroup)
         const unsigned g = scan_mfma_grid(c, rounds, U, persist);

@@ -364,6 +364,121 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The fused count in its own tiling.  Only the NUMBER of windows with d <= tau leaves the chip, so the results need no particular place in
+// the register file -- and the natural-layout tiling above pays for its free output layout with a block-diagonal A (half of every
+// instruction multiplies zeros: 6 MFMAs per 1024 windows).  Here a column is a SEGMENT of 32 consecutive windows and a row one of its 32
+// shifts: D[m][n] = dist(window 32 n + m), the 63 positions a segment's windows cover are 4 K-steps of 16, and nothing is wasted: 4 MFMAs
+// per 1024 windows.  Lane (n = l & 31, h = l >> 5) of K-step j needs the one-hot operand of bases 32 n + 16 j + 8 h .. + 8: half h of the
+// 16-byte group 2 n + j -- not the lane's own group, so all four operands come from the strip, which keeps even and odd groups in separate
+// regions (a K-step's 32 reads are then 32 consecutive 16-byte entries: conflict-free).
+// w[delta + 8][4 j + i]: dword i of K-step j for the row with delta = m - 8 h (i = position - m only depends on it), built on the host.
+struct CountMfmaTable { uint32_t w[40][16]; };
+
+template <int U, bool NTLD>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
+                       unsigned long long *__restrict__ result, unsigned long long *__restrict__ total /* zero between launches */,
+                       unsigned *__restrict__ ticket, unsigned long long *__restrict__ slot, const CountMfmaTable tab) {
+    constexpr int kRegion = (32 * U + 1) * 16 + 64; // one (half, parity) region: 32 U entries + the halo's + 16 banks of padding (the two parities of a store do not alias)
+    __shared__ __attribute__((aligned(16))) uint8_t strips[kBlock / 64][4 * kRegion];
+    const unsigned long long nwin = n - k + 1;
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    uint8_t *strip = strips[wave_in_block()];
+
+    ScanTrip<U> cur;
+    unsigned long long r0 = wave * U;
+    if (r0 < rounds) scan_trip_load<U, 3, NTLD>(ref, r0, rounds, lane, cur);
+    const unsigned m32 = lane & 31u, hh = lane >> 5;
+    i32x8 A[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        A[j] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A[j][i] = (int)tab.w[m32 + 8u - 8u * hh][4 * j + i];
+    }
+    const float tauf = (float)tau;
+    uint32_t hits = 0;
+    // where group g of the trip lives: region (half e, parity g & 1), entry g >> 1
+    const unsigned wr0 = (lane & 1u) * kRegion + 16u * (lane >> 1);                 // the lane's own group l of round u: + 2 kRegion e + 512 u
+    const unsigned rd = hh * 2u * kRegion + 16u * m32;                              // lane (n, h), K-step j of round u: + (j & 1) kRegion + 16 (32 u + (j >> 1))
+
+    while (r0 < rounds) {
+        const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
+        ScanTrip<U> nxt;
+        const unsigned long long rn = r0 + nwaves * U;
+        if (rn < rounds) scan_trip_load<U, 3, NTLD>(ref, rn, rounds, lane, nxt);
+        wave_lds_fence(); // the previous trip's readers are done
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32x4 x = cur.v[u][0];
+            uint32_t bad = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
+            if (__builtin_expect((bad & 0xDFDFDFDFu) != 0u && (unsigned)u < m, 0)) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+            const i32x8 e0 = onehot8(x.x, x.y), e1 = onehot8(x.z, x.w);
+            *reinterpret_cast<u32x4 *>(strip + wr0 + 512 * u) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
+            *reinterpret_cast<u32x4 *>(strip + wr0 + 512 * u + 2 * kRegion) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+        }
+        if (lane < 2) { // the halo: groups 64 m and 64 m + 1 (after the last VALID round; in-order LDS: the later write wins over a clamped copy)
+            const i32x8 e0 = onehot8(cur.hv.x, cur.hv.y), e1 = onehot8(cur.hv.z, cur.hv.w);
+            *reinterpret_cast<u32x4 *>(strip + lane * kRegion + 512 * m) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
+            *reinterpret_cast<u32x4 *>(strip + lane * kRegion + 512 * m + 2 * kRegion) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((unsigned)u >= m) break; // wave-uniform
+            i32x8 B[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + rd + (j & 1) * kRegion + 16 * (32 * u + (j >> 1)));
+                B[j] = i32x8{(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[j], acc, 4, 4, 0, 127, 0, 127);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hits += (uint32_t)__builtin_popcountll(__ballot(acc[r] <= tauf));
+        }
+        cur = nxt;
+        r0 = rn;
+    }
+
+    // tail: one window per thread, byte loads
+    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    uint32_t tail_hits = 0;
+    for (unsigned long long i = (rounds << 10) + gt; i < nwin; i += nthreads) {
+        unsigned long long w = 0;
+        bool flagged = false;
+        for (unsigned b = 0; b < k; ++b) {
+            const uint32_t byte = ref[i + b];
+            if (!valid_base(byte) && !flagged) { latch_bad(slot, i + b, byte); flagged = true; }
+            w |= (unsigned long long)code_of(byte) << (2 * b);
+        }
+        const unsigned long long x = (w ^ query) & kmask;
+        tail_hits += (uint32_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull) <= tau ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tail_hits += __shfl_xor(tail_hits, off);
+    __shared__ uint32_t part[kBlock / 64];
+    if (lane == 0) part[threadIdx.x >> 6] = hits + tail_hits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
+        if (s) add_performed(total, s);
+        if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
+    }
+}
+
 // the second launch of the one-trip-per-wave fused count: sum + re-arm the partial accumulators (stream order makes the first launch's atomics visible)
 __global__ void __launch_bounds__(kScanPartials)
 scan_count_finish_kernel(unsigned long long *__restrict__ partials, unsigned long long *__restrict__ result) {
