@@ -1065,8 +1065,9 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
         extra["kmer_hdist_count"] = {"workload": f"same scan, fused `d <= {tau}` count instead of the distance bytes (1 B read per window)",
                                      "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "matches": int(cnt1.item()),
                                      "matches_check": int((dist_out <= tau).sum().item()),
-                                     "bound": "vector-instruction issue on the matrix-core form too (56 vector instructions per 1024 windows at 4.3 cycles each + 6 MFMA, "
-                                              "profiles/r05_pmc_scan_mfma.txt): 0.20-0.22 ms against the bit-plane form's 0.30-0.33 and an HBM floor of 0.145",
+                                     "bound": "vector-instruction issue and the dependent MFMA chain, not HBM (floor 0.145 ms): the count's own tiling (segments of 32 windows x 32 shifts, "
+                                              "4 MFMAs + ~50 vector instructions per 1024 windows, a resident grid) runs 0.185-0.20 ms; on the scan's natural-layout tiling 0.20-0.22; "
+                                              "round 4's bit-plane form 0.30-0.33 (profiles/r05_ab_count_own_tiling.txt, r05_pmc_scan_mfma.txt)",
                                      "algorithmic_gb_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 1), "roofline": hbm(n - k + 1, ms)}
         c96 = timed_queue(torch, stream, lambda i: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1), n_launches=96, idle_s=1.0)
         extra["kmer_hdist_count"]["from_idle_queue_of_96"] = {"mean_ms": round(sum(c96) / len(c96), 4), "last16_ms": round(sum(c96[-16:]) / 16, 4), "slowest_ms": round(max(c96[1:]), 4)}

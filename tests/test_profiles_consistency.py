@@ -1,5 +1,5 @@
 """CPU test of the evidence chain: the fractions DESIGN.md / README.md quote for the BASELINE configs can be recomputed from the raw
-rocprofv3 CSVs tracked under profiles/r04_rocprof/ alone, agree with profiles/hbm_traffic.json (written by tools/prof_summary.py) and,
+rocprofv3 CSVs tracked under profiles/r05_rocprof/ alone, agree with profiles/hbm_traffic.json (written by tools/prof_summary.py) and,
 within box-to-box spread, with the bench line kept beside them.  Nothing here touches a GPU or the library."""
 import csv
 import json
@@ -8,7 +8,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "profiles", "r04_rocprof")
+PROF = os.path.join(ROOT, "profiles", "r05_rocprof")
 PEAK = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
 
 
@@ -44,7 +44,7 @@ def test_timed_step_kernels_from_the_raw_csvs(traffic, kernel, alg, lo):
     assert 0.999 <= hbm / alg <= 1.01, hbm / alg  # no wasted re-reads
 
 
-@pytest.mark.parametrize("cfg,kernel,alg", [("cfg3", "kmer_dense_kernel", 10**8 * 39), ("cfg5", "kmer_scan2_kernel", 2 * (10**9 - 30))])
+@pytest.mark.parametrize("cfg,kernel,alg", [("cfg3", "kmer_dense_kernel", 10**8 * 39), ("cfg5", "kmer_scan_mfma_kernel", 2 * (10**9 - 30)), ("cfg5count", "kmer_count_mfma_kernel", 10**9 - 30)])
 def test_configs_3_and_5_alone_from_the_raw_csvs(traffic, cfg, kernel, alg):
     avg_ns, calls = _stats(f"kernel_stats_{cfg}.csv", kernel)
     t = traffic[cfg]
@@ -54,18 +54,24 @@ def test_configs_3_and_5_alone_from_the_raw_csvs(traffic, cfg, kernel, alg):
     assert abs(hbm / t["hbm_bytes_per_launch"] - 1) < 1e-6 and 0.999 <= hbm / alg <= 1.03, hbm / alg
     if cfg == "cfg3":
         assert alg / avg_ns / PEAK >= 0.75
+        return
+    # a queue of 96 launches that starts on an idle chip: the average includes the power controller's dip after the first launches
+    series = t["launch_series_us"]
+    assert len(series) == calls >= 64
+    settled = sum(series[-16:]) / 16
+    assert abs(t["last16_avg_ns"] / 1e3 - settled) < 0.1
+    if cfg == "cfg5":
+        # the matrix-core scan: settled at the HBM plateau, from-idle mean within 5 % of it (round 4's bit-plane scan: 0.78-0.79 settled, 0.72 mean,
+        # worst launch 1.4-1.5 x settled)
+        assert alg / (settled * 1e3) / PEAK >= 0.77 and alg / avg_ns / PEAK >= 0.74
+        assert avg_ns / 1e3 <= 1.05 * settled and max(series[1:]) <= 1.32 * settled
     else:
-        # the scan is VALU-issue bound: the queue's average includes the clock dip after idle; the settled rate is the last 16
-        series = t["launch_series_us"]
-        assert len(series) == calls >= 64
-        settled = sum(series[-16:]) / 16
-        assert abs(t["last16_avg_ns"] / 1e3 - settled) < 0.1
-        assert alg / (settled * 1e3) / PEAK >= 0.72 and alg / avg_ns / PEAK >= 0.65
-        assert max(series[4:24]) > 1.15 * settled  # the dip is really in the trace (if it ever disappears, DESIGN 3.4 needs rewriting)
+        # the fused count moves half the bytes in well under the scan's time (round 4: the same time as the scan, 0.33 ms)
+        assert settled <= 215.0 and avg_ns / 1e3 <= 250.0
 
 
 def test_bench_line_beside_the_profiles_agrees(traffic):
-    line = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")))
     assert line["parity_vs_oracle"]["ok"] is True and line["parity_vs_oracle"]["encode_words_compared"] == 31_250_000
     assert line["config"]["library_csrc_sha16"] == line["config"]["csrc_sha16"] == traffic["csrc_sha16"]
     assert list(line)[-1] == "configs"
@@ -74,6 +80,9 @@ def test_bench_line_beside_the_profiles_agrees(traffic):
     # HIP events around a launch include the gap to its neighbour; rocprofv3 times the kernel alone: the bench's figure is the lower one
     assert 0.93 * enc_prof <= cfgs["cfg2_encode"] <= 1.01 * enc_prof, (cfgs["cfg2_encode"], enc_prof)
     assert abs(cfgs["cfg3_kmer_batch"] - traffic["cfg3"]["frac_of_8tb_s"]) < 0.03
-    assert abs(cfgs["cfg5_one_queue_of_64_last16"] - traffic["cfg5"]["last16_frac_of_8tb_s"]) < 0.05
+    # config 5: the line's figure IS the conservative reading (queue of 96 from an idle chip) and agrees with the rocprofv3 trace of the scan alone
+    assert abs(cfgs["cfg5_kmer_hdist_scan"] - traffic["cfg5"]["frac_of_8tb_s"]) < 0.03, (cfgs["cfg5_kmer_hdist_scan"], traffic["cfg5"]["frac_of_8tb_s"])
+    assert abs(cfgs["cfg5_from_idle_last16"] - traffic["cfg5"]["last16_frac_of_8tb_s"]) < 0.03
+    assert cfgs["cfg5_sustained_bursts"] >= cfgs["cfg5_kmer_hdist_scan"]
     assert line["roofline"]["traffic"] and abs(line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"] - 1) < 0.01
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["native_value"] > 0

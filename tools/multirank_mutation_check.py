@@ -14,6 +14,11 @@ and the same four in the single-process form (bitnuc_encode_sharded_allgather_ov
   E  = A there, F = B there, G = D there
   H  the per-rank entry points do not refuse a single-process communicator: the driver's refusal check fails (and the call would
      block for the mock's patience, 60 s, before RCCL-like ncclInternalError)
+and three in the gather of UNEQUAL word counts of a ragged batch split by whole sequences (round 5: bitnuc_allgatherv_words_dev / _all,
+driver modes ragged / ragged_all):
+  I  a peer's slot is received one word too far                         (addressing: first[s] + 1)
+  J  a rank sends its slot with the NEXT rank's word count              (count mismatch: the mock, stricter than NCCL, fails the pair)
+  K  a rank with an empty slot is still sent to / received from as if it held one word (the schedule: messages != non-empty x (P - 1))
 """
 import os
 import shutil
@@ -35,11 +40,15 @@ MUT = {
     "F": ("            if (hipEventRecord(comms[i]->all_moved, comms[i]->xfer) == hipSuccess) (void)hipStreamWaitEvent(ctxs[i]->stream, comms[i]->all_moved, 0);", "            if (false) {}"),
     "G": ("uint64_t *theirs = d_alls[i] + (size_t)s * count + w0;", "uint64_t *theirs = d_alls[i] + (size_t)s * count + w0 + (s == 1 && p == 2 ? 1 : 0);"),
     "H": ("bool per_rank_call_would_block(const bitnuc_comm *comm) { return comm->single_process && !comm->threaded && comm->nranks > 1; }", "bool per_rank_call_would_block(const bitnuc_comm *) { return false; }"),
+    "I": ("if (rc == 0 && counts[s]) rc = r.Recv(d_all + first[s], counts[s], kNcclUint64, s, comm->nccl, stream);", "if (rc == 0 && counts[s]) rc = r.Recv(d_all + first[s] + (s == 1 ? 1 : 0), counts[s], kNcclUint64, s, comm->nccl, stream);"),
+    "J": ("if (counts[me]) rc = r.Send(d_all + first[me], counts[me], kNcclUint64, s, comm->nccl, stream);", "if (counts[me]) rc = r.Send(d_all + first[me], counts[(me + 1) % P], kNcclUint64, s, comm->nccl, stream);"),
+    "K": ("if (rc == 0 && counts[s]) rc = r.Recv(d_all + first[s], counts[s], kNcclUint64, s, comm->nccl, stream);", "if (rc == 0) rc = r.Recv(d_all + first[s], counts[s] ? counts[s] : 1, kNcclUint64, s, comm->nccl, stream);"),
 }
-PER_RANK, ALL_RANKS = "ABCD", "EFGH"
+PER_RANK, ALL_RANKS, RAGGED = "ABCD", "EFGH", "IJK"
 ODD, BIG = 32 * 100_003, 32 * 4_000_003
 SCENARIOS = [(4, ODD, 6, "overlap", 5), (8, ODD, 8, "overlap", 2), (4, BIG, 8, "overlap", 3), (2, BIG, 4, "overlap", 2)]
 SCENARIOS_ALL = [(4, ODD, 6, "overlap_all", 3), (8, ODD, 8, "overlap_all", 2), (4, BIG, 8, "overlap_all", 2), (2, BIG, 4, "overlap_all", 2)]
+SCENARIOS_RAGGED = [(4, 3000, 11, "ragged", 2), (8, 3000, 11, "ragged", 2), (4, 3000, 11, "ragged_all", 2), (8, 5, 3, "ragged_all", 1), (2, 3000, 5, "ragged", 3), (4, 3000, 7, "ragged_threaded", 2)]
 
 
 def main():
@@ -76,10 +85,10 @@ def main():
     noticed, runs = {}, {}
     for name, d in libs.items():
         for delay in (0, 2000):
-            for sc in (SCENARIOS_ALL if name in ALL_RANKS else SCENARIOS + SCENARIOS_ALL if name == "product" else SCENARIOS):
+            for sc in (SCENARIOS_ALL if name in ALL_RANKS else SCENARIOS_RAGGED if name in RAGGED else SCENARIOS + SCENARIOS_ALL + SCENARIOS_RAGGED if name == "product" else SCENARIOS):
                 if name == "H" and (delay or sc[0] != 4 or sc[1] != ODD):
                     continue  # one run shows it (every blocked operation costs the mock's patience, shortened to 0.3 s here)
-                env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([d, mock, os.environ.get("LD_LIBRARY_PATH", "")]), MOCK_RCCL_DELAY_US=str(delay), **({"MOCK_RCCL_PATIENCE_MS": "300"} if name == "H" else {}))
+                env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([d, mock, os.environ.get("LD_LIBRARY_PATH", "")]), MOCK_RCCL_DELAY_US=str(delay), **({"MOCK_RCCL_PATIENCE_MS": "300"} if name in "HJK" else {}))
                 r = subprocess.run([exe, *map(str, sc)], capture_output=True, text=True, timeout=300, env=env)
                 first = (r.stderr.strip().splitlines() or [""])[0][:110]
                 print(f"{name:8s} fabric delay {delay:4d} us  P={sc[0]} shard={sc[1]:>9d} pieces={sc[2]} rounds={sc[4]}: {'ok' if r.returncode == 0 else 'FAILS  ' + first}", flush=True)
@@ -89,8 +98,8 @@ def main():
     for name, k in noticed.items():
         print(f"{name:8s}: {k} of {runs[name]} runs fail")
     shutil.rmtree(work, ignore_errors=True)
-    ok = noticed["product"] == 0 and all(noticed[m] > 0 for m in "ABDEFGH")
-    print("verdict:", "the product passes every run; defects A, B, D (per-rank form) and E, F, G, H (single-process form) are noticed" if ok else "UNEXPECTED")
+    ok = noticed["product"] == 0 and all(noticed[m] > 0 for m in "ABDEFGHIJK")
+    print("verdict:", "the product passes every run; defects A, B, D (per-rank form), E, F, G, H (single-process form) and I, J, K (gather of unequal counts) are noticed" if ok else "UNEXPECTED")
     return 0 if ok else 1
 
 
