@@ -170,6 +170,12 @@ unsigned scan_mfma_grid(const bitnuc_ctx *c, unsigned long long rounds, int U, b
     return (unsigned)(want < cap ? want : cap);
 }
 
+// ... and of the fused count in its own tiling: a bounded number of workgroups (each arrives once at the accumulator and the ticket)
+unsigned count_mfma_grid(const bitnuc_ctx *c, unsigned long long rounds, int U) {
+    const unsigned long long want = rounds / ((kBlock / 64) * (unsigned long long)U) + 1, cap = (unsigned long long)c->num_cu * (unsigned)knobs(c).scan_mfma_count_grid;
+    return (unsigned)(want < cap ? want : cap);
+}
+
 hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, uint64_t query, uint8_t *dist,
                        unsigned long long *slot) {
     uint32_t ql, qh;
@@ -192,7 +198,7 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
 #define SCANM(P, UU, PK, SH, PS) kmer_scan_mfma_kernel<P, UU, false, PK, SH, PS><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, 0u, dist, nullptr, nullptr, nullptr, slot, tab)
 #define SCANM_PS(P, UU, PK, SH) do { if (persist) SCANM(P, UU, PK, SH, true); else SCANM(P, UU, PK, SH, false); } while (0)
 #define SCANM_NT(UU, PK, SH) do { if (ntld) SCANM_PS(3, UU, PK, SH); else SCANM_PS(2, UU, PK, SH); } while (0)
-#define SCANM_U(PK, SH) do { if (U == 2) SCANM_NT(2, PK, SH); else SCANM_NT(4, PK, SH); } while (0)
+#define SCANM_U(PK, SH) do { if (U == 2) SCANM_NT(2, PK, SH); else if (U == 3 && SH == 4 && PK == 1) SCANM_NT(3, 1, 4); else SCANM_NT(4, PK, SH); } while (0)
         if (shift == 0) { if (pack == 0) SCANM_PS(3, 2, 0, 0); else SCANM_PS(3, 2, 1, 0); }
         else if (shift == 1) { if (pack == 0) SCANM_U(0, 1); else if (pack == 1) SCANM_U(1, 1); else SCANM_U(2, 1); }
         else if (shift == 2) { if (pack == 0) SCANM_U(0, 2); else if (pack == 1) SCANM_U(1, 2); else SCANM_U(2, 2); }
@@ -404,9 +410,11 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
         if constexpr (!kEvidenceBuild) {
             // the shipped form: the count's own tiling (segments of 32 windows x 32 shifts: 4 MFMAs per 1024 windows, nothing multiplies zeros), a
             // resident grid (one arrival per workgroup at the ticket), the next trip's loads issued before the current one is computed
+            // Trips of 3 rounds: the strip then lets six waves share a SIMD (four with trips of 4), and 18 workgroups per CU -- three
+            // generations of the six resident ones -- leave the dispatcher room to even out the CUs' tails (profiles/r05_ab_count_grid_sweep*.txt).
             CountMfmaTable ct;
             count_mfma_table(query, k, &ct);
-            kmer_count_mfma_kernel<4, true><<<scan_mfma_grid(c, rounds, 4, true), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
+            kmer_count_mfma_kernel<3, true><<<count_mfma_grid(c, rounds, 3), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
             HIPCHK(hipGetLastError());
             return BITNUC_OK;
         }
@@ -416,8 +424,10 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
         if (knobs(c).scan_mfma_count_form == 1) { // the count's own tiling: segments of 32 windows, 4 MFMAs per 1024 windows
             CountMfmaTable ct;
             count_mfma_table(query, k, &ct);
-            const unsigned g = scan_mfma_grid(c, rounds, knobs(c).scan_mfma_unroll, true);
-            if (knobs(c).scan_mfma_unroll == 2) kmer_count_mfma_kernel<2, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
+            const int CU_ = knobs(c).scan_mfma_count_rounds;
+            const unsigned g = count_mfma_grid(c, rounds, CU_);
+            if (CU_ == 2) kmer_count_mfma_kernel<2, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
+            else if (CU_ == 3) kmer_count_mfma_kernel<3, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
             else kmer_count_mfma_kernel<4, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
             HIPCHK(hipGetLastError());
             return BITNUC_OK;

@@ -57,6 +57,8 @@ struct SweepKnobs {
     int scan_mfma_shift = 4;     // ... the shifted operands: 0 = two more global loads, 1 = the bytes through a wave-private LDS strip, 2 = DPP + scalar halo,
                                  //     3 = the one-hot operands through the strip, 4 = ... with the lane's own operands kept in registers (ships)
     int scan_mfma_count_form = 1;    // ... the fused count: 1 = its own tiling (segments of 32 windows, 4 MFMAs per 1024 windows: kmer_count_mfma_kernel, ships), 0 = the scan's natural-layout tiling
+    int scan_mfma_count_rounds = 3;  // kmer_count_mfma_kernel: rounds per trip (2, 3, 4): 3 lets six waves share a SIMD
+    int scan_mfma_count_grid = 18;   // ... workgroups per CU (six are resident: three generations)
     int scan_mfma_count_persist = 1; // ... the fused count: 1 = a resident grid (ships), 0 = one trip per wave (two atomics per workgroup at the accumulator and the ticket)
     int scan_mfma_persist = 0;   // ... 1 = a resident grid walks the trips with register prefetch, 0 = one trip per wave
     int scan_mfma_pack = 1;      // ... f32 -> u8: 0 = v_cvt_pk_u8_f32, 1 = 2^23 bias + row scales (copied), 2 = ... (bias by a seventh instruction)

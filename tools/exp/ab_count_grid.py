@@ -32,8 +32,8 @@ oracle_py.lib()
 rng = np.random.default_rng(9)
 small_ok = True
 ctx.require_variant("scan_mfma_count_form", 1)
-for U in (4, 2):
-    ctx.require_variant("scan_mfma_unroll", U)
+for U in (4, 3, 2):
+    ctx.require_variant("scan_mfma_count_rounds", U)
     for kk in (1, 2, 15, 16, 17, 31, 32):
         for nn in (kk, 1055, 1056, 1057, 2080, 2081, 4128, 4129, 5153, 9 * 1024 + 77, 200003):
             if nn < kk:
@@ -65,12 +65,22 @@ for U in (4, 2):
                 print(f"own tiling: invalid byte at {pos} reported as {(e.byte, e.index)}")
                 small_ok = False
 print("own tiling, small sizes vs oracle:", "ok" if small_ok else "FAILED", flush=True)
-FORMS = [(4, 4, 1, 0), (4, 4, 1, 1), (4, 2, 1, 1), (4, 4, 0, 0), (4, 2, 1, 0), (3, 4, 1, 0)]  # (shift, rounds per trip, resident grid, count_form)
+KEYS = ("scan_mfma_shift", "scan_mfma_unroll", "scan_mfma_count_rounds", "scan_mfma_count_persist", "scan_mfma_count_form", "scan_mfma_grid", "scan_mfma_count_grid")
+
+
+def knob_values(f):
+    sh, U, cp, cf = f[:4]
+    g = f[4] if len(f) > 4 else 4
+    return (sh, 4 if U == 3 else U, U, cp, cf, min(g, 32), g)  # natural tiling: scan_mfma_unroll / scan_mfma_grid; own tiling: scan_mfma_count_rounds / scan_mfma_count_grid
+
+
+FORMS = [(4, 4, 1, 0), (4, 3, 1, 1, 18), (4, 3, 1, 1, 6), (4, 3, 1, 1, 24), (4, 4, 1, 1, 4), (4, 4, 1, 1, 12), (4, 2, 1, 1, 16)]  # (scan shift, rounds per trip, resident grid, count_form[, workgroups per CU])  # (shift, rounds per trip, resident grid, count_form)
 ok = True
 for tau in (18, 8, 31):
     want = int((d[:n - k + 1] <= tau).sum().item())
-    for sh, U, cp, cf in FORMS:
-        for key, v in (("scan_mfma_shift", sh), ("scan_mfma_unroll", U), ("scan_mfma_count_persist", cp), ("scan_mfma_count_form", cf)):
+    for f in FORMS:
+        sh, U, cp, cf = f[:4]
+        for key, v in zip(KEYS, knob_values(f)):
             ctx.require_variant(key, v)
         for _ in range(2):  # twice: the accumulators must be zero again after a call
             ctx.kmer_hdist_count_dev(ref, n, k, q, tau, cnt)
@@ -105,19 +115,19 @@ def queue(N=96):
     return sum(us) / N, sum(us[-16:]) / 16, max(us[1:])
 
 
-KEYS = ("scan_mfma_shift", "scan_mfma_unroll", "scan_mfma_count_persist", "scan_mfma_count_form")
+
 res = {f: [] for f in FORMS}
 for rnd in range(6):
     for f in FORMS:
-        for key, v in zip(KEYS, f):
+        for key, v in zip(KEYS, knob_values(f)):
             ctx.require_variant(key, v)
         t = burst()
         if rnd:
             res[f].append(t)
 for f in FORMS:
     m = statistics.median(res[f])
-    for key, v in zip(KEYS, f):
+    for key, v in zip(KEYS, knob_values(f)):
         ctx.require_variant(key, v)
     mean, settled, worst = queue()
-    print(f"{'own tiling (4 MFMA)   ' if f[3] else 'natural tiling shift ' + str(f[0])} U {f[1]} {'resident grid + ticket   ' if f[2] else 'one trip per wave + finish'}: bursts {m*1e3:6.1f} us ({(n-k+1)/m/8e7:4.1f} % of 8 TB/s)   from idle: mean of 96 {mean:6.1f} us, last 16 {settled:6.1f} us, slowest {worst:6.1f} us", flush=True)
+    print(f"{'own tiling (4 MFMA)   ' if f[3] else 'natural tiling shift ' + str(f[0])} U {f[1]} grid {f[4] if len(f) > 4 else 4}/CU {'resident grid + ticket   ' if f[2] else 'one trip per wave + finish'}: bursts {m*1e3:6.1f} us ({(n-k+1)/m/8e7:4.1f} % of 8 TB/s)   from idle: mean of 96 {mean:6.1f} us, last 16 {settled:6.1f} us, slowest {worst:6.1f} us", flush=True)
 sys.exit(0 if ok and small_ok else 1)
