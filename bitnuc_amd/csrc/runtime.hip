@@ -330,7 +330,7 @@ constexpr SweepKey kSweepKeys[] = {
     {"scan_mfma_count_grid", &bitnuc_rt::SweepKnobs::scan_mfma_count_grid, 1, 64, 0, {0, 0, 0}},
     {"scan_mfma_count_persist", &bitnuc_rt::SweepKnobs::scan_mfma_count_persist, 0, 1, 0, {0, 0, 0}},
     {"scan_mfma_persist", &bitnuc_rt::SweepKnobs::scan_mfma_persist, 0, 1, 0, {0, 0, 0}},
-    {"scan_mfma_grid", &bitnuc_rt::SweepKnobs::scan_mfma_grid, 1, 32, 0, {0, 0, 0}},
+    {"scan_mfma_grid", &bitnuc_rt::SweepKnobs::scan_mfma_grid, 1, 256, 0, {0, 0, 0}},
     {"scan_mfma_pack", &bitnuc_rt::SweepKnobs::scan_mfma_pack, 0, 2, 0, {0, 0, 0}},
     {"scan_mfma_policy", &bitnuc_rt::SweepKnobs::scan_mfma_policy, 0, 3, 0, {0, 0, 0}},
     {"hdist_tiled", &bitnuc_rt::SweepKnobs::hdist_tiled, 0, 1, 0, {0, 0, 0}},

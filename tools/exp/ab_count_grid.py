@@ -71,7 +71,7 @@ KEYS = ("scan_mfma_shift", "scan_mfma_unroll", "scan_mfma_count_rounds", "scan_m
 def knob_values(f):
     sh, U, cp, cf = f[:4]
     g = f[4] if len(f) > 4 else 4
-    return (sh, 4 if U == 3 else U, U, cp, cf, min(g, 32), g)  # natural tiling: scan_mfma_unroll / scan_mfma_grid; own tiling: scan_mfma_count_rounds / scan_mfma_count_grid
+    return (sh, 4 if U == 3 else U, U, cp, cf, g, g)  # natural tiling: scan_mfma_unroll / scan_mfma_grid; own tiling: scan_mfma_count_rounds / scan_mfma_count_grid
 
 
 FORMS = [(4, 4, 1, 0), (4, 3, 1, 1, 18), (4, 3, 1, 1, 6), (4, 3, 1, 1, 24), (4, 4, 1, 1, 4), (4, 4, 1, 1, 12), (4, 2, 1, 1, 16)]  # (scan shift, rounds per trip, resident grid, count_form[, workgroups per CU])  # (shift, rounds per trip, resident grid, count_form)
