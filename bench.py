@@ -790,6 +790,10 @@ def run_rank(args, real_stdout, traffic):
                 extra["encode_allgather_end_to_end"] = e2e
             else:
                 extra["encode_allgather_end_to_end"] = {"skipped": "needs RCCL (backend nccl on every rank)"}
+            # north_star's own split: a batch of independent sequences, whole sequences per rank, gather of unequal word counts (soft block)
+            wd.arm(max(args.dist_timeout, 240.0), "ragged batch split by whole sequences")
+            extra["ragged_batch_sharded"] = bounded("ragged_batch_sharded", lambda: ragged_batch_block(args, ctx, torch, dist, ctl, rank, world, dev if not rehearse else None, on_gpu_collectives, rehearse, fence, state),
+                                                    min(args.dist_timeout, 200.0), state, torch, dev if not rehearse else None)
             # the fabric roofline of the gather -- the per-link rate is MEASURED on this node
             # (hipMemcpyPeerAsync from rank 0's device to every other rank's device, one link at a time and all at once)
             # while the other ranks wait at a host-side barrier; never quoted from the nominal figure alone.  Soft block, as above.
@@ -875,6 +879,92 @@ def bounded(name, fn, seconds, state, torch, dev):
     if "error" in box:
         return {"error": box["error"]}
     return box.get("value")
+
+
+def ragged_batch_block(args, ctx, torch, dist, ctl, rank, world, dev, on_gpu_collectives, rehearse, fence, state):
+    """north_star's multi-GPU split, measured where a node exists: "batches of independent sequences shard trivially across the 8 GPUs
+    with RCCL all-gather over xGMI only for the final concatenation" (SURVEY 8e sentence 2).  A ragged batch -- 2^20 reads of 0..300 bases per
+    rank, empty ones among them, one 10^7-base sequence that is longer than a fair share -- is split by WHOLE sequences
+    (bitnuc_amd.dist.batch_shard_ranges), every rank plan-encodes its run straight into its slot of the output (no data-path collective) and
+    the UNEQUAL word counts are gathered in place (grouped point-to-point).  Checked literally: every rank also encodes the WHOLE batch by
+    itself and compares all words.  Without a GPU (--rehearse-cpu) the slots hold their global word indices: the exchange alone."""
+    import numpy as np
+    from bitnuc_amd.dist import allgatherv_packed_, batch_shard, batch_shard_ranges
+    per_rank = 2000 if rehearse else 1 << 20
+    count = world * per_rank
+    rng = np.random.default_rng(SEED)  # the same batch on every rank
+    lens = rng.integers(0, 301, size=count).astype(np.uint64)
+    lens[::97] = 0
+    lens[count // 3] = 40_000 if rehearse else 10_000_003
+    off = np.zeros(count + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    seq_first, word_first = batch_shard_ranges(off, world)
+    s0, s1, b0, b1, local, w0, nw = batch_shard(off, rank, world)
+    total_words, total_bases = int(word_first[-1]), int(off[-1])
+    res = {"workload": f"{count} independent sequences of 0..300 bases (every 97th empty) + one of {int(lens[count // 3])} bases, {total_bases} bases, split by whole sequences",
+           "sequences_per_rank": [int(seq_first[r + 1] - seq_first[r]) for r in range(world)],
+           "words_per_rank": [int(word_first[r + 1] - word_first[r]) for r in range(world)], "total_words": total_words}
+    reps = 3
+    if rehearse:
+        out = torch.full((total_words,), -1, dtype=torch.int64)
+        out[w0:w0 + nw] = torch.arange(w0, w0 + nw, dtype=torch.int64)
+        allgatherv_packed_(out, word_first, group=ctl)
+        res["all_slots_ok"] = bool(torch.equal(out, torch.arange(total_words, dtype=torch.int64)))
+    else:
+        import bitnuc_amd
+        seq = torch.empty(b1 - b0 + 64, dtype=torch.uint8, device=dev)
+        if b1 > b0:
+            ctx.nucgen_dev(seq, b1 - b0, SEED + 7, first=b0)  # exactly this rank's bases of the batch's stream
+        plan = bitnuc_amd.BatchPlan(ctx, torch.from_numpy(local.astype(np.int64)).to(dev), s1 - s0)
+        assert plan.total_words == nw, (plan.total_words, nw)
+        out = torch.full((total_words,), -1, dtype=torch.int64, device=dev)
+
+        def encode_mine():
+            if nw:
+                plan.encode_dev(seq, out[w0:w0 + nw])
+
+        def gather():
+            if on_gpu_collectives:
+                allgatherv_packed_(out, word_first, group=ctl)
+                return out
+            host = out.cpu()  # a gloo rehearsal on a GPU box: the exchange runs on host copies
+            allgatherv_packed_(host, word_first, group=ctl)
+            return host.to(dev)
+        encode_mine()
+        full = gather()
+        fence()
+        t = time.perf_counter()
+        for _ in range(reps):
+            encode_mine()
+        fence()
+        res["encode_ms_max_over_ranks_incl_barrier"] = round((time.perf_counter() - t) / reps * 1e3, 3)
+        t = time.perf_counter()
+        for _ in range(reps):
+            full = gather()
+        fence()
+        ag = (time.perf_counter() - t) / reps
+        res["gather_ms"] = round(ag * 1e3, 3)
+        res["gather_gb_s_received_per_gpu"] = round((total_words - nw) * 8 / ag / 1e9, 2)
+        # the check: this rank encodes the WHOLE batch by itself
+        whole = torch.empty(total_bases + 64, dtype=torch.uint8, device=dev)
+        ctx.nucgen_dev(whole, total_bases, SEED + 7)
+        plan_all = bitnuc_amd.BatchPlan(ctx, torch.from_numpy(off.astype(np.int64)).to(dev), count)
+        ref = torch.empty(plan_all.total_words, dtype=torch.int64, device=dev)
+        plan_all.encode_dev(whole, ref)
+        ctx.sync()
+        res["all_slots_ok"] = bool(plan_all.total_words == total_words and torch.equal(full, ref))
+        if not res["all_slots_ok"] and plan_all.total_words == total_words:
+            w = int(torch.nonzero(full != ref)[0])
+            res["first_bad_word"] = w
+            res["first_bad_slot"] = int(np.searchsorted(word_first, w, side="right") - 1)
+        plan.close()
+        plan_all.close()
+        del whole, ref
+    if res["all_slots_ok"] is False:
+        state["rc"] = 3
+    res["note"] = ("whole sequences per rank (no rank encodes part of a sequence), each rank's actual word count gathered in place -- no padding to the largest slot; "
+                   "fabric-bound like config 4's gather, outside the timed step")
+    return res
 
 
 def xgmi_roofline(args, torch, rank, world, local_rank, rehearse, ag):
@@ -1065,12 +1155,12 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
         # SURVEY 8d cfg 5's optional fused output: only the COUNT of windows with d <= tau leaves the chip (1 B read per window)
         cnt1 = torch.zeros(1, dtype=torch.int64, device=dev)
         tau = 8
-        ms = timed(lambda: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1))
+        ms, iso = both(lambda: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1))
         extra["kmer_hdist_count"] = {"workload": f"same scan, fused `d <= {tau}` count instead of the distance bytes (1 B read per window)",
-                                     "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "matches": int(cnt1.item()),
+                                     "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "isolated_ms": round(iso, 4), "timing": SUST, "matches": int(cnt1.item()),
                                      "matches_check": int((dist_out <= tau).sum().item()),
                                      "bound": "vector-instruction issue and the dependent MFMA chain, not HBM (floor 0.145 ms): the count's own tiling (segments of 32 windows x 32 shifts, "
-                                              "4 MFMAs + ~50 vector instructions per 1024 windows, a resident grid) runs 0.185-0.20 ms; on the scan's natural-layout tiling 0.20-0.22; "
+                                              "4 MFMAs + ~50 vector instructions per 1024 windows, trips of 3 rounds, 18 workgroups per CU) runs 0.17-0.18 ms in bursts, 0.185-0.195 settled in one queue; on the scan's natural-layout tiling 0.20-0.22; "
                                               "round 4's bit-plane form 0.30-0.33 (profiles/r05_ab_count_own_tiling.txt, r05_pmc_scan_mfma.txt)",
                                      "algorithmic_gb_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 1), "roofline": hbm(n - k + 1, ms)}
         c96 = timed_queue(torch, stream, lambda i: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1), n_launches=96, idle_s=1.0, every=8)

@@ -35,6 +35,9 @@ def test_self_launch_two_ranks_prints_one_line():
     assert line["allgather_packed"]["all_slots_ok"] is True  # EVERY rank's slot of the gathered buffer against what it must hold
     assert "encode_allgather_end_to_end" in line
     assert "stalled" not in line and "collective_error" not in line
+    # north_star's own split: a ragged batch by whole sequences, gather of unequal word counts (here: the exchange alone, slots hold their word indices)
+    rb = line["ragged_batch_sharded"]
+    assert rb["all_slots_ok"] is True and sum(rb["words_per_rank"]) == rb["total_words"] and len(set(rb["words_per_rank"])) == 2
 
 
 def test_a_wrong_word_in_a_peer_slot_fails_the_run():

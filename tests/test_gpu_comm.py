@@ -81,7 +81,11 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["rccl_ok"] is None
     assert line["allgather_packed"]["own_slot_ok"] is True and "encode_allgather_end_to_end" in line
-    # round 5: every slot of the gathered buffer against the closed form of the seeded stream (2^20 words of each rank's shard here)
+    # round 5: the ragged batch split by whole sequences -- each rank plan-encodes its run on the GPU, unequal word counts gathered (over gloo: on host copies),
+    # every word compared with one rank's encode of the WHOLE batch
+    rb = line["ragged_batch_sharded"]
+    assert rb["all_slots_ok"] is True and sum(rb["words_per_rank"]) == rb["total_words"] and rb["gather_ms"] > 0, rb
+    # ... and every slot of the gathered buffer against the closed form of the seeded stream (2^20 words of each rank's shard here)
     assert line["allgather_packed"]["all_slots_ok"] is True and line["allgather_packed"]["first_bad_slot"] is None
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", "2", "--warmup", "1",
                           "--bases", str(10**7), "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=dict(env, BITNUC_BENCH_PLANT_BAD_SLOT="1"))
