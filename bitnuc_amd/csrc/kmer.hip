@@ -1,7 +1,7 @@
 // kmer.hip -- k-mer compositions of the hot path behind the C ABI (include/bitnuc_hip.h): batched as_2bit over many
 // <= 32-mers (BASELINE config 3, README.md:52-56), every window of a sequence (src/lib.rs:170-173), the sliding pack +
 // Hamming scan (config 5: packing/mod.rs:80-110 o hamming/scalar.rs:11-48) and bulk hdist (hamming/multi.rs:121-160).
-// Kernels: kmer_device.h.
+// Kernels: kmer_device.h; config 5 on the matrix cores: scan_mfma_device.h.
 #include "runtime.h"
 #include "kmer_device.h"
 #include "scan_mfma_device.h"

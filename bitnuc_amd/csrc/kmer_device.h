@@ -1,6 +1,7 @@
 // kmer_device.h -- gfx950 device code for the k-mer compositions of the hot path:
 //   * batched as_2bit over many <=32-mers at a byte stride   (BASELINE config 3)
-//   * sliding-window k-mer pack + Hamming distance to a query (BASELINE config 5)
+//   * sliding-window k-mer pack + Hamming distance to a query (BASELINE config 5): the bit-plane forms of rounds 1-4 -- since round 5 the
+//     shipped form runs on the matrix cores (scan_mfma_device.h); what stays in use from here is the unaligned-pointer path
 //   * bulk packed-vs-packed Hamming distance (hdist)
 //
 // Values follow src/utils/packing/naive.rs:8-18 (pack) and
@@ -10,10 +11,10 @@
 //   kmer_dense_kernel<nt, nt, XCD, 1>                      stride == k batches (config 3)
 //   kmer_batch_kernel<STAGED>                              any other stride, leftovers, unaligned pointers
 //   kmer_slide2_kernel<nt, 4>, kmer_slide_kernel<S>, kmer_slide_any_kernel     every window / small strides -> u64
-//   kmer_scan2_kernel<aligned, nt, nt, 4, COUNT, GEN 1>    config 5 and its fused d <= tau count; kmer_scan_kernel<unaligned> for unaligned pointers
+//   kmer_scan_kernel<unaligned>, kmer_scan2_kernel<unaligned, COUNT>    config 5 and its fused count for UNALIGNED pointers only (aligned: scan_mfma_device.h)
 //   hdist_kernel, nucgen_kernel
-// EVIDENCE BUILD ONLY (-DBITNUC_SWEEP_VARIANTS; csrc/evidence/kmer_evidence.h and the other instantiations of the templates below): kmer_scan_kernel's aligned policies (rounds of 992 windows), kmer_scan2_kernel GEN 0 and
-// its other policies / trip lengths, kmer_scan3_kernel (round 4: a wave owns consecutive rounds), kmer_slide_kernel<1> with rounds per
+// EVIDENCE BUILD ONLY (-DBITNUC_SWEEP_VARIANTS; csrc/evidence/kmer_evidence.h and the other instantiations of the templates below): kmer_scan_kernel's aligned policies (rounds of 992 windows), kmer_scan2_kernel
+// aligned (GEN 1: what round 4 shipped; GEN 0 and its other policies / trip lengths), kmer_scan3_kernel (round 4: a wave owns consecutive rounds), kmer_slide_kernel<1> with rounds per
 // trip, the other dense unrolls / policies -- profiles/NARRATIVE_r01_r03.md 3.3-3.4, profiles/README.md.
 #pragma once
 #include "device_prims.h"

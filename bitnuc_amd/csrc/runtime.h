@@ -1,7 +1,7 @@
 // runtime.h -- internal interface between the translation units of libbitnuc_hip.so (not installed, not part of the C ABI):
 //   runtime.hip   the context: device + stream, error slots and their lifetime, scratch, knobs       (this header's functions)
 //   codec.hip     bulk encode / decode, the single-word API, the pipelined host-pointer path, probes  (codec_device.h)
-//   kmer.hip      k-mer batches, sliding scan, bulk hdist                                            (kmer_device.h)
+//   kmer.hip      k-mer batches, sliding scan (matrix cores), bulk hdist                             (kmer_device.h, scan_mfma_device.h)
 //   batch.hip     ragged / planned / fixed-length batches of reads                                   (batch_device.h)
 //   analysis.hip  base counts, many-pair hdist, split_packed                                         (analysis_device.h)
 //   comm.hip      RCCL all-gather of the packed words, xGMI link probe
@@ -51,8 +51,8 @@ struct SweepKnobs {
                                  // the bit-plane forms (v_alignbit + v_bcnt per window, VALU-issue bound): 1 = line-aligned rounds of 1024 windows, two-LUT planes + scalar halo
                                  // (kmer_scan2_kernel GEN 1: shipped in round 4), 6 = the same with rounds 2-3's plane build (GEN 0), 0 = rounds of 992 windows (kmer_scan_kernel),
                                  // 2 / 3 / 4 / 5 = kmer_scan3_kernel (a wave owns 12 / 20 / 16 / 32 consecutive rounds: slower, profiles/r04_ab_scan3.txt)
-    int scan_mfma_unroll = 4;    // kmer_scan_mfma_kernel: consecutive 1 KiB rounds per wave trip: 2 or 4
-    int scan_mfma_grid = 4;      // ... persistent form: resident 256-thread workgroups per CU
+    int scan_mfma_unroll = 4;    // kmer_scan_mfma_kernel: consecutive 1 KiB rounds per wave trip: 2, 3 or 4 (profiles/r05_ab_scan_trip_length.txt)
+    int scan_mfma_grid = 4;      // ... bounded-grid form (scan_mfma_persist 1): workgroups per CU (profiles/r05_ab_scan_grid*.txt: flatter from idle, 2.5-5 % slower settled)
     int scan_mfma_policy = 3;    // ... bit 0: nt loads (stores are nt)
     int scan_mfma_shift = 4;     // ... the shifted operands: 0 = two more global loads, 1 = the bytes through a wave-private LDS strip, 2 = DPP + scalar halo,
                                  //     3 = the one-hot operands through the strip, 4 = ... with the lane's own operands kept in registers (ships)

@@ -13,9 +13,14 @@
 // exact data): A lane l = row l & 31, K-block l >> 5; B lane l = column l & 31, K-block l >> 5; D lane l register r = column l & 31,
 // row (r & 3) + 8 (r >> 2) + 4 (l >> 5).
 //
-// Tiling: NO lane ever holds anything but its own natural 16 bytes.  A wave round is 1 KiB of windows at a 1 KiB aligned offset
-// (as kmer_scan2_kernel); lane l = (column n = l & 31, half h = l >> 5) loads the 16 bases at 16 l (+ 16 b for b = 1, 2: the next
-// two lanes' bytes, fully coalesced loads that hit the lines the first one brought in) and ends up holding the 16 distances of the
+// WHAT SHIPS (the product library instantiates exactly these two; every other template argument is an alternative that lost its A/B and
+// is compiled into the evidence build only -- profiles/r05_ab_*.txt):
+//   kmer_scan_mfma_kernel<POLICY 3, U 4, COUNT false, PACK 1, SHIFT 4, PERSIST false>   the distance bytes: one trip of four rounds per wave
+//   kmer_count_mfma_kernel<U 3, nt loads>                                                the fused count of d <= tau in its own tiling
+//
+// Tiling of the scan: NO lane ever holds anything but its own natural 16 bytes.  A wave round is 1 KiB of windows at a 1 KiB aligned
+// offset (as kmer_scan2_kernel); lane l = (column n = l & 31, half h = l >> 5) loads the 16 bases at 16 l, obtains the one-hot operands of the
+// next two lanes' bytes (SHIFT below: through a wave-private LDS strip in the shipped form) and ends up holding the 16 distances of the
 // windows that start at those 16 bases: D row m <-> (shift rho = (m & 3) + 4 (m >> 3), half a = (m >> 2) & 1), window =
 // 16 (n + 32 a) + rho, so register r of lane (n, h) is window 16 l + r -- one natural dwordx4 store, no transpose anywhere.
 // The price: A is block-diagonal (row half a only meets K-block a), i.e. half of every instruction multiplies zeros; 6 instructions
@@ -24,8 +29,8 @@
 // Packing the 16 f32 results into 16 bytes costs 2 instructions per 4 windows instead of 4: the accumulator starts at 2^23 (the
 // integer d then sits in the low mantissa bits) and A's rows carry the E8M0 block scale 2^(8 (rho & 3)) for rho & 3 < 3, so three
 // results OR together into bytes 0-2 and a v_perm drops the fourth into byte 3.  Everything is an integer below 2^24: exact.
-// Invalid bytes: checked once per round on the lane's own 16 bytes with the codec's validity residue (device_prims.h); their one-hot
-// is all zero, the call fails with INVALID_BASE anyway.
+// Invalid bytes: checked once per round on the lane's own 16 bytes (a second v_perm LUT on the same index holds the upper-case byte the
+// index stands for: x ^ t is 0 or the case bit for a valid byte); their one-hot is all zero, the call fails with INVALID_BASE anyway.
 #pragma once
 #include "device_prims.h"
 #include "kmer_device.h" // wave_shl1
