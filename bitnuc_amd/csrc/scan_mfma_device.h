@@ -249,7 +249,7 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
                         if ((badr[u] & 0xDFDFDFDFu) != 0u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
                 }
                 if constexpr (!PERSIST) break;
-                cur = nxt;
+                if (rn < rounds) cur = nxt;
                 r0 = rn;
                 continue;
             }
@@ -325,7 +325,7 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
             scan_mfma_emit<COUNT, PACK, NTST>(acc, tauf, hits, dist + wb + 16 * lane);
         }
         if constexpr (!PERSIST) break;
-        cur = nxt;
+        if (rn < rounds) cur = nxt; // (otherwise the loop ends: nothing was loaded into nxt)
         r0 = rn;
     }
 
@@ -451,7 +451,7 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
 #pragma unroll
             for (int r = 0; r < 16; ++r) hits += (uint32_t)__builtin_popcountll(__ballot(acc[r] <= tauf));
         }
-        cur = nxt;
+        if (rn < rounds) cur = nxt; // (otherwise the loop ends: nothing was loaded into nxt)
         r0 = rn;
     }
 
@@ -484,7 +484,9 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
     }
 }
 
-// the second launch of the one-trip-per-wave fused count: sum + re-arm the partial accumulators (stream order makes the first launch's atomics visible)
+#ifdef BITNUC_SWEEP_VARIANTS
+// the second launch of the one-trip-per-wave fused count (evidence build: that form lost its A/B): sum + re-arm the partial accumulators (stream
+// order makes the first launch's atomics visible)
 __global__ void __launch_bounds__(kScanPartials)
 scan_count_finish_kernel(unsigned long long *__restrict__ partials, unsigned long long *__restrict__ result) {
     __shared__ unsigned long long part[kScanPartials / 64];
@@ -500,5 +502,6 @@ scan_count_finish_kernel(unsigned long long *__restrict__ partials, unsigned lon
         *result = s;
     }
 }
+#endif
 
 } // namespace bitnuc_dev
