@@ -1141,12 +1141,16 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
     # launches on a busy chip; and -- the CONSERVATIVE one, the one `configs.cfg5_kmer_hdist_scan` carries -- a queue of 96 launches that
     # starts on an idle chip (1 s of host sleep), which includes the power controller's dip after the first launches and is what a
     # rocprofv3 trace of the scan alone measures (profiles/r05_rocprof/kernel_stats_cfg5.csv).
-    q96 = timed_queue(torch, stream, lambda i: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, douts[i & 1]), n_launches=96, idle_s=1.0, every=8)  # 12 groups of 8
+    # (three such queues, each after its own second of idleness; the one with the MEDIAN mean is reported, all three means beside it: a single
+    # queue now and then contains a group that takes 100 us longer for reasons outside the kernel -- profiles/r05_bench_n1_outlier_group.json)
+    runs = sorted((timed_queue(torch, stream, lambda i: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, douts[i & 1]), n_launches=96, idle_s=1.0, every=8) for _ in range(3)), key=sum)  # 12 groups of 8 each
+    q96 = runs[1]
     extra["kmer_hdist_scan"]["from_idle_queue_of_96"] = {"mean_ms": round(sum(q96) / len(q96), 4), "first8_ms": round(q96[0], 4), "slowest_group_of_8_ms": round(max(q96), 4),
                                                          "last16_ms": round(sum(q96[-2:]) / 2, 4), "mean_frac": hbm(2 * (n - k + 1), sum(q96) / len(q96))["frac"],
                                                          "last16_frac": hbm(2 * (n - k + 1), sum(q96[-2:]) / 2)["frac"],
                                                          "slowest_group_over_settled": round(max(q96) / (sum(q96[-2:]) / 2), 3),
-                                                         "groups_of_8_ms": [round(x, 4) for x in q96]}
+                                                         "groups_of_8_ms": [round(x, 4) for x in q96],
+                                                         "mean_ms_of_the_three_queues": [round(sum(r) / len(r), 4) for r in runs], "reported": "the queue with the median mean"}
     qs = timed_queue(torch, stream, lambda i: ctx.kmer_hdist_scan_dev(seqs[0], n, k, q, douts[i & 1]))
     extra["kmer_hdist_scan"]["one_queue_of_64"] = {"mean_ms": round(sum(qs) / len(qs), 4), "first4_ms": round(sum(qs[:4]) / 4, 4), "slowest_ms": round(max(qs), 4),
                                                    "last16_ms": round(sum(qs[-16:]) / 16, 4), "mean_frac": hbm(2 * (n - k + 1), sum(qs) / len(qs))["frac"],
@@ -1160,11 +1164,13 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
                                      "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "isolated_ms": round(iso, 4), "timing": SUST, "matches": int(cnt1.item()),
                                      "matches_check": int((dist_out <= tau).sum().item()),
                                      "bound": "vector-instruction issue and the dependent MFMA chain, not HBM (floor 0.145 ms): the count's own tiling (segments of 32 windows x 32 shifts, "
-                                              "4 MFMAs + ~50 vector instructions per 1024 windows, trips of 3 rounds, 18 workgroups per CU) runs 0.17-0.18 ms in bursts, 0.185-0.195 settled in one queue; on the scan's natural-layout tiling 0.20-0.22; "
+                                              "4 MFMAs + ~50 vector instructions per 1024 windows, trips of 3 rounds, 18 workgroups per CU) runs 0.170 ms on a cool chip (the first launches of a queue from idle), 0.184 settled, 0.19-0.20 in bursts right after other work; on the scan's natural-layout tiling 0.20-0.22; "
                                               "round 4's bit-plane form 0.30-0.33 (profiles/r05_ab_count_own_tiling.txt, r05_pmc_scan_mfma.txt)",
                                      "algorithmic_gb_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 1), "roofline": hbm(n - k + 1, ms)}
-        c96 = timed_queue(torch, stream, lambda i: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1), n_launches=96, idle_s=1.0, every=8)
-        extra["kmer_hdist_count"]["from_idle_queue_of_96"] = {"mean_ms": round(sum(c96) / len(c96), 4), "last16_ms": round(sum(c96[-2:]) / 2, 4), "slowest_group_of_8_ms": round(max(c96), 4)}
+        cruns = sorted((timed_queue(torch, stream, lambda i: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1), n_launches=96, idle_s=1.0, every=8) for _ in range(3)), key=sum)
+        c96 = cruns[1]
+        extra["kmer_hdist_count"]["from_idle_queue_of_96"] = {"mean_ms": round(sum(c96) / len(c96), 4), "first8_ms": round(c96[0], 4), "last16_ms": round(sum(c96[-2:]) / 2, 4), "slowest_group_of_8_ms": round(max(c96), 4),
+                                                              "mean_ms_of_the_three_queues": [round(sum(r) / len(r), 4) for r in cruns], "reported": "the queue with the median mean"}
     # bulk packed-vs-packed Hamming distance (hdist, hamming/multi.rs:121-160): 16 B per 32-base word pair
     wa, wb = words[0], torch.empty(nw, dtype=torch.int64, device=dev)
     ctx.nucgen_dev(backs[0], n, SEED + 200)
