@@ -385,7 +385,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
 kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
                        unsigned long long *__restrict__ result, unsigned long long *__restrict__ total /* zero between launches */,
                        unsigned *__restrict__ ticket, unsigned long long *__restrict__ slot, const CountMfmaTable tab) {
-    constexpr int kRegion = (32 * U + 1) * 16 + 64; // one (half, parity) region: 32 U entries + the halo's + 16 banks of padding (the two parities of a store do not alias)
+    // one (half, parity) region: 32 U entries + the halo's, padded so that the odd-parity region starts 16 banks (64 B mod 128) after the even one: a
+    // ds_write_b128 serves 8 consecutive lanes at a time = 4 even groups (64 B of region 0) + 4 odd ones (64 B of region 1), which must not share a bank
+    // (round 5's first padding, + 64 B, put them 20 banks apart: SQ_LDS_BANK_CONFLICT = 30 % of the LDS cycles, profiles/r05_pmc_scan_mfma_shipped_forms.txt)
+    constexpr int kRegion = (32 * U + 1) * 16 + 48;
+    static_assert(kRegion % 128 == 64, "the two parities of one store must land 16 banks apart");
     __shared__ __attribute__((aligned(16))) uint8_t strips[kBlock / 64][4 * kRegion];
     const unsigned long long nwin = n - k + 1;
     const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;

@@ -25,7 +25,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "scan" not in name:
+        if "scan" not in name and "kmer_count" not in name:
             continue
         k = name.split("(")[0].replace("void ", "").replace("bitnuc_dev::", "")
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
