@@ -654,6 +654,14 @@ class CommGroup:
                 e.rank = int(err.value) if st == L.INVALID_BASE else None  # whose shard holds the byte
                 raise
 
+    def context(self, rank):
+        """Rank `rank`'s context as a Context object that does NOT own the handle (the group destroys it): for the calls a rank makes
+        on its own device between the group's exchanges -- building a BatchPlan, encoding its run of a ragged batch into its slot."""
+        c = Context.__new__(Context)
+        c._lib, c._h, c.device = self._lib, C.c_void_p(self._ctxs[rank]), None
+        c.close = lambda: None  # the handle is the group's
+        return c
+
     def allgatherv_words(self, counts, d_alls):
         """bitnuc_allgatherv_words_all: every rank's counts[r] words (already at d_alls[r] + sum(counts[:r])) reach every rank's buffer."""
         arr = (C.c_size_t * self.n)(*[int(x) for x in counts])

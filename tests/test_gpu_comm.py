@@ -193,6 +193,66 @@ def test_multi_gpu_sharded_allgather_single_process(oracle, world):
     g.close()
 
 
+@pytest.mark.parametrize("world", [1] + WORLDS)  # world 1: the same code on the one GPU every box has (the gather is then a no-op)
+def test_multi_gpu_ragged_batch_by_whole_sequences_allgatherv(oracle, world):
+    """north_star's split on real GPUs (skipped below `world` devices): a ragged batch -- reads of 0..300 bases, empty ones, one sequence longer
+    than a fair share -- partitioned by whole sequences (bitnuc_batch_shard_ranges), every rank's run plan-encoded on ITS device straight into
+    its slot, the unequal word counts gathered in place by bitnuc_allgatherv_words_all (one thread holds all ranks); every rank's buffer ==
+    one GPU's plan encode of the whole batch == the oracle's per-sequence loop (src/utils/mod.rs:22-25; padding rule packing/avx.rs:147-148)."""
+    if _gpus() < world:
+        pytest.skip(f"needs >= {world} GPUs")
+    import torch
+    import bitnuc_amd as bn
+    rng = np.random.default_rng(1234 + world)
+    count = 20000 * world
+    lens = rng.integers(0, 301, size=count).astype(np.uint64)
+    lens[::97] = 0
+    lens[count // 3] = 3_000_001
+    off = np.zeros(count + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    seq = oracle.nucgen(int(off[-1]), SEED + 5, flags=2)
+    seq_first, word_first = bn.batch_shard_ranges(off, world)
+    total = int(word_first[-1])
+    counts = [int(word_first[r + 1] - word_first[r]) for r in range(world)]
+    # (a rank may be left without a sequence: allowed, it sends nothing)
+    g = bn.CommGroup(world)
+    alls, keep = [], []
+    for r in range(world):
+        d = torch.device("cuda", r)
+        s0, s1 = int(seq_first[r]), int(seq_first[r + 1])
+        local = (off[s0:s1 + 1] - off[s0]).astype(np.int64)
+        mine = torch.from_numpy(seq[int(off[s0]):int(off[s1])].copy()).to(d)
+        out = torch.full((total + 8,), -1, dtype=torch.int64, device=d)
+        c = g.context(r)
+        plan = bn.BatchPlan(c, torch.from_numpy(local).to(d), s1 - s0)
+        assert plan.total_words == counts[r]
+        torch.cuda.synchronize(r)
+        if counts[r]:
+            plan.encode_dev(mine, out[int(word_first[r]):])
+        alls.append(out)
+        keep.append((plan, mine))
+    g.allgatherv_words(counts, alls)  # synchronises every stream
+    c0 = bn.Context(0)
+    plan_all = bn.BatchPlan(c0, torch.from_numpy(off.astype(np.int64)).to("cuda:0"), count)
+    ref = torch.empty(total, dtype=torch.int64, device="cuda:0")
+    plan_all.encode_dev(torch.from_numpy(seq).to("cuda:0"), ref)
+    c0.sync()
+    for r in range(world):
+        got = alls[r].to("cuda:0")
+        assert torch.equal(got[:total], ref) and bool((got[total:] == -1).all()), r
+    # ... and the oracle's per-sequence loop on a prefix of the batch
+    h = ref.cpu().numpy().view(np.uint64)
+    W = np.concatenate([[0], np.cumsum((lens + 31) // 32)]).astype(np.int64)
+    for i in list(range(0, 200)) + [count // 3, count - 1]:
+        s = seq[int(off[i]):int(off[i + 1])]
+        assert np.array_equal(h[W[i]:W[i + 1]], oracle.encode(s) if len(s) else np.zeros(0, np.uint64)), i
+    for plan, _ in keep:
+        plan.close()
+    plan_all.close()
+    c0.close()
+    g.close()
+
+
 @pytest.mark.parametrize("mode", ["sendrecv", "bcast"])
 @pytest.mark.parametrize("world", WORLDS)
 def test_multi_gpu_sharded_allgather_one_process_per_gpu(oracle, tmp_path, world, mode):
