@@ -127,7 +127,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            self._lib.bitnuc_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):  # CommGroup.context(): the handle is the group's
+                self._lib.bitnuc_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -658,8 +659,7 @@ class CommGroup:
         """Rank `rank`'s context as a Context object that does NOT own the handle (the group destroys it): for the calls a rank makes
         on its own device between the group's exchanges -- building a BatchPlan, encoding its run of a ragged batch into its slot."""
         c = Context.__new__(Context)
-        c._lib, c._h, c.device = self._lib, C.c_void_p(self._ctxs[rank]), None
-        c.close = lambda: None  # the handle is the group's
+        c._lib, c._h, c.device, c._borrowed = self._lib, C.c_void_p(self._ctxs[rank]), None, True
         return c
 
     def allgatherv_words(self, counts, d_alls):
