@@ -131,6 +131,7 @@ void scan_mfma_table(uint64_t query, size_t k, ScanMfmaTable *t) {
         lo[16 + i] = (uint8_t)((q != 0 ? 0x02 : 0) | (q != 1 ? 0x20 : 0));
         hi[16 + i] = (uint8_t)((q != 2 ? 0x02 : 0) | (q != 3 ? 0x20 : 0));
     }
+    memset(t->w[16], 0, sizeof t->w[16]);
     for (int rho = 0; rho < 16; ++rho)
         for (int s = 0; s < 6; ++s)
             for (int i = 0; i < 4; ++i) {
@@ -142,12 +143,14 @@ void scan_mfma_table(uint64_t query, size_t k, ScanMfmaTable *t) {
             }
 }
 
-// ... and of the fused count's own tiling (CountMfmaTable): row m of K-block h only depends on delta = m - 8 h
-void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t) {
+// ... and of the fused count's own tiling (CountMfmaTable): row m of K-block h only depends on delta = m - 8 h.
+// thresholded (kmer_count_mfma_kernel's EMIT 1, 2): rows with (m & 3) < 3 carry -1.0 (0b1010) instead of 1.0 -- their results count DOWN from
+// 32 + tau -- and a threshold no window can miss (tau >= k) gets the all-zero table: d = 0 <= min(tau, 31).
+void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t, bool thresholded = false, unsigned tau = 0) {
     uint8_t lo[128], hi[128]; // [32 + i]
     memset(lo, 0, sizeof lo);
     memset(hi, 0, sizeof hi);
-    for (size_t i = 0; i < k; ++i) {
+    for (size_t i = 0; i < k && !(thresholded && tau >= k); ++i) {
         const unsigned q = (unsigned)((query >> (2 * i)) & 3);
         lo[32 + i] = (uint8_t)((q != 0 ? 0x02 : 0) | (q != 1 ? 0x20 : 0));
         hi[32 + i] = (uint8_t)((q != 2 ? 0x02 : 0) | (q != 3 ? 0x20 : 0));
@@ -159,6 +162,7 @@ void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t) {
                 const uint8_t *src = (i & 1) ? hi : lo;
                 uint32_t w = 0;
                 for (int b = 0; b < 4; ++b) w |= (uint32_t)src[32 + p0 + b - d] << (8 * b);
+                if (thresholded && ((d + 8) & 3) != 3) w |= w << 2; // 0b0010 -> 0b1010: the sign bit of every non-zero nibble
                 t->w[d + 8][4 * j + i] = w;
             }
 }
@@ -204,6 +208,7 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
         else if (shift == 2) { if (pack == 0) SCANM_U(0, 2); else if (pack == 1) SCANM_U(1, 2); else SCANM_U(2, 2); }
         else if (shift == 3) { if (pack == 0) SCANM_U(0, 3); else if (pack == 1) SCANM_U(1, 3); else SCANM_U(2, 3); }
         else if (shift == 4) { if (pack == 0) SCANM_U(0, 4); else if (pack == 1) SCANM_U(1, 4); else SCANM_U(2, 4); }
+        else if (shift == 6) SCANM_U(1, 6);
         else { if (pack == 0) SCANM_U(0, 5); else SCANM_U(1, 5); }
 #undef SCANM_U
 #undef SCANM_NT
@@ -412,9 +417,11 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
             // resident grid (one arrival per workgroup at the ticket), the next trip's loads issued before the current one is computed
             // Trips of 3 rounds: the strip then lets six waves share a SIMD (four with trips of 4), and 18 workgroups per CU -- three
             // generations of the six resident ones -- leave the dispatcher room to even out the CUs' tails (profiles/r05_ab_count_grid_sweep*.txt).
+            // The threshold is part of the product (EMIT 2: 6-bit fields 32 + tau - d, three rows per register; v_or3 + v_bitop3 + v_bcnt per four windows,
+            // nothing on the scalar unit), and a trip's registers take the next trip's loads as soon as its bytes are in the strip (profiles/r05_ab_count_emit*.txt).
             CountMfmaTable ct;
-            count_mfma_table(query, k, &ct);
-            kmer_count_mfma_kernel<3, true><<<count_mfma_grid(c, rounds, 3), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
+            count_mfma_table(query, k, &ct, true, tau);
+            kmer_count_mfma_kernel<3, true, 2><<<count_mfma_grid(c, rounds, 3), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
             HIPCHK(hipGetLastError());
             return BITNUC_OK;
         }
@@ -423,12 +430,14 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
         scan_mfma_table(query, k, &tab);
         if (knobs(c).scan_mfma_count_form == 1) { // the count's own tiling: segments of 32 windows, 4 MFMAs per 1024 windows
             CountMfmaTable ct;
-            count_mfma_table(query, k, &ct);
-            const int CU_ = knobs(c).scan_mfma_count_rounds;
+            const int CU_ = knobs(c).scan_mfma_count_rounds, emit = knobs(c).scan_mfma_count_emit;
+            count_mfma_table(query, k, &ct, emit != 0, tau);
             const unsigned g = count_mfma_grid(c, rounds, CU_);
-            if (CU_ == 2) kmer_count_mfma_kernel<2, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
-            else if (CU_ == 3) kmer_count_mfma_kernel<3, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
-            else kmer_count_mfma_kernel<4, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
+#define COUNTOWN(UU, EM) kmer_count_mfma_kernel<UU, true, EM><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct)
+#define COUNTOWN_E(UU) do { if (emit == 0) COUNTOWN(UU, 0); else if (emit == 1) COUNTOWN(UU, 1); else COUNTOWN(UU, 2); } while (0)
+            if (CU_ == 2) COUNTOWN_E(2); else if (CU_ == 3) COUNTOWN_E(3); else COUNTOWN_E(4);
+#undef COUNTOWN_E
+#undef COUNTOWN
             HIPCHK(hipGetLastError());
             return BITNUC_OK;
         }

@@ -56,6 +56,7 @@ struct SweepKnobs {
     int scan_mfma_policy = 3;    // ... bit 0: nt loads (stores are nt)
     int scan_mfma_shift = 4;     // ... the shifted operands: 0 = two more global loads, 1 = the bytes through a wave-private LDS strip, 2 = DPP + scalar halo,
                                  //     3 = the one-hot operands through the strip, 4 = ... with the lane's own operands kept in registers (ships)
+    int scan_mfma_count_emit = 2;    // ... its own tiling's results -> count: 0 = v_cmp + s_bcnt1 per register, 1 = threshold fields inside the product (v_or3 + v_bitop3 + v_bcnt per four windows), 2 = 1 + the next trip loaded into the same registers (ships)
     int scan_mfma_count_form = 1;    // ... the fused count: 1 = its own tiling (segments of 32 windows, 4 MFMAs per 1024 windows: kmer_count_mfma_kernel, ships), 0 = the scan's natural-layout tiling
     int scan_mfma_count_rounds = 3;  // kmer_count_mfma_kernel: rounds per trip (2, 3, 4): 3 lets six waves share a SIMD
     int scan_mfma_count_grid = 18;   // ... workgroups per CU (six are resident: three generations)

@@ -16,7 +16,7 @@
 // WHAT SHIPS (the product library instantiates exactly these two; every other template argument is an alternative that lost its A/B and
 // is compiled into the evidence build only -- profiles/r05_ab_*.txt):
 //   kmer_scan_mfma_kernel<POLICY 3, U 4, COUNT false, PACK 1, SHIFT 4, PERSIST false>   the distance bytes: one trip of four rounds per wave
-//   kmer_count_mfma_kernel<U 3, nt loads>                                                the fused count of d <= tau in its own tiling
+//   kmer_count_mfma_kernel<U 3, nt loads, EMIT 2>                                        the fused count of d <= tau in its own tiling, the threshold inside the product
 //
 // Tiling of the scan: NO lane ever holds anything but its own natural 16 bytes.  A wave round is 1 KiB of windows at a 1 KiB aligned
 // offset (as kmer_scan2_kernel); lane l = (column n = l & 31, half h = l >> 5) loads the 16 bases at 16 l, obtains the one-hot operands of the
@@ -47,7 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // operand, for the row whose windows start rho bases into the lane's 16.  Byte t of dwords {0, 1} (2, 3) belongs to position
 // 16 b + 8 e + t (+ 4): dword 0 / 2 holds channels A (low nibble) and C, dword 1 / 3 channels G and T; a nibble is 1.0 (0b0010)
 // where the channel differs from the query's base at i = position - rho, 0 where it equals it or i is outside [0, k).
-struct ScanMfmaTable { uint32_t w[16][24]; };
+struct ScanMfmaTable { uint32_t w[17][24]; }; // row 16: zeros (SHIFT 6: the rows of the half a lane's K-block does not meet)
 
 // 8 bases (two ASCII dwords) -> 32 one-hot nibbles in the same order
 __device__ __forceinline__ i32x8 onehot8(uint32_t x0, uint32_t x1) {
@@ -70,6 +70,8 @@ __device__ __forceinline__ i32x8 onehot8(uint32_t x0, uint32_t x1) {
 //       three times (the count kernel is VALU-issue bound: each vector instruction per round costs 2 us per 10^9 windows)
 //   4 = as 3, but a lane keeps the operands of its OWN 16 bytes in registers: four ds_read_b128 per round instead of six (the strip
 //       costs 2 x 13 LDS cycles to write and 4 per read, MI355X_MICROARCH.md LDS table; 8 more registers per round of the trip)
+//   6 = as 4 with less bookkeeping: the zero half of the block-diagonal A comes from a seventeenth, all-zero table row instead of 24 v_and per
+//       trip, and the invalid-byte residue is OR-ed over the trip and tested once instead of once per round
 //   5 = as 3 with the trip SOFTWARE-PIPELINED: rounds 0 and 1 are expanded up front, round u + 2 is expanded -- and round u - 1's results
 //       are packed / counted -- in the same basic block as round u's six dependent MFMAs, so that the wave's vector work sits in the 24
 //       issue cycles each 32-cycle MFMA leaves free instead of waiting for the chain to end (profiles/r05_pmc_scan_mfma.txt: in form 4
@@ -145,7 +147,8 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
     constexpr bool NTLD = (POLICY & 1) != 0, NTST = (POLICY & 2) != 0;
     constexpr int kPlane = U * 1024 + 32;                    // a trip's bytes (SHIFT 1) or one of its two operand planes (SHIFT 3): U KiB + the halo
     constexpr bool PIPE = SHIFT == 5;
-    constexpr bool ONEHOT = SHIFT == 3 || SHIFT == 4 || PIPE, KEEP = SHIFT == 4; // (the pipelined form reads all six operands back: its registers go to the second accumulator)
+    constexpr bool LEAN = SHIFT == 6;
+    constexpr bool ONEHOT = SHIFT == 3 || SHIFT == 4 || LEAN || PIPE, KEEP = SHIFT == 4 || LEAN; // (the pipelined form reads all six operands back: its registers go to the second accumulator)
     static_assert(!PIPE || U >= 2, "the pipelined trip expands two rounds ahead");
     constexpr int kStrip = ONEHOT ? 2 * kPlane : kPlane;
     constexpr bool LDS = SHIFT == 1 || ONEHOT;
@@ -169,7 +172,11 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
     for (int s = 0; s < 6; ++s) {
         A[s] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) A[s][i] = (int)(tab.w[rho][4 * s + i] & keep);
+        for (int i = 0; i < 4; ++i) A[s][i] = LEAN ? (int)tab.w[keep ? rho : 16u][4 * s + i] : (int)(tab.w[rho][4 * s + i] & keep);
+    }
+    if constexpr (PERSIST) { // the table's loads end BEFORE the loop: otherwise every trip waits for vmcnt(0) -- its own prefetch -- at its first MFMA (kmer_count_mfma_kernel's note)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(A[s][0]), "+v"(A[s][1]), "+v"(A[s][2]), "+v"(A[s][3]));
     }
     constexpr bool BIAS = !COUNT && PACK != 0;
     const int scale_a = !BIAS ? 127 : 127 + 8 * (int)((m32 & 3u) == 3u ? 0u : (m32 & 3u)); // E8M0: 2^(8 (rho & 3)) for rho & 3 < 3
@@ -256,6 +263,7 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
         }
         if constexpr (ONEHOT) {
             wave_lds_fence(); // the previous trip's readers are done
+            uint32_t trip_bad = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const u32x4 x = cur.v[u][0];
@@ -264,7 +272,8 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
                 uint32_t bad = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
-                if (__builtin_expect((bad & 0xDFDFDFDFu) != 0u && (unsigned)u < m, 0)) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+                if constexpr (LEAN) trip_bad |= bad; // (a clamped copy repeats a round of this trip: nothing it could add)
+                else if (__builtin_expect((bad & 0xDFDFDFDFu) != 0u && (unsigned)u < m, 0)) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
                 const i32x8 e0 = onehot8(x.x, x.y), e1 = onehot8(x.z, x.w);
                 if constexpr (KEEP) { own[u][0] = e0; own[u][1] = e1; }
                 *reinterpret_cast<u32x4 *>(strip + 1024 * u + 16 * lane) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
@@ -274,6 +283,12 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
                 const i32x8 e0 = onehot8(cur.hv.x, cur.hv.y), e1 = onehot8(cur.hv.z, cur.hv.w);
                 *reinterpret_cast<u32x4 *>(strip + 1024 * m + 16 * lane) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
                 *reinterpret_cast<u32x4 *>(strip + kPlane + 1024 * m + 16 * lane) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+            }
+            if constexpr (LEAN) {
+                if (__builtin_expect((trip_bad & 0xDFDFDFDFu) != 0u, 0)) { // some lane of the trip holds an invalid byte: find the round
+#pragma unroll 1
+                    for (unsigned u = 0; u < m; ++u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+                }
             }
             wave_lds_fence();
         }
@@ -380,7 +395,19 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
 // w[delta + 8][4 j + i]: dword i of K-step j for the row with delta = m - 8 h (i = position - m only depends on it), built on the host.
 struct CountMfmaTable { uint32_t w[40][16]; };
 
-template <int U, bool NTLD>
+//
+// EMIT: how 1024 f32 distances become a count.
+//   0 = sixteen v_cmp_le_f32 into wave masks + s_bcnt1 + s_add each (round 5's first form: 16 vector and 32 scalar instructions per round; the
+//       scalar unit is shared by the CU's four SIMDs, and its ~50 instructions per round cost as many issue slots as the ~55 vector ones)
+//   1 = the threshold inside the product: A's entries are -1.0 and its rows carry the E8M0 scale 2^(6 j), j = row & 3 < 3, the accumulator starts at
+//       2^23 + (32 + tau) 2^(6 j): a result's mantissa holds the 6-bit field 32 + tau - d of its row, whose top bit says d <= tau, and three rows OR
+//       into one register.  Row j = 3 (entries +1.0, scale 2, start -(2 tau + 1)) holds 2 d - 2 tau - 1: an odd number below 64 -- six significant
+//       bits, so mantissa bits 17 and below are zero and its SIGN says d <= tau.  (x | b3) & 0x80020820 then has one bit per hit of four windows:
+//       v_or3 + v_bitop3 + v_bcnt (which accumulates) per four windows = 12 vector instructions per round and none on the scalar unit; every
+//       partial sum is an integer below 2^24: exact.  The invalid-byte residue is OR-ed over the trip and tested once.
+//   2 = as 1, and the NEXT trip's loads are issued after this trip's bytes have been expanded into the strip, into the same registers (no second
+//       set of registers, no copy at the end of a trip; the matrix phase of the trip hides the loads)
+template <int U, bool NTLD, int EMIT>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
                        unsigned long long *__restrict__ result, unsigned long long *__restrict__ total /* zero between launches */,
@@ -409,8 +436,22 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
 #pragma unroll
         for (int i = 0; i < 4; ++i) A[j][i] = (int)tab.w[m32 + 8u - 8u * hh][4 * j + i];
     }
+    if constexpr (EMIT != 0) {
+        // a use of the table's registers BEFORE the loop.  The table arrives by global loads (a lane-varying index into the kernel arguments);
+        // left pending into the loop, they make the compiler wait for vmcnt(0) at the first MFMA of EVERY trip -- i.e. for the next trip's
+        // loads, issued a few instructions earlier, whose whole point is to fly during the matrix phase (round 5's first form did that)
+        asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[0][3]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2]), "+v"(A[1][3]),
+                          "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[2][2]), "+v"(A[2][3]), "+v"(A[3][0]), "+v"(A[3][1]), "+v"(A[3][2]), "+v"(A[3][3]));
+    }
     const float tauf = (float)tau;
-    uint32_t hits = 0;
+    uint32_t hits = 0;      // EMIT 0: wave-uniform
+    uint32_t lane_hits = 0; // EMIT 1, 2: per lane
+    const unsigned jrow = m32 & 3u, taup = tau < 31u ? tau : 31u; // (tau >= k: the host passes an all-zero table, d = 0 <= taup)
+    const int scale_a = EMIT == 0 ? 127 : 127 + (jrow == 3u ? 1 : 6 * (int)jrow);
+    f32x16 c0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c0[i] = EMIT == 0 ? 0.f : (i & 3) == 3 ? -(float)(2u * taup + 1u) : 8388608.f + (float)((32u + taup) << (6 * (i & 3)));
+    if constexpr (EMIT != 0) asm volatile("" : "+v"(c0)); // sixteen registers used as an untied C operand (scan_mfma_emit's note)
     // where group g of the trip lives: region (half e, parity g & 1), entry g >> 1
     const unsigned wr0 = (lane & 1u) * kRegion + 16u * (lane >> 1);                 // the lane's own group l of round u: + 2 kRegion e + 512 u
     const unsigned rd = hh * 2u * kRegion + 16u * m32;                              // lane (n, h), K-step j of round u: + (j & 1) kRegion + 16 (32 u + (j >> 1))
@@ -419,15 +460,20 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
         const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
         ScanTrip<U> nxt;
         const unsigned long long rn = r0 + nwaves * U;
-        if (rn < rounds) scan_trip_load<U, 3, NTLD>(ref, rn, rounds, lane, nxt);
+        if constexpr (EMIT != 2) { if (rn < rounds) scan_trip_load<U, 3, NTLD>(ref, rn, rounds, lane, nxt); }
         wave_lds_fence(); // the previous trip's readers are done
+        uint32_t trip_bad = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const u32x4 x = cur.v[u][0];
             uint32_t bad = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
-            if (__builtin_expect((bad & 0xDFDFDFDFu) != 0u && (unsigned)u < m, 0)) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+            if constexpr (EMIT == 0) {
+                if (__builtin_expect((bad & 0xDFDFDFDFu) != 0u && (unsigned)u < m, 0)) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+            } else {
+                trip_bad |= bad; // (a clamped copy repeats a round of this trip: nothing it could add)
+            }
             const i32x8 e0 = onehot8(x.x, x.y), e1 = onehot8(x.z, x.w);
             *reinterpret_cast<u32x4 *>(strip + wr0 + 512 * u) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
             *reinterpret_cast<u32x4 *>(strip + wr0 + 512 * u + 2 * kRegion) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
@@ -437,6 +483,13 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
             *reinterpret_cast<u32x4 *>(strip + lane * kRegion + 512 * m) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
             *reinterpret_cast<u32x4 *>(strip + lane * kRegion + 512 * m + 2 * kRegion) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
         }
+        if constexpr (EMIT != 0) {
+            if (__builtin_expect((trip_bad & 0xDFDFDFDFu) != 0u, 0)) { // some lane of the trip holds an invalid byte: find the round
+#pragma unroll 1
+                for (unsigned u = 0; u < m; ++u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+            }
+        }
+        if constexpr (EMIT == 2) { if (rn < rounds) scan_trip_load<U, 3, NTLD>(ref, rn, rounds, lane, cur); } // cur's bytes are in the strip: its registers take the next trip
         wave_lds_fence();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -447,15 +500,23 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
                 const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + rd + (j & 1) * kRegion + 16 * (32 * u + (j >> 1)));
                 B[j] = i32x8{(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
             }
-            f32x16 acc;
+            f32x16 acc = c0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[j], acc, 4, 4, 0, scale_a, 0, 127);
+            if constexpr (EMIT == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[j], acc, 4, 4, 0, 127, 0, 127);
+                for (int r = 0; r < 16; ++r) hits += (uint32_t)__builtin_popcountll(__ballot(acc[r] <= tauf));
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hits += (uint32_t)__builtin_popcountll(__ballot(acc[r] <= tauf));
+                for (int q = 0; q < 4; ++q) {
+                    // (__float_as_uint on a copy: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
+                    const float d0 = acc[4 * q], d1 = acc[4 * q + 1], d2 = acc[4 * q + 2], d3 = acc[4 * q + 3];
+                    const uint32_t x = __float_as_uint(d0) | __float_as_uint(d1) | __float_as_uint(d2);
+                    lane_hits += (uint32_t)__builtin_popcount((x | __float_as_uint(d3)) & 0x80020820u);
+                }
+            }
         }
-        if (rn < rounds) cur = nxt; // (otherwise the loop ends: nothing was loaded into nxt)
+        if constexpr (EMIT != 2) { if (rn < rounds) cur = nxt; } // (otherwise the loop ends: nothing was loaded into nxt)
         r0 = rn;
     }
 
@@ -475,6 +536,7 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
         const unsigned long long x = (w ^ query) & kmask;
         tail_hits += (uint32_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull) <= tau ? 1u : 0u;
     }
+    tail_hits += lane_hits;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tail_hits += __shfl_xor(tail_hits, off);
     __shared__ uint32_t part[kBlock / 64];

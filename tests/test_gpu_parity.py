@@ -157,7 +157,7 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
                                  ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 7, (0, 1, 2, 6)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
-                                 ("scan_mfma_shift", 4, (0, 1, 2, 3, 5)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2, 3)), ("scan_mfma_persist", 0, (1,)), ("scan_mfma_count_persist", 1, (0,)), ("scan_mfma_count_form", 1, (0,)), ("scan_mfma_count_rounds", 3, (2, 4)), ("scan_mfma_count_grid", 18, (4,)),
+                                 ("scan_mfma_shift", 4, (0, 1, 2, 3, 5)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2, 3)), ("scan_mfma_persist", 0, (1,)), ("scan_mfma_count_persist", 1, (0,)), ("scan_mfma_count_form", 1, (0,)), ("scan_mfma_count_emit", 2, (0, 1)), ("scan_mfma_count_rounds", 3, (2, 4)), ("scan_mfma_count_grid", 18, (4,)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,)),
                                  ("batch_dense", 1, (0,)), ("batch_slide", 1, (0,)), ("batch_host_plan", 1, (0,)), ("fixed_stream", 1, (0,)), ("owner_est", 3, (0, 1, 2)),
                                  ("plan_enc_block", 256, (64, 128)), ("kmer_block", 256, (64, 128)), ("hdist_tiled", 0, (1,)), ("hdist_words_impl", 1, (0,)),
@@ -501,7 +501,7 @@ SCAN_FORMS = [("ships", {})] + \
     [(f"mfma-shift{sh}-pack{pk}-U{u}-persist{ps}", dict(scan_mfma_shift=sh, scan_mfma_pack=pk, scan_mfma_unroll=u, scan_mfma_persist=ps))
      for sh, pk, u, ps in ((4, 1, 4, 1), (4, 0, 2, 0), (4, 2, 4, 0), (4, 1, 3, 0), (5, 0, 4, 0), (5, 1, 2, 1), (3, 1, 4, 0), (3, 0, 2, 1), (1, 1, 4, 0), (1, 2, 2, 1), (2, 1, 4, 0), (2, 0, 2, 1), (0, 1, 2, 1), (0, 0, 2, 0))] + \
     [(f"bitplane-impl{i}-unroll{u}", dict(scan_impl=i, scan_unroll=u)) for i, u in ((1, 4), (1, 2), (1, 1), (6, 4), (0, 4), (0, 2), (0, 1), (2, 4), (3, 4), (4, 4))]
-SCAN_DEFAULTS = dict(scan_impl=7, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1, scan_mfma_count_form=1, scan_mfma_count_rounds=3, scan_mfma_count_grid=18)
+SCAN_DEFAULTS = dict(scan_impl=7, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1, scan_mfma_count_form=1, scan_mfma_count_emit=2, scan_mfma_count_rounds=3, scan_mfma_count_grid=18)
 
 
 @pytest.mark.parametrize("form", SCAN_FORMS, ids=[name for name, _ in SCAN_FORMS])
@@ -574,39 +574,51 @@ def test_scan_matrix_core_forms_first_invalid_byte_and_count(ctx, sweep_ctx, ora
                 ctx.require_variant(key, v)
 
 
-@pytest.mark.parametrize("U,grid", [(3, 18), (4, 4), (2, 16), (3, 1)], ids=["ships-trips-of-3", "evidence-trips-of-4", "evidence-trips-of-2", "evidence-one-workgroup-per-CU"])
-def test_fused_count_own_tiling_vs_oracle(ctx, sweep_ctx, oracle, U, grid):
-    """kmer_count_mfma_kernel (segments of 32 windows x 32 shifts, 4 MFMAs per 1024 windows): the count of d <= tau for every k, at sizes around
-    the rounds, the trips and the 32-byte halo, equals the count over the oracle's distance bytes (hamming/scalar.rs:11-48 over naive.rs:3-20 per
-    window); the first invalid byte is reported with its index; back-to-back launches find the accumulator re-armed."""
+@pytest.mark.parametrize("U,grid,emit", [(3, 18, 2), (3, 18, 0), (3, 18, 1), (4, 4, 2), (2, 16, 1), (4, 12, 0), (3, 1, 2)],
+                         ids=["ships", "evidence-compare-per-register", "evidence-threshold-in-product-second-register-set", "evidence-trips-of-4", "evidence-trips-of-2",
+                              "evidence-trips-of-4-compare-per-register", "evidence-one-workgroup-per-CU"])
+def test_fused_count_own_tiling_vs_oracle(ctx, sweep_ctx, oracle, U, grid, emit):
+    """kmer_count_mfma_kernel (segments of 32 windows x 32 shifts, 4 MFMAs per 1024 windows; the threshold inside the product in the shipped form): the
+    count of d <= tau for every k, at sizes around the rounds, the trips and the 32-byte halo, on random data and on data where most windows are hits, for
+    thresholds on both sides of k (tau >= k: every window counts; tau up to 2^32 - 1), equals the count over the oracle's distance bytes
+    (hamming/scalar.rs:11-48 over naive.rs:3-20 per window); the first invalid byte is reported with its index; back-to-back launches find the
+    accumulator re-armed."""
     import bitnuc_amd as bn
     import torch
     dev = torch.device("cuda:0")
-    shipped = (U, grid) == (3, 18)
+    shipped = (U, grid, emit) == (3, 18, 2)
     if not shipped:
         ctx = sweep_ctx
-        for key, v in {**SCAN_DEFAULTS, "scan_mfma_count_rounds": U, "scan_mfma_count_grid": grid}.items():
+        for key, v in {**SCAN_DEFAULTS, "scan_mfma_count_rounds": U, "scan_mfma_count_grid": grid, "scan_mfma_count_emit": emit}.items():
             ctx.require_variant(key, v)
     try:
-        assert ctx.get("scan_mfma_count_form") == 1 and ctx.get("scan_mfma_count_rounds") == U
+        assert ctx.get("scan_mfma_count_form") == 1 and ctx.get("scan_mfma_count_rounds") == U and ctx.get("scan_mfma_count_emit") == emit
         rng = np.random.default_rng(41 + U)
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
         for k in (1, 2, 15, 16, 17, 31, 32):
             for n in (k, 1055, 1056, 1057, 2080, 2081, 3104, 3105, 4128, 4129, 5153, 6 * 1024 + 32, 6 * 1024 + 33, 8 * 1024 + 32, 9 * 1024 + 77, 200003, 3 * 10**6 + 77):
                 if n < k or (n > 10**6 and k not in (31, 32)):
                     continue
-                s = ALPHA8[rng.integers(0, 8, size=n)]
                 q = int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 4)) << 62)
-                t = torch.from_numpy(s).to(dev)
-                d = oracle.kmer_hdist_scan(s, k, q)
-                for tau in (0, k // 2, k):
-                    torch.cuda.synchronize()
-                    ctx.kmer_hdist_count_dev(t, n, k, q, tau, cnt)
-                    ctx.kmer_hdist_count_dev(t, n, k, q, tau, cnt)
-                    ctx.sync()
-                    assert int(cnt.item()) == int((d <= tau).sum()), (k, n, tau)
+                for kind in ("random", "periodic"):
+                    if kind == "random":
+                        s = ALPHA8[rng.integers(0, 8, size=n)]
+                    elif n > 10**6:
+                        continue
+                    else:  # the query's own bases repeated, with a few substitutions: the windows at multiples of k are hits or near hits
+                        unit = np.array([ord("ACGT"[(q >> (2 * i)) & 3]) for i in range(k)], dtype=np.uint8)
+                        s = np.tile(unit, n // k + 1)[:n].copy()
+                        s[rng.integers(0, n, size=max(1, n // 50))] = ord("a")
+                    t = torch.from_numpy(s).to(dev)
+                    d = oracle.kmer_hdist_scan(s, k, q)
+                    for tau in sorted({0, 1, k // 2, k - 1, k, k + 1, 31, 32, 33, 2**32 - 1}):
+                        torch.cuda.synchronize()
+                        ctx.kmer_hdist_count_dev(t, n, k, q, tau, cnt)
+                        ctx.kmer_hdist_count_dev(t, n, k, q, tau, cnt)
+                        ctx.sync()
+                        assert int(cnt.item()) == int((d <= tau).sum()), (k, n, tau, kind)
         s = ALPHA8[rng.integers(0, 8, size=50000)].copy()
-        for pos in (0, 15, 16, 1023, 1024, 1040, 1055, 1056, 4095, 4096, 4097, 4127, 4128, 30000, 49999):
+        for pos in (0, 15, 16, 1023, 1024, 1040, 1055, 1056, 3071, 3072, 3104, 4095, 4096, 4097, 4127, 4128, 30000, 49999):
             b = s.copy()
             b[pos] = ord("N")
             if pos + 9 < b.size:

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""The matrix-core scan (distance bytes): one trip per wave (the dispatcher walks 61 K workgroups) against a bounded grid whose waves walk several trips with register prefetch (scan_mfma_persist 1, scan_mfma_grid workgroups per CU): the strip
-lets 4 / 6 / 9 workgroups share a CU.  Bursts of 8 and a 96-launch queue from an idle chip in groups of 8; outputs compared."""
+"""The matrix-core scan (distance bytes), one trip of four rounds per wave: the shipped form (scan_mfma_shift 4) against the same with less bookkeeping
+(6: the zero half of the block-diagonal A from an all-zero table row instead of 24 v_and per trip, the invalid-byte residue tested once per trip
+instead of once per round).  Bursts of 8 and a 96-launch queue from an idle chip in groups of 8, interleaved twice; outputs compared; invalid bytes
+planted at round / trip boundaries must be reported by both."""
 import os
 import statistics
 import sys
@@ -21,12 +23,12 @@ ref = torch.empty(n, dtype=torch.uint8, device=dev)
 ctx.nucgen_dev(ref, n, 0xB17C0DE)
 outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
 ctx.sync()
-FORMS = [(0, 4)] + [(1, g) for g in (8, 16, 32, 48, 64, 96)]  # (persist, workgroups per CU)
+FORMS = [4, 6]  # scan_mfma_shift
 
 
 def use(f):
-    ctx.require_variant("scan_mfma_persist", f[0])
-    ctx.require_variant("scan_mfma_grid", f[1])
+    ctx.require_variant("scan_mfma_persist", 0)
+    ctx.require_variant("scan_mfma_shift", f)
 
 
 base = None
@@ -39,6 +41,25 @@ for U in FORMS:
         base = d
     else:
         print(f"form {U} == one trip per wave: {torch.equal(d, base)}", flush=True)
+import numpy as np
+host = ref[:50000].cpu().numpy()
+for f in FORMS:
+    use(f)
+    for pos in (0, 15, 16, 1023, 1024, 1040, 1055, 1056, 4095, 4096, 4097, 4127, 4128, 30000, 49999):
+        b = host.copy()
+        b[pos] = ord("N")
+        if pos + 9 < b.size:
+            b[pos + 9] = ord("X")
+        tb = torch.from_numpy(b).to(dev)
+        torch.cuda.synchronize()
+        ctx.kmer_hdist_scan_dev(tb, b.size, 31, q, outs[0])
+        try:
+            ctx.sync()
+            print(f"shift {f}: invalid byte at {pos} NOT reported")
+        except bitnuc_amd.NucleotideError as e:
+            if (e.byte, e.index) != (ord("N"), pos):
+                print(f"shift {f}: invalid byte at {pos} reported as {(e.byte, e.index)}")
+print("invalid bytes: checked", flush=True)
 flip = [0]
 
 
@@ -79,9 +100,9 @@ for rnd in range(7):
         t = burst()
         if rnd:
             res[U].append(t)
-for rep in range(2):
+for rep in range(3):
     for U in FORMS:
         use(U)
         g = queue()
         m = statistics.median(res[U])
-        print(f"{'one trip per wave      ' if not U[0] else 'bounded grid, ' + str(U[1]).rjust(2) + ' per CU'}: bursts {m*1e3:6.1f} us ({alg/m/8e7:4.1f} %)   from idle: mean {sum(g)/len(g):6.1f} us ({alg/(sum(g)/len(g))/8e4:4.1f} %), settled {sum(g[-2:])/2:6.1f}, slowest group {max(g):6.1f}   groups: {' '.join(f'{x:.0f}' for x in g)}", flush=True)
+        print(f"scan_mfma_shift {U}: bursts {m*1e3:6.1f} us ({alg/m/8e7:4.1f} %)   from idle: mean {sum(g)/len(g):6.1f} us ({alg/(sum(g)/len(g))/8e4:4.1f} %), settled {sum(g[-2:])/2:6.1f}, slowest group {max(g):6.1f}   groups: {' '.join(f'{x:.0f}' for x in g)}", flush=True)
