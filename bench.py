@@ -706,7 +706,11 @@ def run_rank(args, real_stdout, traffic):
                            "cfg5_sustained_bursts": frac("kmer_hdist_scan"),
                            "cfg5_one_queue_of_64_mean": (scan.get("one_queue_of_64") or {}).get("mean_frac"),
                            "cfg5_one_queue_of_64_last16": (scan.get("one_queue_of_64") or {}).get("last16_frac"),
-                           "cfg5_fused_count": frac("kmer_hdist_count"),
+                           # ... and its fused count read the same way: the mean of a 96-launch queue from an idle chip (the first launches run on a cool chip, the middle in the dip)
+                           "cfg5_fused_count": ((extra.get("kmer_hdist_count") or {}).get("from_idle_queue_of_96") or {}).get("mean_frac"),
+                           "cfg5_fused_count_first8": ((extra.get("kmer_hdist_count") or {}).get("from_idle_queue_of_96") or {}).get("first8_frac"),
+                           "cfg5_fused_count_last16": ((extra.get("kmer_hdist_count") or {}).get("from_idle_queue_of_96") or {}).get("last16_frac"),
+                           "cfg5_fused_count_burst_after_the_scan_queues": frac("kmer_hdist_count"),
                            "unit": "fraction of 8 TB/s HBM3E on algorithmic bytes; null = block not run"}
         return line
 
@@ -1163,13 +1167,17 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
         extra["kmer_hdist_count"] = {"workload": f"same scan, fused `d <= {tau}` count instead of the distance bytes (1 B read per window)",
                                      "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "isolated_ms": round(iso, 4), "timing": SUST, "matches": int(cnt1.item()),
                                      "matches_check": int((dist_out <= tau).sum().item()),
-                                     "bound": "vector-instruction issue and the dependent MFMA chain, not HBM (floor 0.145 ms): the count's own tiling (segments of 32 windows x 32 shifts, "
-                                              "4 MFMAs + ~50 vector instructions per 1024 windows, trips of 3 rounds, 18 workgroups per CU) runs 0.170 ms on a cool chip (the first launches of a queue from idle), 0.184 settled, 0.19-0.20 in bursts right after other work; on the scan's natural-layout tiling 0.20-0.22; "
-                                              "round 4's bit-plane form 0.30-0.33 (profiles/r05_ab_count_own_tiling.txt, r05_pmc_scan_mfma.txt)",
+                                     "bound": "HBM while the clock is high (bursts on a cool chip: 0.153-0.160 ms = 0.78-0.82 of 8 TB/s), the CU's cycles once it has fallen (the count's own tiling: segments of 32 windows x "
+                                              "32 shifts, per 1024 windows 4 MFMAs + ~45 vector instructions -- the threshold is inside the product: 6-bit fields 32 + tau - d, three rows per register, v_or3 + v_bitop3 + v_bcnt per four "
+                                              "windows, nothing on the scalar unit -- trips of 3 rounds, 18 workgroups per CU; `ms` here is a burst right after the scan's queues, i.e. inside the power controller's dip; "
+                                              "from_idle_queue_of_96 is the reading `configs.cfg5_fused_count` carries); round 5's first form (v_cmp + s_bcnt1 per register) 0.177 / 0.186 / 0.202, the scan's natural-layout tiling 0.20-0.22, "
+                                              "round 4's bit-plane form 0.30-0.33 (profiles/r05_ab_count_emit*.txt, r05_ab_count_own_tiling.txt, r05_pmc_scan_mfma_emit.txt)",
                                      "algorithmic_gb_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 1), "roofline": hbm(n - k + 1, ms)}
         cruns = sorted((timed_queue(torch, stream, lambda i: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1), n_launches=96, idle_s=1.0, every=8) for _ in range(3)), key=sum)
         c96 = cruns[1]
         extra["kmer_hdist_count"]["from_idle_queue_of_96"] = {"mean_ms": round(sum(c96) / len(c96), 4), "first8_ms": round(c96[0], 4), "last16_ms": round(sum(c96[-2:]) / 2, 4), "slowest_group_of_8_ms": round(max(c96), 4),
+                                                              "mean_frac": hbm(n - k + 1, sum(c96) / len(c96))["frac"], "first8_frac": hbm(n - k + 1, c96[0])["frac"], "last16_frac": hbm(n - k + 1, sum(c96[-2:]) / 2)["frac"],
+                                                              "groups_of_8_ms": [round(x, 4) for x in c96],
                                                               "mean_ms_of_the_three_queues": [round(sum(r) / len(r), 4) for r in cruns], "reported": "the queue with the median mean"}
     # bulk packed-vs-packed Hamming distance (hdist, hamming/multi.rs:121-160): 16 B per 32-base word pair
     wa, wb = words[0], torch.empty(nw, dtype=torch.int64, device=dev)

@@ -66,8 +66,9 @@ def test_configs_3_and_5_alone_from_the_raw_csvs(traffic, cfg, kernel, alg):
         assert alg / (settled * 1e3) / PEAK >= 0.77 and alg / avg_ns / PEAK >= 0.74
         assert avg_ns / 1e3 <= 1.05 * settled and max(series[1:]) <= 1.32 * settled
     else:
-        # the fused count moves half the bytes in well under the scan's time (round 4: the same time as the scan, 0.33 ms)
-        assert settled <= 215.0 and avg_ns / 1e3 <= 250.0
+        # the fused count moves half the bytes in well under the scan's time (round 4: the same time as the scan, 0.33 ms); its first launches -- a cool
+        # chip -- run at the HBM plateau
+        assert settled <= 195.0 and avg_ns / 1e3 <= 215.0 and sum(series[1:9]) / 8 <= 175.0
 
 
 def test_bench_line_beside_the_profiles_agrees(traffic):
@@ -84,5 +85,8 @@ def test_bench_line_beside_the_profiles_agrees(traffic):
     assert abs(cfgs["cfg5_kmer_hdist_scan"] - traffic["cfg5"]["frac_of_8tb_s"]) < 0.03, (cfgs["cfg5_kmer_hdist_scan"], traffic["cfg5"]["frac_of_8tb_s"])
     assert abs(cfgs["cfg5_from_idle_last16"] - traffic["cfg5"]["last16_frac_of_8tb_s"]) < 0.03
     assert cfgs["cfg5_sustained_bursts"] >= cfgs["cfg5_kmer_hdist_scan"]
+    # ... and so is the fused count's
+    assert abs(cfgs["cfg5_fused_count"] - traffic["cfg5count"]["frac_of_8tb_s"]) < 0.03, (cfgs["cfg5_fused_count"], traffic["cfg5count"]["frac_of_8tb_s"])
+    assert cfgs["cfg5_fused_count_first8"] >= cfgs["cfg5_fused_count_last16"] >= cfgs["cfg5_fused_count"]
     assert line["roofline"]["traffic"] and abs(line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"] - 1) < 0.01
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["native_value"] > 0

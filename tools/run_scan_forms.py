@@ -29,4 +29,9 @@ for f in FORMS:
     for _ in range(N):
         ctx.kmer_hdist_count_dev(ref, n, k, q, 18, cnt)
     ctx.sync()
+for emit in (0, 1, 2):  # the fused count's own tiling: how a round's 1024 distances become a count (kmer_count_mfma_kernel<3, true, EMIT>)
+    ctx.require_variant("scan_mfma_count_emit", emit)
+    for _ in range(N):
+        ctx.kmer_hdist_count_dev(ref, n, k, q, 18, cnt)
+    ctx.sync()
 print("done", int(cnt.item()))
