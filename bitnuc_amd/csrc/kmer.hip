@@ -122,15 +122,23 @@ void query_planes(uint64_t query, size_t k, uint32_t *ql, uint32_t *qh) {
 
 // The query's operand of the matrix-core scan (scan_mfma_device.h: ScanMfmaTable): per window shift rho and K-step, the nibbles that
 // are 1.0 where a channel differs from the query's base (hamming/scalar.rs:33-47 counts the differing 2-bit fields).
-void scan_mfma_table(uint64_t query, size_t k, ScanMfmaTable *t) {
+// match = true: the nibbles are -1.0 (0b1010) where a channel EQUALS the query's base and the accumulators start at 2^23 + k 2^(8 (r & 3)) (r & 3 = 3: 2^23 + k): the
+// product counts the matches down from k -- the same distance with a third of the non-zero entries (one channel of four instead of three).
+void scan_mfma_table(uint64_t query, size_t k, ScanMfmaTable *t, bool match = false) {
     uint8_t lo[80], hi[80]; // [16 + i]: channels (A, C) and (G, T) of query position i; zero outside [0, k)
     memset(lo, 0, sizeof lo);
     memset(hi, 0, sizeof hi);
     for (size_t i = 0; i < k; ++i) {
         const unsigned q = (unsigned)((query >> (2 * i)) & 3);
-        lo[16 + i] = (uint8_t)((q != 0 ? 0x02 : 0) | (q != 1 ? 0x20 : 0));
-        hi[16 + i] = (uint8_t)((q != 2 ? 0x02 : 0) | (q != 3 ? 0x20 : 0));
+        if (match) {
+            lo[16 + i] = (uint8_t)((q == 0 ? 0x0A : 0) | (q == 1 ? 0xA0 : 0));
+            hi[16 + i] = (uint8_t)((q == 2 ? 0x0A : 0) | (q == 3 ? 0xA0 : 0));
+        } else {
+            lo[16 + i] = (uint8_t)((q != 0 ? 0x02 : 0) | (q != 1 ? 0x20 : 0));
+            hi[16 + i] = (uint8_t)((q != 2 ? 0x02 : 0) | (q != 3 ? 0x20 : 0));
+        }
     }
+    for (int j = 0; j < 4; ++j) t->c[j] = 8388608.f + (match ? (float)((unsigned)k << (j == 3 ? 0 : 8 * j)) : 0.f);
     memset(t->w[16], 0, sizeof t->w[16]);
     for (int rho = 0; rho < 16; ++rho)
         for (int s = 0; s < 6; ++s)
@@ -144,17 +152,33 @@ void scan_mfma_table(uint64_t query, size_t k, ScanMfmaTable *t) {
 }
 
 // ... and of the fused count's own tiling (CountMfmaTable): row m of K-block h only depends on delta = m - 8 h.
-// thresholded (kmer_count_mfma_kernel's EMIT 1, 2): rows with (m & 3) < 3 carry -1.0 (0b1010) instead of 1.0 -- their results count DOWN from
-// 32 + tau -- and a threshold no window can miss (tau >= k) gets the all-zero table: d = 0 <= min(tau, 31).
-void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t, bool thresholded = false, unsigned tau = 0) {
+// thresholded (kmer_count_mfma_kernel's EMIT 1, 2): result register r (rows with m & 3 = r & 3 = j) must end at 2^23 + (32 + tau - d) 2^(6 j) for j < 3 and at
+// 2 d - 2 tau - 1 for j = 3 (scan_mfma_device.h).  match = false: the entries mark the channels that DIFFER from the query's base (-1.0 for j < 3, +1.0 for j = 3)
+// and the accumulators start at 2^23 + (32 + tau) 2^(6 j) / -(2 tau + 1).  match = true: they mark the channel that EQUALS it (+1.0 / -1.0: a third of the non-zero
+// entries), d = k - matches, and the accumulators start at 2^23 + (32 + tau - k) 2^(6 j) / 2 k - 2 tau - 1.  A threshold no window can miss (tau >= k) gets the
+// all-zero table and the start values of tau = k: every field reads 32, every j = 3 result -1.
+void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t, bool thresholded = false, unsigned tau = 0, bool match = false) {
     uint8_t lo[128], hi[128]; // [32 + i]
     memset(lo, 0, sizeof lo);
     memset(hi, 0, sizeof hi);
-    for (size_t i = 0; i < k && !(thresholded && tau >= k); ++i) {
+    const bool all = thresholded && tau >= k;
+    for (size_t i = 0; i < k && !all; ++i) {
         const unsigned q = (unsigned)((query >> (2 * i)) & 3);
-        lo[32 + i] = (uint8_t)((q != 0 ? 0x02 : 0) | (q != 1 ? 0x20 : 0));
-        hi[32 + i] = (uint8_t)((q != 2 ? 0x02 : 0) | (q != 3 ? 0x20 : 0));
+        if (thresholded && match) {
+            lo[32 + i] = (uint8_t)((q == 0 ? 0x02 : 0) | (q == 1 ? 0x20 : 0));
+            hi[32 + i] = (uint8_t)((q == 2 ? 0x02 : 0) | (q == 3 ? 0x20 : 0));
+        } else {
+            lo[32 + i] = (uint8_t)((q != 0 ? 0x02 : 0) | (q != 1 ? 0x20 : 0));
+            hi[32 + i] = (uint8_t)((q != 2 ? 0x02 : 0) | (q != 3 ? 0x20 : 0));
+        }
     }
+    const unsigned te = all ? (unsigned)k : tau; // tau < k <= 32 otherwise
+    for (int j = 0; j < 4; ++j) {
+        if (!thresholded) t->c[j] = 0.f;
+        else if (j < 3) t->c[j] = 8388608.f + (float)((match ? 32u + te - (unsigned)k : 32u + te) << (6 * j));
+        else t->c[j] = match ? (float)(2 * (int)k - 2 * (int)te - 1) : -(float)(2 * te + 1);
+    }
+    if (all) for (int j = 0; j < 3; ++j) t->c[j] = 8388608.f + (float)(32u << (6 * j)), t->c[3] = -1.f;
     for (int d = -8; d < 32; ++d)
         for (int j = 0; j < 4; ++j)
             for (int i = 0; i < 4; ++i) {
@@ -162,7 +186,8 @@ void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t, bool threshol
                 const uint8_t *src = (i & 1) ? hi : lo;
                 uint32_t w = 0;
                 for (int b = 0; b < 4; ++b) w |= (uint32_t)src[32 + p0 + b - d] << (8 * b);
-                if (thresholded && ((d + 8) & 3) != 3) w |= w << 2; // 0b0010 -> 0b1010: the sign bit of every non-zero nibble
+                // the sign bit of every non-zero nibble (0b0010 -> 0b1010) where the row counts DOWN: j < 3 with differing channels, j = 3 with equal ones
+                if (thresholded && ((((d + 8) & 3) != 3) != match)) w |= w << 2;
                 t->w[d + 8][4 * j + i] = w;
             }
 }
@@ -185,17 +210,33 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
     uint32_t ql, qh;
     query_planes(query, k, &ql, &qh);
     const bool al = aligned16(ref) && aligned16(dist);
-    if (knobs(c).scan_impl == 7 && al) { // the contraction on the matrix cores (scan_mfma_device.h): ships since round 5
-        ScanMfmaTable tab;
-        scan_mfma_table(query, k, &tab);
+    if (knobs(c).scan_impl == 8 && al) {
+        // The shipped form: the contraction on the matrix cores in the tiling the fused count introduced -- a column is a segment of 32 windows, a row one of its 32
+        // shifts: four MFMAs per 1024 windows -- one trip of 4 rounds per wave (the dispatcher walks the trips), one-hot operands through a wave-private LDS strip,
+        // 2^23 bias + row scales for the byte pack, two v_permlane32_swap put the packed dwords in store order, nt loads and stores (scan_mfma_device.h:
+        // kmer_scan_seg_mfma_kernel; profiles/r05_ab_scan_seg.txt against the natural-layout tiling's six MFMAs, which shipped first)
+        CountMfmaTable ct;
+        count_mfma_table(query, k, &ct);
+        for (int j = 0; j < 4; ++j) ct.c[j] = 8388608.f;
         const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
         if constexpr (!kEvidenceBuild) {
-            // the shipped form: one trip of 4 rounds per wave (the dispatcher walks the trips), one-hot operands through a wave-private
-            // LDS strip with the lane's own kept in registers, 2^23 bias + row scales for the byte pack, nt loads and stores
-            kmer_scan_mfma_kernel<3, 4, false, 1, 4, false><<<scan_mfma_grid(c, rounds, 4, false), kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, 0u, dist, nullptr, nullptr, nullptr, slot, tab);
+            kmer_scan_seg_mfma_kernel<3, 4><<<scan_mfma_grid(c, rounds, 4, false), kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
             return hipGetLastError();
         }
 #ifdef BITNUC_SWEEP_VARIANTS
+        const int U = knobs(c).scan_mfma_unroll;
+        const unsigned grid = scan_mfma_grid(c, rounds, U, false);
+        if (U == 2) kmer_scan_seg_mfma_kernel<3, 2><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
+        else if (U == 3) kmer_scan_seg_mfma_kernel<3, 3><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
+        else kmer_scan_seg_mfma_kernel<3, 4><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
+        return hipGetLastError();
+#endif
+    }
+#ifdef BITNUC_SWEEP_VARIANTS
+    if (knobs(c).scan_impl == 7 && al) { // the natural-layout tiling (six MFMAs per 1024 windows, results already in store order): round 5's first matrix-core form
+        ScanMfmaTable tab;
+        scan_mfma_table(query, k, &tab, knobs(c).scan_mfma_match != 0 && knobs(c).scan_mfma_pack == 1);
+        const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
         const int U = knobs(c).scan_mfma_unroll, pack = knobs(c).scan_mfma_pack, shift = knobs(c).scan_mfma_shift;
         const bool persist = knobs(c).scan_mfma_persist != 0, ntld = (knobs(c).scan_mfma_policy & 1) != 0;
         const unsigned grid = scan_mfma_grid(c, rounds, U, persist);
@@ -215,8 +256,8 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
 #undef SCANM_PS
 #undef SCANM
         return hipGetLastError();
-#endif
     }
+#endif
     const int unroll = knobs(c).scan_unroll, kb = knobs(c).kmer_block;
 #ifdef BITNUC_SWEEP_VARIANTS
     if (knobs(c).scan_impl >= 2 && knobs(c).scan_impl <= 5 && al) { // line-aligned rounds, a wave owns consecutive rounds and carries the halo planes (kmer_scan3_kernel)
@@ -411,7 +452,7 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
     const unsigned long long want = rounds / ((kBlock / 64) * 4) + 1, cap = (unsigned long long)c->num_cu * 8;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     unsigned long long *res = reinterpret_cast<unsigned long long *>(d_count);
-    if (knobs(c).scan_impl == 7 && aligned16(d_ref)) {
+    if (knobs(c).scan_impl >= 7 && aligned16(d_ref)) {
         if constexpr (!kEvidenceBuild) {
             // the shipped form: the count's own tiling (segments of 32 windows x 32 shifts: 4 MFMAs per 1024 windows, nothing multiplies zeros), a
             // resident grid (one arrival per workgroup at the ticket), the next trip's loads issued before the current one is computed
@@ -420,7 +461,7 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
             // The threshold is part of the product (EMIT 2: 6-bit fields 32 + tau - d, three rows per register; v_or3 + v_bitop3 + v_bcnt per four windows,
             // nothing on the scalar unit), and a trip's registers take the next trip's loads as soon as its bytes are in the strip (profiles/r05_ab_count_emit*.txt).
             CountMfmaTable ct;
-            count_mfma_table(query, k, &ct, true, tau);
+            count_mfma_table(query, k, &ct, true, tau, knobs(c).scan_mfma_match != 0);
             kmer_count_mfma_kernel<3, true, 2><<<count_mfma_grid(c, rounds, 3), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
             HIPCHK(hipGetLastError());
             return BITNUC_OK;
@@ -431,7 +472,7 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
         if (knobs(c).scan_mfma_count_form == 1) { // the count's own tiling: segments of 32 windows, 4 MFMAs per 1024 windows
             CountMfmaTable ct;
             const int CU_ = knobs(c).scan_mfma_count_rounds, emit = knobs(c).scan_mfma_count_emit;
-            count_mfma_table(query, k, &ct, emit != 0, tau);
+            count_mfma_table(query, k, &ct, emit != 0, tau, knobs(c).scan_mfma_match != 0);
             const unsigned g = count_mfma_grid(c, rounds, CU_);
 #define COUNTOWN(UU, EM) kmer_count_mfma_kernel<UU, true, EM><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct)
 #define COUNTOWN_E(UU) do { if (emit == 0) COUNTOWN(UU, 0); else if (emit == 1) COUNTOWN(UU, 1); else COUNTOWN(UU, 2); } while (0)

@@ -47,7 +47,8 @@ struct SweepKnobs {
     int kmer_block = 256;        // threads per workgroup of the dense-batch and scan kernels: 64, 128 or 256
     int dense_unroll = 1;        // items (64 k-mers = 2 dwordx4 per lane) in flight per wave: 1, 2 or 4
     int scan_unroll = 4;         // rounds (1 KiB loads) in flight per wave: 1, 2 or 4
-    int scan_impl = 7;           // 7 = the one-hot contraction on the matrix cores (kmer_scan_mfma_kernel: ships since round 5, profiles/r05_ab_scan_mfma*.txt);
+    int scan_impl = 8;           // the one-hot contraction on the matrix cores: 8 = in the fused count's tiling (kmer_scan_seg_mfma_kernel: four MFMAs per 1024 windows + two v_permlane32_swap, ships:
+                                 // profiles/r05_ab_scan_seg.txt), 7 = the natural-layout tiling (kmer_scan_mfma_kernel: six MFMAs, round 5's first form, profiles/r05_ab_scan_mfma*.txt);
                                  // the bit-plane forms (v_alignbit + v_bcnt per window, VALU-issue bound): 1 = line-aligned rounds of 1024 windows, two-LUT planes + scalar halo
                                  // (kmer_scan2_kernel GEN 1: shipped in round 4), 6 = the same with rounds 2-3's plane build (GEN 0), 0 = rounds of 992 windows (kmer_scan_kernel),
                                  // 2 / 3 / 4 / 5 = kmer_scan3_kernel (a wave owns 12 / 20 / 16 / 32 consecutive rounds: slower, profiles/r04_ab_scan3.txt)
@@ -56,6 +57,7 @@ struct SweepKnobs {
     int scan_mfma_policy = 3;    // ... bit 0: nt loads (stores are nt)
     int scan_mfma_shift = 4;     // ... the shifted operands: 0 = two more global loads, 1 = the bytes through a wave-private LDS strip, 2 = DPP + scalar halo,
                                  //     3 = the one-hot operands through the strip, 4 = ... with the lane's own operands kept in registers (ships)
+    int scan_mfma_match = 0;         // ... the query's side of the product: 0 = 1.0 on the channels that DIFFER from the query's base (three of four), 1 = -1.0 on the one that EQUALS it, counted down from k (a third of the non-zero entries)
     int scan_mfma_count_emit = 2;    // ... its own tiling's results -> count: 0 = v_cmp + s_bcnt1 per register, 1 = threshold fields inside the product (v_or3 + v_bitop3 + v_bcnt per four windows), 2 = 1 + the next trip loaded into the same registers (ships)
     int scan_mfma_count_form = 1;    // ... the fused count: 1 = its own tiling (segments of 32 windows, 4 MFMAs per 1024 windows: kmer_count_mfma_kernel, ships), 0 = the scan's natural-layout tiling
     int scan_mfma_count_rounds = 3;  // kmer_count_mfma_kernel: rounds per trip (2, 3, 4): 3 lets six waves share a SIMD

@@ -322,10 +322,11 @@ constexpr SweepKey kSweepKeys[] = {
     {"kmer_block", &bitnuc_rt::SweepKnobs::kmer_block, 0, 0, 0, {64, 128, 256}},
     {"dense_unroll", &bitnuc_rt::SweepKnobs::dense_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
     {"scan_unroll", &bitnuc_rt::SweepKnobs::scan_unroll, 0, 0, 1ull << 1 | 1ull << 2 | 1ull << 4, {0, 0, 0}},
-    {"scan_impl", &bitnuc_rt::SweepKnobs::scan_impl, 0, 7, 0, {0, 0, 0}},
+    {"scan_impl", &bitnuc_rt::SweepKnobs::scan_impl, 0, 8, 0, {0, 0, 0}},
     {"scan_mfma_unroll", &bitnuc_rt::SweepKnobs::scan_mfma_unroll, 0, 0, 1ull << 2 | 1ull << 3 | 1ull << 4, {0, 0, 0}},
     {"scan_mfma_shift", &bitnuc_rt::SweepKnobs::scan_mfma_shift, 0, 6, 0, {0, 0, 0}},
     {"scan_mfma_count_form", &bitnuc_rt::SweepKnobs::scan_mfma_count_form, 0, 1, 0, {0, 0, 0}},
+    {"scan_mfma_match", &bitnuc_rt::SweepKnobs::scan_mfma_match, 0, 1, 0, {0, 0, 0}},
     {"scan_mfma_count_emit", &bitnuc_rt::SweepKnobs::scan_mfma_count_emit, 0, 2, 0, {0, 0, 0}},
     {"scan_mfma_count_rounds", &bitnuc_rt::SweepKnobs::scan_mfma_count_rounds, 2, 4, 0, {0, 0, 0}},
     {"scan_mfma_count_grid", &bitnuc_rt::SweepKnobs::scan_mfma_count_grid, 1, 64, 0, {0, 0, 0}},

@@ -47,7 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // operand, for the row whose windows start rho bases into the lane's 16.  Byte t of dwords {0, 1} (2, 3) belongs to position
 // 16 b + 8 e + t (+ 4): dword 0 / 2 holds channels A (low nibble) and C, dword 1 / 3 channels G and T; a nibble is 1.0 (0b0010)
 // where the channel differs from the query's base at i = position - rho, 0 where it equals it or i is outside [0, k).
-struct ScanMfmaTable { uint32_t w[17][24]; }; // row 16: zeros (SHIFT 6: the rows of the half a lane's K-block does not meet)
+struct ScanMfmaTable { uint32_t w[17][24]; float c[4]; }; // row 16: zeros (SHIFT 6: the rows of the half a lane's K-block does not meet); c[r & 3]: where result register r's accumulator starts (PACK 1)
 
 // 8 bases (two ASCII dwords) -> 32 one-hot nibbles in the same order
 __device__ __forceinline__ i32x8 onehot8(uint32_t x0, uint32_t x1) {
@@ -182,7 +182,7 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
     const int scale_a = !BIAS ? 127 : 127 + 8 * (int)((m32 & 3u) == 3u ? 0u : (m32 & 3u)); // E8M0: 2^(8 (rho & 3)) for rho & 3 < 3
     f32x16 c0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c0[i] = BIAS && PACK == 1 ? 8388608.f : 0.f;
+    for (int i = 0; i < 16; ++i) c0[i] = BIAS && PACK == 1 ? tab.c[i & 3] : 0.f; // 2^23, or 2^23 + k 2^(8 (i & 3)) when the table counts matches DOWN from k (kmer.hip: scan_mfma_table)
     if constexpr (BIAS && PACK == 1) asm volatile("" : "+v"(c0)); // sixteen registers used as an untied C operand (a splat constant is re-materialised by 16 v_mov per round)
     const i32x8 bias_a = {lane < 32 ? 2 : 0, 0, 0, 0, 0, 0, 0, 0};                                   // PACK 2: nibble 0 of K-block 0 = 1.0, every row
     const i32x8 bias_b = {0x22222222, 0x22222222, 0x22222222, 0x22222222, 0, 0, 0, 0};              // ... x ones, scale 2^23
@@ -393,7 +393,7 @@ kmer_scan_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, uns
 // 16-byte group 2 n + j -- not the lane's own group, so all four operands come from the strip, which keeps even and odd groups in separate
 // regions (a K-step's 32 reads are then 32 consecutive 16-byte entries: conflict-free).
 // w[delta + 8][4 j + i]: dword i of K-step j for the row with delta = m - 8 h (i = position - m only depends on it), built on the host.
-struct CountMfmaTable { uint32_t w[40][16]; };
+struct CountMfmaTable { uint32_t w[40][16]; float c[4]; }; // c[r & 3]: where result register r's accumulator starts (EMIT 1, 2)
 
 //
 // EMIT: how 1024 f32 distances become a count.
@@ -446,11 +446,11 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
     const float tauf = (float)tau;
     uint32_t hits = 0;      // EMIT 0: wave-uniform
     uint32_t lane_hits = 0; // EMIT 1, 2: per lane
-    const unsigned jrow = m32 & 3u, taup = tau < 31u ? tau : 31u; // (tau >= k: the host passes an all-zero table, d = 0 <= taup)
+    const unsigned jrow = m32 & 3u;
     const int scale_a = EMIT == 0 ? 127 : 127 + (jrow == 3u ? 1 : 6 * (int)jrow);
     f32x16 c0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c0[i] = EMIT == 0 ? 0.f : (i & 3) == 3 ? -(float)(2u * taup + 1u) : 8388608.f + (float)((32u + taup) << (6 * (i & 3)));
+    for (int i = 0; i < 16; ++i) c0[i] = EMIT == 0 ? 0.f : tab.c[i & 3]; // kmer.hip: count_mfma_table
     if constexpr (EMIT != 0) asm volatile("" : "+v"(c0)); // sixteen registers used as an untied C operand (scan_mfma_emit's note)
     // where group g of the trip lives: region (half e, parity g & 1), entry g >> 1
     const unsigned wr0 = (lane & 1u) * kRegion + 16u * (lane >> 1);                 // the lane's own group l of round u: + 2 kRegion e + 512 u
@@ -547,6 +547,110 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
         for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
         if (s) add_performed(total, s);
         if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The distance bytes in the count's tiling (segments of 32 windows x 32 shifts: four MFMAs per 1024 windows instead of the natural-layout tiling's six,
+// nothing multiplies zeros).  What the natural layout got for free -- register r of lane l = window 16 l + r -- costs two instructions here: lane (n, h)
+// holds windows 32 n + 8 q + 4 h + i (q = r >> 2, i = r & 3), i.e. after the 2^23-bias pack one dword per q holding four consecutive distance bytes, and
+// two v_permlane32_swap (lanes l and l + 32 exchange a register) give lane (n, 0) the dwords (q0, partner's q0, q1, partner's q1) = bytes 32 n .. 32 n + 15
+// and lane (n, 1) (partner's q2, q2, partner's q3, q3) = bytes 32 n + 16 .. 32 n + 31: one natural dwordx4 store per lane at 16 (2 n + h).
+// Why: profiles/r05_ablate_count_parts.txt -- the matrix pipe's power is what lowers the clock in a queue that starts on an idle chip; a third fewer
+// matrix instructions is the one lever on that dip.  One trip of U rounds per wave, as the shipped natural-layout form.
+template <int POLICY, int U>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, uint8_t *__restrict__ dist,
+                          unsigned long long *__restrict__ slot, const CountMfmaTable tab) {
+    constexpr bool NTLD = (POLICY & 1) != 0, NTST = (POLICY & 2) != 0;
+    constexpr int kRegion = (32 * U + 1) * 16 + 48; // kmer_count_mfma_kernel's strip
+    static_assert(kRegion % 128 == 64, "the two parities of one store must land 16 banks apart");
+    __shared__ __attribute__((aligned(16))) uint8_t strips[kBlock / 64][4 * kRegion];
+    const unsigned long long nwin = n - k + 1;
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
+    uint8_t *strip = strips[wave_in_block()];
+    const unsigned long long r0 = wave * U;
+    if (r0 < rounds) {
+        ScanTrip<U> cur;
+        scan_trip_load<U, 3, NTLD>(ref, r0, rounds, lane, cur); // before the table: its loads overlap these
+        const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
+        const unsigned m32 = lane & 31u, hh = lane >> 5;
+        i32x8 A[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            A[j] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[j][i] = (int)tab.w[m32 + 8u - 8u * hh][4 * j + i];
+        }
+        const int scale_a = 127 + 8 * (int)((m32 & 3u) == 3u ? 0u : (m32 & 3u)); // E8M0: 2^(8 (row & 3)) for row & 3 < 3 (scan_mfma_emit's pack)
+        f32x16 c0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c0[i] = tab.c[i & 3]; // 2^23
+        asm volatile("" : "+v"(c0)); // sixteen registers used as an untied C operand
+        const unsigned wr0 = (lane & 1u) * kRegion + 16u * (lane >> 1);
+        const unsigned rd = hh * 2u * kRegion + 16u * m32;
+        uint32_t trip_bad = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32x4 x = cur.v[u][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) trip_bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
+            const i32x8 e0 = onehot8(x.x, x.y), e1 = onehot8(x.z, x.w);
+            *reinterpret_cast<u32x4 *>(strip + wr0 + 512 * u) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
+            *reinterpret_cast<u32x4 *>(strip + wr0 + 512 * u + 2 * kRegion) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+        }
+        if (lane < 2) { // the halo: groups 64 m and 64 m + 1 (after the last VALID round; in-order LDS: the later write wins over a clamped copy)
+            const i32x8 e0 = onehot8(cur.hv.x, cur.hv.y), e1 = onehot8(cur.hv.z, cur.hv.w);
+            *reinterpret_cast<u32x4 *>(strip + lane * kRegion + 512 * m) = u32x4{(uint32_t)e0[0], (uint32_t)e0[1], (uint32_t)e0[2], (uint32_t)e0[3]};
+            *reinterpret_cast<u32x4 *>(strip + lane * kRegion + 512 * m + 2 * kRegion) = u32x4{(uint32_t)e1[0], (uint32_t)e1[1], (uint32_t)e1[2], (uint32_t)e1[3]};
+        }
+        if (__builtin_expect((trip_bad & 0xDFDFDFDFu) != 0u, 0)) { // some lane of the trip holds an invalid byte: find the round
+#pragma unroll 1
+            for (unsigned u = 0; u < m; ++u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((unsigned)u >= m) break; // wave-uniform
+            i32x8 B[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + rd + (j & 1) * kRegion + 16 * (32 * u + (j >> 1)));
+                B[j] = i32x8{(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+            }
+            f32x16 acc = c0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[j], acc, 4, 4, 0, scale_a, 0, 127);
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // (__float_as_uint on a copy: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
+                const float d0 = acc[4 * q], d1 = acc[4 * q + 1], d2 = acc[4 * q + 2], d3 = acc[4 * q + 3];
+                o[q] = __builtin_amdgcn_perm(__float_as_uint(d3), __float_as_uint(d0) | __float_as_uint(d1) | __float_as_uint(d2), 0x04020100u);
+            }
+            // v_permlane32_swap a, b: a's lanes 32-63 <-> b's lanes 0-31
+            const auto s02 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
+            const auto s13 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
+            store_group<NTST, true>(dist + ((r0 + u) << 10) + 16u * (2u * m32 + hh), u32x4{s02[0], s02[1], s13[0], s13[1]});
+        }
+    }
+
+    // tail: one window per thread, byte loads
+    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (rounds << 10) + gt; i < nwin; i += nthreads) {
+        unsigned long long w = 0;
+        bool flagged = false;
+        for (unsigned b = 0; b < k; ++b) {
+            const uint32_t byte = ref[i + b];
+            if (!valid_base(byte) && !flagged) { latch_bad(slot, i + b, byte); flagged = true; }
+            w |= (unsigned long long)code_of(byte) << (2 * b);
+        }
+        const unsigned long long x = (w ^ query) & kmask;
+        dist[i] = (uint8_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);
     }
 }
 

@@ -139,7 +139,7 @@ def test_product_library_holds_no_evidence_kernels():
     assert "encode_kernel" in product and "kmer_scan2_kernel" in product
     # the matrix-core scan ships in exactly one instantiation (distance bytes: one trip per wave) and the fused count in one (its own tiling, a
     # resident grid); their other operand / pack / trip / tiling forms are evidence
-    assert set(re.findall(r"kmer_scan_mfma_kernel<([^>]*)>", product)) == {"3, 4, false, 1, 4, false"}
+    assert set(re.findall(r"kmer_scan_seg_mfma_kernel<([^>]*)>", product)) == {"3, 4"} and "kmer_scan_mfma_kernel<" not in product
     assert set(re.findall(r"kmer_count_mfma_kernel<([^>]*)>", product)) == {"3, true, 2"}
     leaked = [n for n in names if n + "<" in product or n + "(" in product]
     assert not leaked, leaked

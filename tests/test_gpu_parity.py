@@ -156,7 +156,7 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     assert all(ctx.set_variant("decode", v) == -2 for v in range(47, 56)) and ctx.get("decode") == 22  # decode_x2_kernel: evidence build
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
-                                 ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 7, (0, 1, 2, 6)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
+                                 ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 8, (0, 1, 2, 6, 7)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
                                  ("scan_mfma_shift", 4, (0, 1, 2, 3, 5)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2, 3)), ("scan_mfma_persist", 0, (1,)), ("scan_mfma_count_persist", 1, (0,)), ("scan_mfma_count_form", 1, (0,)), ("scan_mfma_count_emit", 2, (0, 1)), ("scan_mfma_count_rounds", 3, (2, 4)), ("scan_mfma_count_grid", 18, (4,)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,)),
                                  ("batch_dense", 1, (0,)), ("batch_slide", 1, (0,)), ("batch_host_plan", 1, (0,)), ("fixed_stream", 1, (0,)), ("owner_est", 3, (0, 1, 2)),
@@ -491,17 +491,20 @@ def test_kmer_batch_errors(ctx, oracle):
     assert np.array_equal(ctx.as_2bit_batch(b"", 0, 1, 5), np.zeros(5, np.uint64))
 
 
-# Forms of the config-5 scan.  "ships" runs on the PRODUCT library: the one-hot contraction on the matrix cores (scan_impl 7: one-hot operands
-# through a wave-private LDS strip, the lane's own kept in registers, one trip of 4 rounds per wave).  The others live in the evidence build: the
-# matrix-core form's alternatives (shift: 0 global re-loads, 1 bytes through the strip, 2 DPP, 3 all six operands through the strip, 5 the software-pipelined trip; pack: 0
-# v_cvt_pk_u8, 2 bias by a seventh instruction; trips of 2 rounds; a resident grid) and rounds 1-4's bit-plane forms (scan_impl, scan_unroll):
-# 1 = line-aligned rounds of 1024 windows (GEN 1 at unroll 4: shipped in round 4), 6 = rounds 2-3's plane build, 0 = rounds of 992 windows,
-# 2 / 3 / 4 = kmer_scan3_kernel with 12 / 20 / 16 rounds per wave.
+# Forms of the config-5 scan.  "ships" runs on the PRODUCT library: the one-hot contraction on the matrix cores in the fused count's tiling (scan_impl 8: segments
+# of 32 windows x 32 shifts, four MFMAs per 1024 windows, two v_permlane32_swap put the packed results in store order, one trip of 4 rounds per wave).  The others
+# live in the evidence build: its trips of 2 / 3 rounds; the natural-layout tiling that shipped first (scan_impl 7: six MFMAs, results already in store order) with
+# its operand / pack / trip / grid forms (shift: 0 global re-loads, 1 bytes through the strip, 2 DPP, 3 all six operands through the strip, 4 the lane's own kept in
+# registers, 5 the software-pipelined trip, 6 less bookkeeping; pack: 0 v_cvt_pk_u8, 2 bias by a seventh instruction; match: the table marks the equal channel and counts down from k)
+# and rounds 1-4's bit-plane forms (scan_impl, scan_unroll): 1 = line-aligned rounds of 1024 windows (GEN 1 at unroll 4: shipped in round 4), 6 = rounds 2-3's plane
+# build, 0 = rounds of 992 windows, 2 / 3 / 4 = kmer_scan3_kernel with 12 / 20 / 16 rounds per wave.
 SCAN_FORMS = [("ships", {})] + \
-    [(f"mfma-shift{sh}-pack{pk}-U{u}-persist{ps}", dict(scan_mfma_shift=sh, scan_mfma_pack=pk, scan_mfma_unroll=u, scan_mfma_persist=ps))
-     for sh, pk, u, ps in ((4, 1, 4, 1), (4, 0, 2, 0), (4, 2, 4, 0), (4, 1, 3, 0), (5, 0, 4, 0), (5, 1, 2, 1), (3, 1, 4, 0), (3, 0, 2, 1), (1, 1, 4, 0), (1, 2, 2, 1), (2, 1, 4, 0), (2, 0, 2, 1), (0, 1, 2, 1), (0, 0, 2, 0))] + \
+    [(f"seg-U{u}", dict(scan_impl=8, scan_mfma_unroll=u)) for u in (3, 2)] + \
+    [(f"mfma-shift{sh}-pack{pk}-U{u}-persist{ps}" + ("-match" if mt else ""), dict(scan_impl=7, scan_mfma_shift=sh, scan_mfma_pack=pk, scan_mfma_unroll=u, scan_mfma_persist=ps, scan_mfma_match=mt))
+     for sh, pk, u, ps, mt in ((4, 1, 4, 0, 0), (4, 1, 4, 1, 0), (4, 0, 2, 0, 0), (4, 2, 4, 0, 0), (4, 1, 3, 0, 0), (5, 0, 4, 0, 0), (5, 1, 2, 1, 0), (3, 1, 4, 0, 0), (3, 0, 2, 1, 0), (1, 1, 4, 0, 0), (1, 2, 2, 1, 0), (2, 1, 4, 0, 0), (2, 0, 2, 1, 0),
+                               (0, 1, 2, 1, 0), (0, 0, 2, 0, 0), (6, 1, 4, 0, 0), (4, 1, 4, 0, 1), (6, 1, 2, 1, 1))] + \
     [(f"bitplane-impl{i}-unroll{u}", dict(scan_impl=i, scan_unroll=u)) for i, u in ((1, 4), (1, 2), (1, 1), (6, 4), (0, 4), (0, 2), (0, 1), (2, 4), (3, 4), (4, 4))]
-SCAN_DEFAULTS = dict(scan_impl=7, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1, scan_mfma_count_form=1, scan_mfma_count_emit=2, scan_mfma_count_rounds=3, scan_mfma_count_grid=18)
+SCAN_DEFAULTS = dict(scan_impl=8, scan_mfma_match=0, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1, scan_mfma_count_form=1, scan_mfma_count_emit=2, scan_mfma_count_rounds=3, scan_mfma_count_grid=18)
 
 
 @pytest.mark.parametrize("form", SCAN_FORMS, ids=[name for name, _ in SCAN_FORMS])
@@ -513,7 +516,7 @@ def test_scan_vs_oracle(ctx, sweep_ctx, oracle, k, form):
         for key, v in {**SCAN_DEFAULTS, **knobs}.items():
             ctx.require_variant(key, v)
     else:
-        assert ctx.get("sweep_build") == 0 and ctx.get("scan_impl") == 7
+        assert ctx.get("sweep_build") == 0 and ctx.get("scan_impl") == 8
     try:
         # (12 / 16 / 20 rounds per wave: sizes around one and two chunks as well; 4 rounds per trip: around 4 KiB + the 32-byte halo)
         for n in [k, k + 1, 1000, 1023, 1024, 1025, 1055, 1056, 1057, 2015, 2016, 2017, 2047, 2048, 2079, 2080, 2081, 3103, 3104, 3105, 4127, 4128, 4129, 5000, 5152, 5153,
@@ -528,9 +531,12 @@ def test_scan_vs_oracle(ctx, sweep_ctx, oracle, k, form):
                 ctx.require_variant(key, v)
 
 
-@pytest.mark.parametrize("form", [f for f in SCAN_FORMS if f[0] == "ships" or f[0].startswith("mfma")][:12], ids=[name for name, _ in SCAN_FORMS if name == "ships" or name.startswith("mfma")][:12])
+MATRIX_FORMS = [f for f in SCAN_FORMS if f[0] == "ships" or f[0].startswith(("mfma", "seg"))]
+
+
+@pytest.mark.parametrize("form", MATRIX_FORMS, ids=[name for name, _ in MATRIX_FORMS])
 def test_scan_matrix_core_forms_first_invalid_byte_and_count(ctx, sweep_ctx, oracle, form):
-    """kmer_scan_mfma_kernel: the first invalid byte wins at round, trip and strip boundaries and inside the halo (a later invalid byte never
+    """kmer_scan_seg_mfma_kernel / kmer_scan_mfma_kernel: the first invalid byte wins at round, trip and strip boundaries and inside the halo (a later invalid byte never
     does, a byte after the last window is never examined: hamming/scalar.rs:11-48 over naive.rs:3-20 per window); bytes past the last window are
     not written; the fused count (bitnuc_kmer_hdist_count_dev) of every form equals the count over the oracle's distance bytes."""
     import bitnuc_amd as bn
@@ -540,8 +546,9 @@ def test_scan_matrix_core_forms_first_invalid_byte_and_count(ctx, sweep_ctx, ora
         ctx = sweep_ctx
         for key, v in {**SCAN_DEFAULTS, **knobs}.items():
             ctx.require_variant(key, v)
-        ctx.require_variant("scan_mfma_count_form", 0)  # the fused count on the scan's own (natural-layout) tiling; "ships" and test_scan_fused_threshold_count run its own tiling
-        ctx.require_variant("scan_mfma_count_persist", knobs["scan_mfma_persist"] ^ 1)  # ... in its two grid forms (resident + ticket / one trip per wave + finishing launch)
+        if knobs["scan_impl"] == 7:
+            ctx.require_variant("scan_mfma_count_form", 0)  # the fused count on the natural-layout tiling; "ships", "seg-*" and test_scan_fused_threshold_count run its own tiling
+            ctx.require_variant("scan_mfma_count_persist", knobs["scan_mfma_persist"] ^ 1)  # ... in its two grid forms (resident + ticket / one trip per wave + finishing launch)
     try:
         rng = np.random.default_rng(505)
         n = 9 * 1024 + 77
