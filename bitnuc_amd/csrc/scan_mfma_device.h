@@ -13,18 +13,21 @@
 // exact data): A lane l = row l & 31, K-block l >> 5; B lane l = column l & 31, K-block l >> 5; D lane l register r = column l & 31,
 // row (r & 3) + 8 (r >> 2) + 4 (l >> 5).
 //
-// WHAT SHIPS (the product library instantiates exactly these two; every other template argument is an alternative that lost its A/B and
+// WHAT SHIPS (the product library instantiates exactly these two; every other kernel / template argument here is an alternative that lost its A/B and
 // is compiled into the evidence build only -- profiles/r05_ab_*.txt):
-//   kmer_scan_mfma_kernel<POLICY 3, U 4, COUNT false, PACK 1, SHIFT 4, PERSIST false>   the distance bytes: one trip of four rounds per wave
-//   kmer_count_mfma_kernel<U 3, nt loads, EMIT 2>                                        the fused count of d <= tau in its own tiling, the threshold inside the product
+//   kmer_scan_seg_mfma_kernel<POLICY 3, U 4>                 the distance bytes: a column is a segment of 32 windows, a row one of its 32 shifts (four MFMAs per
+//                                                            1024 windows), two v_permlane32_swap put the packed results in store order, one trip of four rounds per wave
+//   kmer_count_mfma_kernel<U 3, nt loads, EMIT 2>            the fused count of d <= tau in the same tiling, the threshold inside the product
 //
-// Tiling of the scan: NO lane ever holds anything but its own natural 16 bytes.  A wave round is 1 KiB of windows at a 1 KiB aligned
+// The tiling that shipped first (kmer_scan_mfma_kernel, below; evidence build since the segment tiling took over): NO lane ever holds anything but its own
+// natural 16 bytes.  A wave round is 1 KiB of windows at a 1 KiB aligned
 // offset (as kmer_scan2_kernel); lane l = (column n = l & 31, half h = l >> 5) loads the 16 bases at 16 l, obtains the one-hot operands of the
 // next two lanes' bytes (SHIFT below: through a wave-private LDS strip in the shipped form) and ends up holding the 16 distances of the
 // windows that start at those 16 bases: D row m <-> (shift rho = (m & 3) + 4 (m >> 3), half a = (m >> 2) & 1), window =
 // 16 (n + 32 a) + rho, so register r of lane (n, h) is window 16 l + r -- one natural dwordx4 store, no transpose anywhere.
 // The price: A is block-diagonal (row half a only meets K-block a), i.e. half of every instruction multiplies zeros; 6 instructions
-// per 1024 windows (3 loads x 2 groups of 8 positions) = 192 matrix cycles per round and SIMD, far below the round's HBM time.
+// per 1024 windows = 192 matrix cycles per round and SIMD -- far below the round's HBM time, but the matrix pipe's POWER is what makes a queue that
+// starts on an idle chip dip (profiles/r05_ablate_count_parts.txt), and a third fewer instructions removed the dip (profiles/r05_ab_scan_seg.txt).
 //
 // Packing the 16 f32 results into 16 bytes costs 2 instructions per 4 windows instead of 4: the accumulator starts at 2^23 (the
 // integer d then sits in the low mantissa bits) and A's rows carry the E8M0 block scale 2^(8 (rho & 3)) for rho & 3 < 3, so three

@@ -44,7 +44,7 @@ def test_timed_step_kernels_from_the_raw_csvs(traffic, kernel, alg, lo):
     assert 0.999 <= hbm / alg <= 1.01, hbm / alg  # no wasted re-reads
 
 
-@pytest.mark.parametrize("cfg,kernel,alg", [("cfg3", "kmer_dense_kernel", 10**8 * 39), ("cfg5", "kmer_scan_mfma_kernel", 2 * (10**9 - 30)), ("cfg5count", "kmer_count_mfma_kernel", 10**9 - 30)])
+@pytest.mark.parametrize("cfg,kernel,alg", [("cfg3", "kmer_dense_kernel", 10**8 * 39), ("cfg5", "kmer_scan_seg_mfma_kernel", 2 * (10**9 - 30)), ("cfg5count", "kmer_count_mfma_kernel", 10**9 - 30)])
 def test_configs_3_and_5_alone_from_the_raw_csvs(traffic, cfg, kernel, alg):
     avg_ns, calls = _stats(f"kernel_stats_{cfg}.csv", kernel)
     t = traffic[cfg]
@@ -61,10 +61,11 @@ def test_configs_3_and_5_alone_from_the_raw_csvs(traffic, cfg, kernel, alg):
     settled = sum(series[-16:]) / 16
     assert abs(t["last16_avg_ns"] / 1e3 - settled) < 0.1
     if cfg == "cfg5":
-        # the matrix-core scan: settled at the HBM plateau, from-idle mean within 5 % of it (round 4's bit-plane scan: 0.78-0.79 settled, 0.72 mean,
-        # worst launch 1.4-1.5 x settled)
-        assert alg / (settled * 1e3) / PEAK >= 0.77 and alg / avg_ns / PEAK >= 0.74
-        assert avg_ns / 1e3 <= 1.05 * settled and max(series[1:]) <= 1.32 * settled
+        # the matrix-core scan in the count's tiling (four MFMAs per 1024 windows): at the HBM plateau from the first launches on -- VERDICT r4's bar: the queue's mean
+        # >= 0.78 of 8 TB/s and no launch (the very first one, which pays the cold start, included) above 1.08 x the settled one (round 4's bit-plane scan: 0.72 and
+        # 1.4-1.5 x; round 5's first matrix-core form, six MFMAs: 0.77-0.795 and 1.07-1.28 x)
+        assert alg / (settled * 1e3) / PEAK >= 0.78 and alg / avg_ns / PEAK >= 0.78
+        assert avg_ns / 1e3 <= 1.03 * settled and max(series) <= 1.08 * settled, (max(series), settled)
     else:
         # the fused count moves half the bytes in well under the scan's time (round 4: the same time as the scan, 0.33 ms); its first launches -- a cool
         # chip -- run at the HBM plateau
