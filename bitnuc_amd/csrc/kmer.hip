@@ -192,6 +192,40 @@ void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t, bool threshol
             }
 }
 
+// ... and of the three-channel count (scan_mfma_device.h: Count3MfmaTable): per lane (row m = lane & 31, K-block h = lane >> 5) and K-step, the 32 nibbles that meet
+// the lane's operand -- K-steps 0 / 1: the (A, C) bytes of positions 32 s + 16 h + b; K-step 2: the G nibbles of positions 32 h .. + 31, odd position in the low nibble.
+// d = #(q_i != T) + sum over the window of v(q_i, channel) x[channel], v = -1 on channel q for q in {A, C, G}, +1 on all three for q = T; rows with m & 3 < 3 carry
+// -v and start at 2^23 + (32 + tau - #(q_i != T)) 2^(6 j) (they end at 32 + tau - d), rows with m & 3 = 3 carry v at scale 2 and start at 2 #(q_i != T) - 2 tau - 1.
+void count3_mfma_table(uint64_t query, size_t k, unsigned tau, Count3MfmaTable *t) {
+    const bool all = tau >= k;
+    unsigned non_t = 0;
+    for (size_t i = 0; i < k; ++i) non_t += ((query >> (2 * i)) & 3) != 3;
+    auto nibble = [&](int m, int p, unsigned ch) -> uint32_t {
+        const int i = p - m;
+        if (all || i < 0 || i >= (int)k) return 0u;
+        const unsigned q = (unsigned)((query >> (2 * i)) & 3);
+        const int v = q == 3 ? 1 : (ch == q ? -1 : 0);
+        const int e = (m & 3) == 3 ? v : -v;
+        return e == 0 ? 0u : e > 0 ? 0x2u : 0xAu;
+    };
+    for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 31, h = lane >> 5;
+        for (int s = 0; s < 3; ++s)
+            for (int i = 0; i < 4; ++i) {
+                uint32_t w = 0;
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int b = 4 * i + bb;
+                    const uint32_t lo = s < 2 ? nibble(m, 32 * s + 16 * h + b, 0) : nibble(m, 32 * h + 2 * b + 1, 2);
+                    const uint32_t hi = s < 2 ? nibble(m, 32 * s + 16 * h + b, 1) : nibble(m, 32 * h + 2 * b, 2);
+                    w |= (lo | hi << 4) << (8 * bb);
+                }
+                t->w[lane][4 * s + i] = w;
+            }
+    }
+    for (int j = 0; j < 3; ++j) t->c[j] = 8388608.f + (float)((all ? 32u : 32u + tau - non_t) << (6 * j));
+    t->c[3] = all ? -1.f : (float)(2 * (int)non_t - 2 * (int)tau - 1);
+}
+
 // grid of the matrix-core scan: resident waves that walk the rounds (each wave builds its constant operand once)
 unsigned scan_mfma_grid(const bitnuc_ctx *c, unsigned long long rounds, int U, bool persist) {
     const unsigned long long want = rounds / ((kBlock / 64) * (unsigned long long)U) + 1; // one trip per wave (+ 1: the tail loop needs a workgroup even without a whole round)
@@ -454,21 +488,30 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
     unsigned long long *res = reinterpret_cast<unsigned long long *>(d_count);
     if (knobs(c).scan_impl >= 7 && aligned16(d_ref)) {
         if constexpr (!kEvidenceBuild) {
-            // the shipped form: the count's own tiling (segments of 32 windows x 32 shifts: 4 MFMAs per 1024 windows, nothing multiplies zeros), a
-            // resident grid (one arrival per workgroup at the ticket), the next trip's loads issued before the current one is computed
-            // Trips of 3 rounds: the strip then lets six waves share a SIMD (four with trips of 4), and 18 workgroups per CU -- three
-            // generations of the six resident ones -- leave the dispatcher room to even out the CUs' tails (profiles/r05_ab_count_grid_sweep*.txt).
-            // The threshold is part of the product (EMIT 2: 6-bit fields 32 + tau - d, three rows per register; v_or3 + v_bitop3 + v_bcnt per four windows,
-            // nothing on the scalar unit), and a trip's registers take the next trip's loads as soon as its bytes are in the strip (profiles/r05_ab_count_emit*.txt).
-            CountMfmaTable ct;
-            count_mfma_table(query, k, &ct, true, tau, knobs(c).scan_mfma_match != 0);
-            kmer_count_mfma_kernel<3, true, 2><<<count_mfma_grid(c, rounds, 3), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, ct);
+            // The shipped form (scan_mfma_device.h: kmer_count3_mfma_kernel): segments of 32 windows x 32 shifts with THREE channels per base -- three MFMAs per 1024
+            // windows --, the threshold inside the product (6-bit fields 32 + tau - d, three rows per register; v_or3 + v_bitop3 + v_bcnt per four windows, nothing on
+            // the scalar unit), a bounded grid (one arrival per workgroup at the ticket) whose waves walk trips of four rounds and load the next trip into the registers
+            // the current one has just left; 12 workgroups per CU (profiles/r05_ab_count_ch3*.txt; the four-channel form it replaced: r05_ab_count_emit*.txt).
+            Count3MfmaTable c3;
+            count3_mfma_table(query, k, tau, &c3);
+            kmer_count3_mfma_kernel<4, true><<<count_mfma_grid(c, rounds, 4), kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, c3);
             HIPCHK(hipGetLastError());
             return BITNUC_OK;
         }
 #ifdef BITNUC_SWEEP_VARIANTS
         ScanMfmaTable tab;
         scan_mfma_table(query, k, &tab);
+        if (knobs(c).scan_mfma_count_form == 2) { // three channels per base: 3 MFMAs per 1024 windows
+            Count3MfmaTable c3;
+            count3_mfma_table(query, k, tau, &c3);
+            const int CU_ = knobs(c).scan_mfma_count_rounds;
+            const unsigned g = count_mfma_grid(c, rounds, CU_);
+            if (CU_ == 2) kmer_count3_mfma_kernel<2, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, c3);
+            else if (CU_ == 3) kmer_count3_mfma_kernel<3, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, c3);
+            else kmer_count3_mfma_kernel<4, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, c3);
+            HIPCHK(hipGetLastError());
+            return BITNUC_OK;
+        }
         if (knobs(c).scan_mfma_count_form == 1) { // the count's own tiling: segments of 32 windows, 4 MFMAs per 1024 windows
             CountMfmaTable ct;
             const int CU_ = knobs(c).scan_mfma_count_rounds, emit = knobs(c).scan_mfma_count_emit;

@@ -59,9 +59,9 @@ struct SweepKnobs {
                                  //     3 = the one-hot operands through the strip, 4 = ... with the lane's own operands kept in registers (ships)
     int scan_mfma_match = 0;         // ... the query's side of the product: 0 = 1.0 on the channels that DIFFER from the query's base (three of four), 1 = -1.0 on the one that EQUALS it, counted down from k (a third of the non-zero entries)
     int scan_mfma_count_emit = 2;    // ... its own tiling's results -> count: 0 = v_cmp + s_bcnt1 per register, 1 = threshold fields inside the product (v_or3 + v_bitop3 + v_bcnt per four windows), 2 = 1 + the next trip loaded into the same registers (ships)
-    int scan_mfma_count_form = 1;    // ... the fused count: 1 = its own tiling (segments of 32 windows, 4 MFMAs per 1024 windows: kmer_count_mfma_kernel, ships), 0 = the scan's natural-layout tiling
-    int scan_mfma_count_rounds = 3;  // kmer_count_mfma_kernel: rounds per trip (2, 3, 4): 3 lets six waves share a SIMD
-    int scan_mfma_count_grid = 18;   // ... workgroups per CU (six are resident: three generations)
+    int scan_mfma_count_form = 2;    // ... the fused count: 2 = segments of 32 windows with three channels per base (kmer_count3_mfma_kernel: 3 MFMAs per 1024 windows, ships), 1 = four channels (kmer_count_mfma_kernel: 4 MFMAs), 0 = the scan's natural-layout tiling (6)
+    int scan_mfma_count_rounds = 4;  // kmer_count3_mfma_kernel / kmer_count_mfma_kernel: rounds per trip (2, 3, 4); the four-channel form shipped with 3 (six waves share a SIMD)
+    int scan_mfma_count_grid = 12;   // ... workgroups per CU (the four-channel form shipped with 18: three generations of the six resident ones)
     int scan_mfma_count_persist = 1; // ... the fused count: 1 = a resident grid (ships), 0 = one trip per wave (two atomics per workgroup at the accumulator and the ticket)
     int scan_mfma_persist = 0;   // ... 1 = a resident grid walks the trips with register prefetch, 0 = one trip per wave
     int scan_mfma_pack = 1;      // ... f32 -> u8: 0 = v_cvt_pk_u8_f32, 1 = 2^23 bias + row scales (copied), 2 = ... (bias by a seventh instruction)

@@ -17,7 +17,8 @@
 // is compiled into the evidence build only -- profiles/r05_ab_*.txt):
 //   kmer_scan_seg_mfma_kernel<POLICY 3, U 4>                 the distance bytes: a column is a segment of 32 windows, a row one of its 32 shifts (four MFMAs per
 //                                                            1024 windows), two v_permlane32_swap put the packed results in store order, one trip of four rounds per wave
-//   kmer_count_mfma_kernel<U 3, nt loads, EMIT 2>            the fused count of d <= tau in the same tiling, the threshold inside the product
+//   kmer_count3_mfma_kernel<U 4, nt loads>                   the fused count of d <= tau: the same segments with THREE channels per base (three MFMAs per 1024 windows), the
+//                                                            threshold inside the product; kmer_count_mfma_kernel (four channels, shipped before it) is evidence
 //
 // The tiling that shipped first (kmer_scan_mfma_kernel, below; evidence build since the segment tiling took over): NO lane ever holds anything but its own
 // natural 16 bytes.  A wave round is 1 KiB of windows at a 1 KiB aligned
@@ -544,6 +545,156 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
     for (int off = 32; off > 0; off >>= 1) tail_hits += __shfl_xor(tail_hits, off);
     __shared__ uint32_t part[kBlock / 64];
     if (lane == 0) part[threadIdx.x >> 6] = hits + tail_hits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
+        if (s) add_performed(total, s);
+        if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The fused count with THREE channels per base: three MFMAs per 1024 windows instead of four.  [b != q] is affine in a 3-channel code (A, C, G one-hot; T = 0):
+// 1 - x_q for q in {A, C, G}, x_A + x_C + x_G for q = T, so d = #(q_i != T) + sum of (-1 | +1) entries times x.  63 positions x 3 channels = 189 nibbles fit the
+// 192 of three K-steps, and because the ORDER of (position, channel) pairs inside the K dimension is free, every operand is an aligned 16-byte piece of one of two
+// arrays the strip holds: the (A, C) byte of every base -- the existing low-LUT output, one v_perm per ASCII dword -- and the G nibble of every base, packed two to
+// a byte (v_perm + v_lshl_or per ASCII dword, one gathering v_perm per two).  K-step 0 / 1: lane (n, h) reads the (A, C) bytes of group 2 n + h / 2 n + 2 + h (even
+// and odd groups in separate regions, 16 banks apart, as above); K-step 2: the G nibbles of positions 32 h .. 32 h + 31 of its segment.  Per round: three
+// ds_read_b128 instead of four, ds_write_b128 + ds_write_b64 instead of two ds_write_b128, six more vector instructions for the nibble packing, a quarter fewer
+// matrix instructions -- whose power is what lowers the clock (profiles/r05_ablate_count_parts.txt).  An invalid byte reads as T; the call fails anyway.
+// w[lane][4 s + i]: the lane's 16-byte operand of K-step s (built on the host: kmer.hip count3_mfma_table); c as CountMfmaTable's.  Threshold fields, ticketed
+// reduction, trips and the in-place prefetch as kmer_count_mfma_kernel's EMIT 2.
+struct Count3MfmaTable { uint32_t w[64][12]; float c[4]; };
+
+template <int U, bool NTLD>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
+                        unsigned long long *__restrict__ result, unsigned long long *__restrict__ total /* zero between launches */,
+                        unsigned *__restrict__ ticket, unsigned long long *__restrict__ slot, const Count3MfmaTable tab) {
+    constexpr int kAc = (32 * U + 1) * 16 + 48; // one parity's (A, C) entries of a trip + the halo's; the odd region starts 16 banks after the even one
+    static_assert(kAc % 128 == 64, "the two parities of one store must land 16 banks apart");
+    constexpr int kG = (32 * U + 1) * 16;       // G nibbles: 16 bytes per 32 positions
+    __shared__ __attribute__((aligned(16))) uint8_t strips[kBlock / 64][2 * kAc + kG];
+    const unsigned long long nwin = n - k + 1;
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    uint8_t *strip = strips[wave_in_block()];
+
+    ScanTrip<U> cur;
+    unsigned long long r0 = wave * U;
+    if (r0 < rounds) scan_trip_load<U, 3, NTLD>(ref, r0, rounds, lane, cur);
+    const unsigned m32 = lane & 31u, hh = lane >> 5;
+    i32x8 A[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        A[j] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A[j][i] = (int)tab.w[lane][4 * j + i];
+    }
+    // the table's loads end BEFORE the loop (kmer_count_mfma_kernel's note)
+    asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[0][3]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2]), "+v"(A[1][3]),
+                      "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[2][2]), "+v"(A[2][3]));
+    uint32_t lane_hits = 0;
+    const unsigned jrow = m32 & 3u;
+    const int scale_a = 127 + (jrow == 3u ? 1 : 6 * (int)jrow);
+    f32x16 c0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c0[i] = tab.c[i & 3];
+    asm volatile("" : "+v"(c0)); // sixteen registers used as an untied C operand
+    const unsigned wr_ac = (lane & 1u) * kAc + 16u * (lane >> 1); // the lane's own group l of round u: + 512 u
+    const unsigned wr_g = 2u * kAc + 8u * lane;                   // ... its 16 G nibbles: + 512 u
+    const unsigned rd_ac = hh * kAc + 16u * m32;                  // K-step s < 2 of round u: + 16 s + 512 u
+    const unsigned rd_g = 2u * kAc + 16u * (m32 + hh);            // K-step 2: + 512 u
+
+    auto expand = [&](const u32x4 &x, u32x4 &ac, uint32_t &g0, uint32_t &g1) {
+        uint32_t t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t si = x[i] & 0x07070707u;
+            ac[i] = __builtin_amdgcn_perm(0u, 0x20000200u, si);              // A -> 0x02, C -> 0x20
+            const uint32_t g = __builtin_amdgcn_perm(0x02000000u, 0u, si);    // G -> 0x02
+            t[i] = (g << 12) | g;                                              // byte 1 = g1 | g0 << 4, byte 3 = g3 | g2 << 4
+        }
+        g0 = __builtin_amdgcn_perm(t[1], t[0], 0x07050301u);
+        g1 = __builtin_amdgcn_perm(t[3], t[2], 0x07050301u);
+    };
+
+    while (r0 < rounds) {
+        const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
+        const unsigned long long rn = r0 + nwaves * U;
+        wave_lds_fence(); // the previous trip's readers are done
+        uint32_t trip_bad = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32x4 x = cur.v[u][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) trip_bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
+            u32x4 ac;
+            uint32_t g0, g1;
+            expand(x, ac, g0, g1);
+            *reinterpret_cast<u32x4 *>(strip + wr_ac + 512 * u) = ac;
+            *reinterpret_cast<u32x2 *>(strip + wr_g + 512 * u) = u32x2{g0, g1};
+        }
+        if (lane < 2) { // the halo: groups 64 m and 64 m + 1 (after the last VALID round; in-order LDS: the later write wins over a clamped copy)
+            u32x4 ac;
+            uint32_t g0, g1;
+            expand(cur.hv, ac, g0, g1);
+            *reinterpret_cast<u32x4 *>(strip + lane * kAc + 512 * m) = ac;
+            *reinterpret_cast<u32x2 *>(strip + 2 * kAc + 512 * m + 8 * lane) = u32x2{g0, g1};
+        }
+        if (__builtin_expect((trip_bad & 0xDFDFDFDFu) != 0u, 0)) { // some lane of the trip holds an invalid byte: find the round
+#pragma unroll 1
+            for (unsigned u = 0; u < m; ++u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+        }
+        if (rn < rounds) scan_trip_load<U, 3, NTLD>(ref, rn, rounds, lane, cur); // cur's bytes are in the strip: its registers take the next trip
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((unsigned)u >= m) break; // wave-uniform
+            i32x8 B[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + (j < 2 ? rd_ac + 16 * j : rd_g) + 512 * u);
+                B[j] = i32x8{(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+            }
+            f32x16 acc = c0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[j], acc, 4, 4, 0, scale_a, 0, 127);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // (__float_as_uint on a copy: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
+                const float d0 = acc[4 * q], d1 = acc[4 * q + 1], d2 = acc[4 * q + 2], d3 = acc[4 * q + 3];
+                const uint32_t x = __float_as_uint(d0) | __float_as_uint(d1) | __float_as_uint(d2);
+                lane_hits += (uint32_t)__builtin_popcount((x | __float_as_uint(d3)) & 0x80020820u);
+            }
+        }
+        r0 = rn;
+    }
+
+    // tail: one window per thread, byte loads
+    const unsigned long long kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    uint32_t tail_hits = 0;
+    for (unsigned long long i = (rounds << 10) + gt; i < nwin; i += nthreads) {
+        unsigned long long w = 0;
+        bool flagged = false;
+        for (unsigned b = 0; b < k; ++b) {
+            const uint32_t byte = ref[i + b];
+            if (!valid_base(byte) && !flagged) { latch_bad(slot, i + b, byte); flagged = true; }
+            w |= (unsigned long long)code_of(byte) << (2 * b);
+        }
+        const unsigned long long x = (w ^ query) & kmask;
+        tail_hits += (uint32_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull) <= tau ? 1u : 0u;
+    }
+    tail_hits += lane_hits;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tail_hits += __shfl_xor(tail_hits, off);
+    __shared__ uint32_t part[kBlock / 64];
+    if (lane == 0) part[threadIdx.x >> 6] = tail_hits;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long s = 0;

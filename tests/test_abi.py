@@ -137,10 +137,10 @@ def test_product_library_holds_no_evidence_kernels():
             "decode_fixed_strip_kernel", "decode_batch_plan_lines_kernel", "kmer_scan3_kernel", "probe_win_shape_kernel"} <= names, names
     product = subprocess.run(["nm", "-C", build.ensure_built()], capture_output=True, text=True).stdout
     assert "encode_kernel" in product and "kmer_scan2_kernel" in product
-    # the matrix-core scan ships in exactly one instantiation (distance bytes: one trip per wave) and the fused count in one (its own tiling, a
-    # resident grid); their other operand / pack / trip / tiling forms are evidence
+    # the matrix-core scan ships in exactly one instantiation (distance bytes: one trip per wave) and the fused count in one (three channels per base, a
+    # resident grid); their other operand / pack / trip / tiling / channel forms are evidence
     assert set(re.findall(r"kmer_scan_seg_mfma_kernel<([^>]*)>", product)) == {"3, 4"} and "kmer_scan_mfma_kernel<" not in product
-    assert set(re.findall(r"kmer_count_mfma_kernel<([^>]*)>", product)) == {"3, true, 2"}
+    assert set(re.findall(r"kmer_count3_mfma_kernel<([^>]*)>", product)) == {"4, true"} and "kmer_count_mfma_kernel<" not in product
     leaked = [n for n in names if n + "<" in product or n + "(" in product]
     assert not leaked, leaked
     if os.path.exists(build.LIB_SWEEP) and not build.is_stale(build.LIB_SWEEP):

@@ -157,7 +157,7 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
                                  ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 8, (0, 1, 2, 6, 7)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
-                                 ("scan_mfma_shift", 4, (0, 1, 2, 3, 5)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2, 3)), ("scan_mfma_persist", 0, (1,)), ("scan_mfma_count_persist", 1, (0,)), ("scan_mfma_count_form", 1, (0,)), ("scan_mfma_count_emit", 2, (0, 1)), ("scan_mfma_count_rounds", 3, (2, 4)), ("scan_mfma_count_grid", 18, (4,)),
+                                 ("scan_mfma_shift", 4, (0, 1, 2, 3, 5)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2, 3)), ("scan_mfma_persist", 0, (1,)), ("scan_mfma_count_persist", 1, (0,)), ("scan_mfma_count_form", 2, (0, 1)), ("scan_mfma_count_emit", 2, (0, 1)), ("scan_mfma_count_rounds", 4, (2, 3)), ("scan_mfma_count_grid", 12, (4, 18)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,)),
                                  ("batch_dense", 1, (0,)), ("batch_slide", 1, (0,)), ("batch_host_plan", 1, (0,)), ("fixed_stream", 1, (0,)), ("owner_est", 3, (0, 1, 2)),
                                  ("plan_enc_block", 256, (64, 128)), ("kmer_block", 256, (64, 128)), ("hdist_tiled", 0, (1,)), ("hdist_words_impl", 1, (0,)),
@@ -504,7 +504,7 @@ SCAN_FORMS = [("ships", {})] + \
      for sh, pk, u, ps, mt in ((4, 1, 4, 0, 0), (4, 1, 4, 1, 0), (4, 0, 2, 0, 0), (4, 2, 4, 0, 0), (4, 1, 3, 0, 0), (5, 0, 4, 0, 0), (5, 1, 2, 1, 0), (3, 1, 4, 0, 0), (3, 0, 2, 1, 0), (1, 1, 4, 0, 0), (1, 2, 2, 1, 0), (2, 1, 4, 0, 0), (2, 0, 2, 1, 0),
                                (0, 1, 2, 1, 0), (0, 0, 2, 0, 0), (6, 1, 4, 0, 0), (4, 1, 4, 0, 1), (6, 1, 2, 1, 1))] + \
     [(f"bitplane-impl{i}-unroll{u}", dict(scan_impl=i, scan_unroll=u)) for i, u in ((1, 4), (1, 2), (1, 1), (6, 4), (0, 4), (0, 2), (0, 1), (2, 4), (3, 4), (4, 4))]
-SCAN_DEFAULTS = dict(scan_impl=8, scan_mfma_match=0, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1, scan_mfma_count_form=1, scan_mfma_count_emit=2, scan_mfma_count_rounds=3, scan_mfma_count_grid=18)
+SCAN_DEFAULTS = dict(scan_impl=8, scan_mfma_match=0, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1, scan_mfma_count_form=2, scan_mfma_count_emit=2, scan_mfma_count_rounds=4, scan_mfma_count_grid=12)
 
 
 @pytest.mark.parametrize("form", SCAN_FORMS, ids=[name for name, _ in SCAN_FORMS])
@@ -581,11 +581,13 @@ def test_scan_matrix_core_forms_first_invalid_byte_and_count(ctx, sweep_ctx, ora
                 ctx.require_variant(key, v)
 
 
-@pytest.mark.parametrize("U,grid,emit", [(3, 18, 2), (3, 18, 0), (3, 18, 1), (4, 4, 2), (2, 16, 1), (4, 12, 0), (3, 1, 2)],
-                         ids=["ships", "evidence-compare-per-register", "evidence-threshold-in-product-second-register-set", "evidence-trips-of-4", "evidence-trips-of-2",
-                              "evidence-trips-of-4-compare-per-register", "evidence-one-workgroup-per-CU"])
-def test_fused_count_own_tiling_vs_oracle(ctx, sweep_ctx, oracle, U, grid, emit):
-    """kmer_count_mfma_kernel (segments of 32 windows x 32 shifts, 4 MFMAs per 1024 windows; the threshold inside the product in the shipped form): the
+@pytest.mark.parametrize("form,U,grid,emit", [(2, 4, 12, 2), (2, 3, 18, 2), (2, 2, 24, 2), (2, 4, 1, 2), (1, 3, 18, 2), (1, 3, 18, 0), (1, 3, 18, 1), (1, 4, 4, 2), (1, 2, 16, 1), (1, 4, 12, 0), (1, 3, 1, 2)],
+                         ids=["ships", "evidence-three-channels-trips-of-3", "evidence-three-channels-trips-of-2", "evidence-three-channels-one-workgroup-per-CU",
+                              "evidence-four-channels", "evidence-four-channels-compare-per-register", "evidence-four-channels-second-register-set", "evidence-four-channels-trips-of-4",
+                              "evidence-four-channels-trips-of-2", "evidence-four-channels-trips-of-4-compare-per-register", "evidence-four-channels-one-workgroup-per-CU"])
+def test_fused_count_own_tiling_vs_oracle(ctx, sweep_ctx, oracle, form, U, grid, emit):
+    """kmer_count3_mfma_kernel (segments of 32 windows x 32 shifts, three channels per base: 3 MFMAs per 1024 windows, the threshold inside the product) and
+    kmer_count_mfma_kernel (four channels: 4 MFMAs; the threshold inside the product or compared per register): the
     count of d <= tau for every k, at sizes around the rounds, the trips and the 32-byte halo, on random data and on data where most windows are hits, for
     thresholds on both sides of k (tau >= k: every window counts; tau up to 2^32 - 1), equals the count over the oracle's distance bytes
     (hamming/scalar.rs:11-48 over naive.rs:3-20 per window); the first invalid byte is reported with its index; back-to-back launches find the
@@ -593,17 +595,17 @@ def test_fused_count_own_tiling_vs_oracle(ctx, sweep_ctx, oracle, U, grid, emit)
     import bitnuc_amd as bn
     import torch
     dev = torch.device("cuda:0")
-    shipped = (U, grid, emit) == (3, 18, 2)
+    shipped = (form, U, grid, emit) == (2, 4, 12, 2)
     if not shipped:
         ctx = sweep_ctx
-        for key, v in {**SCAN_DEFAULTS, "scan_mfma_count_rounds": U, "scan_mfma_count_grid": grid, "scan_mfma_count_emit": emit}.items():
+        for key, v in {**SCAN_DEFAULTS, "scan_mfma_count_form": form, "scan_mfma_count_rounds": U, "scan_mfma_count_grid": grid, "scan_mfma_count_emit": emit}.items():
             ctx.require_variant(key, v)
     try:
-        assert ctx.get("scan_mfma_count_form") == 1 and ctx.get("scan_mfma_count_rounds") == U and ctx.get("scan_mfma_count_emit") == emit
-        rng = np.random.default_rng(41 + U)
+        assert ctx.get("scan_mfma_count_form") == form and ctx.get("scan_mfma_count_rounds") == U and ctx.get("scan_mfma_count_emit") == emit
+        rng = np.random.default_rng(41 + U + 7 * form)
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
         for k in (1, 2, 15, 16, 17, 31, 32):
-            for n in (k, 1055, 1056, 1057, 2080, 2081, 3104, 3105, 4128, 4129, 5153, 6 * 1024 + 32, 6 * 1024 + 33, 8 * 1024 + 32, 9 * 1024 + 77, 200003, 3 * 10**6 + 77):
+            for n in (k, 1055, 1056, 1057, 2080, 2081, 3104, 3105, 4128, 4129, 5152, 5153, 6 * 1024 + 32, 6 * 1024 + 33, 8 * 1024 + 32, 9 * 1024 + 77, 200003, 3 * 10**6 + 77):
                 if n < k or (n > 10**6 and k not in (31, 32)):
                     continue
                 q = int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 4)) << 62)

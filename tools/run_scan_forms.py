@@ -29,9 +29,22 @@ for f in FORMS:
     for _ in range(N):
         ctx.kmer_hdist_count_dev(ref, n, k, q, 18, cnt)
     ctx.sync()
-for emit in (0, 1, 2):  # the fused count's own tiling: how a round's 1024 distances become a count (kmer_count_mfma_kernel<3, true, EMIT>)
+ctx.require_variant("scan_mfma_count_form", 1)
+ctx.require_variant("scan_mfma_count_rounds", 3)
+ctx.require_variant("scan_mfma_count_grid", 18)
+for emit in (0, 1, 2):  # the four-channel count: how a round's 1024 distances become a count (kmer_count_mfma_kernel<3, true, EMIT>)
     ctx.require_variant("scan_mfma_count_emit", emit)
     for _ in range(N):
         ctx.kmer_hdist_count_dev(ref, n, k, q, 18, cnt)
     ctx.sync()
+ctx.require_variant("scan_mfma_count_form", 2)  # three channels per base (kmer_count3_mfma_kernel<4, true>, ships)
+ctx.require_variant("scan_mfma_count_rounds", 4)
+ctx.require_variant("scan_mfma_count_grid", 12)
+for _ in range(N):
+    ctx.kmer_hdist_count_dev(ref, n, k, q, 18, cnt)
+ctx.sync()
+ctx.require_variant("scan_impl", 8)  # the scan in the segment tiling (kmer_scan_seg_mfma_kernel<3, 4>, ships)
+for _ in range(N):
+    ctx.kmer_hdist_scan_dev(ref, n, k, q, dist)
+ctx.sync()
 print("done", int(cnt.item()))
