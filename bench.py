@@ -1167,11 +1167,11 @@ def side_measurements(args, ctx, torch, dev, stream, seqs, words, backs, n, nw, 
         extra["kmer_hdist_count"] = {"workload": f"same scan, fused `d <= {tau}` count instead of the distance bytes (1 B read per window)",
                                      "gwindows_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 2), "ms": round(ms, 4), "isolated_ms": round(iso, 4), "timing": SUST, "matches": int(cnt1.item()),
                                      "matches_check": int((dist_out <= tau).sum().item()),
-                                     "bound": "HBM while the clock is high (bursts on a cool chip: 0.153-0.160 ms = 0.78-0.82 of 8 TB/s), the CU's cycles once it has fallen (the count's own tiling: segments of 32 windows x "
-                                              "32 shifts, per 1024 windows 4 MFMAs + ~45 vector instructions -- the threshold is inside the product: 6-bit fields 32 + tau - d, three rows per register, v_or3 + v_bitop3 + v_bcnt per four "
-                                              "windows, nothing on the scalar unit -- trips of 3 rounds, 18 workgroups per CU; `ms` here is a burst right after the scan's queues, i.e. inside the power controller's dip; "
-                                              "from_idle_queue_of_96 is the reading `configs.cfg5_fused_count` carries); round 5's first form (v_cmp + s_bcnt1 per register) 0.177 / 0.186 / 0.202, the scan's natural-layout tiling 0.20-0.22, "
-                                              "round 4's bit-plane form 0.30-0.33 (profiles/r05_ab_count_emit*.txt, r05_ab_count_own_tiling.txt, r05_pmc_scan_mfma_emit.txt)",
+                                     "bound": "HBM while the clock is high (bursts: 0.153-0.160 ms = 0.78-0.82 of 8 TB/s), the CU's cycles once it has fallen (segments of 32 windows x 32 shifts with THREE channels "
+                                              "per base -- [b != q] is affine in an (A, C, G) one-hot with T = 0 --: per 1024 windows 3 MFMAs + ~50 vector instructions; the threshold is inside the product: 6-bit fields 32 + tau - d, three rows per "
+                                              "register, v_or3 + v_bitop3 + v_bcnt per four windows, nothing on the scalar unit; trips of 4 rounds, 12 workgroups per CU; `ms` here is a burst right after the scan's queues; "
+                                              "from_idle_queue_of_96 is the reading `configs.cfg5_fused_count` carries); the four-channel form 0.160 / 0.177 / 0.195 (bursts / settled / from idle), round 5's first form (v_cmp + s_bcnt1 per register) 0.177 / 0.186 / 0.202, "
+                                              "round 4's bit-plane form 0.30-0.33 (profiles/r05_ab_count_ch3*.txt, r05_ab_count_emit*.txt, r05_pmc_scan_mfma_final_forms.txt)",
                                      "algorithmic_gb_s": round((n - k + 1) / (ms * 1e-3) / 1e9, 1), "roofline": hbm(n - k + 1, ms)}
         cruns = sorted((timed_queue(torch, stream, lambda i: ctx.kmer_hdist_count_dev(seqs[0], n, k, q, tau, cnt1), n_launches=96, idle_s=1.0, every=8) for _ in range(3)), key=sum)
         c96 = cruns[1]
