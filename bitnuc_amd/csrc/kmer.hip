@@ -120,7 +120,8 @@ void query_planes(uint64_t query, size_t k, uint32_t *ql, uint32_t *qh) {
     }
 }
 
-// The query's operand of the matrix-core scan (scan_mfma_device.h: ScanMfmaTable): per window shift rho and K-step, the nibbles that
+#ifdef BITNUC_SWEEP_VARIANTS
+// The query's operand of the natural-layout matrix-core scan (evidence/scan_mfma_evidence.h: ScanMfmaTable): per window shift rho and K-step, the nibbles that
 // are 1.0 where a channel differs from the query's base (hamming/scalar.rs:33-47 counts the differing 2-bit fields).
 // match = true: the nibbles are -1.0 (0b1010) where a channel EQUALS the query's base and the accumulators start at 2^23 + k 2^(8 (r & 3)) (r & 3 = 3: 2^23 + k): the
 // product counts the matches down from k -- the same distance with a third of the non-zero entries (one channel of four instead of three).
@@ -150,8 +151,10 @@ void scan_mfma_table(uint64_t query, size_t k, ScanMfmaTable *t, bool match = fa
                 t->w[rho][4 * s + i] = w;
             }
 }
+#endif
 
-// ... and of the fused count's own tiling (CountMfmaTable): row m of K-block h only depends on delta = m - 8 h.
+// The query's operand of the segment tiling with four channels per base (scan_mfma_device.h: CountMfmaTable; the shipped scan, the four-channel count of the
+// evidence build): row m of K-block h only depends on delta = m - 8 h.
 // thresholded (kmer_count_mfma_kernel's EMIT 1, 2): result register r (rows with m & 3 = r & 3 = j) must end at 2^23 + (32 + tau - d) 2^(6 j) for j < 3 and at
 // 2 d - 2 tau - 1 for j = 3 (scan_mfma_device.h).  match = false: the entries mark the channels that DIFFER from the query's base (-1.0 for j < 3, +1.0 for j = 3)
 // and the accumulators start at 2^23 + (32 + tau) 2^(6 j) / -(2 tau + 1).  match = true: they mark the channel that EQUALS it (+1.0 / -1.0: a third of the non-zero

@@ -134,7 +134,8 @@ def test_product_library_holds_no_evidence_kernels():
     for f in glob.glob(os.path.join(ROOT, "bitnuc_amd", "csrc", "evidence", "*.h")):
         names |= set(re.findall(r"^(\w+_kernel)\(", open(f).read(), flags=re.M))
     assert {"encode_quad_kernel", "encode_ballot_kernel", "decode_x2_kernel", "encode_batch2_kernel", "decode_batch2_kernel", "block_owner_kernel",
-            "decode_fixed_strip_kernel", "decode_batch_plan_lines_kernel", "kmer_scan3_kernel", "probe_win_shape_kernel"} <= names, names
+            "decode_fixed_strip_kernel", "decode_batch_plan_lines_kernel", "kmer_scan3_kernel", "probe_win_shape_kernel",
+            "kmer_scan_mfma_kernel", "kmer_count_mfma_kernel", "scan_count_finish_kernel"} <= names, names
     product = subprocess.run(["nm", "-C", build.ensure_built()], capture_output=True, text=True).stdout
     assert "encode_kernel" in product and "kmer_scan2_kernel" in product
     # the matrix-core scan ships in exactly one instantiation (distance bytes: one trip per wave) and the fused count in one (three channels per base, a
