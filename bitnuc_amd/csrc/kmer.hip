@@ -196,7 +196,7 @@ void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t, bool threshol
 }
 
 // ... and of the three-channel count (scan_mfma_device.h: Count3MfmaTable): per lane (row m = lane & 31, K-block h = lane >> 5) and K-step, the 32 nibbles that meet
-// the lane's operand -- K-steps 0 / 1: the (A, C) bytes of positions 32 s + 16 h + b; K-step 2: the G nibbles of positions 32 h .. + 31, odd position in the low nibble.
+// the lane's operand -- K-steps 0 / 1: the (A, C) bytes of positions 32 s + 16 h + b; K-step 2: the G nibbles of positions 32 h .. + 31, byte b holding positions 8 (b >> 2) + (b & 3) and that + 4.
 // d = #(q_i != T) + sum over the window of v(q_i, channel) x[channel], v = -1 on channel q for q in {A, C, G}, +1 on all three for q = T; rows with m & 3 < 3 carry
 // -v and start at 2^23 + (32 + tau - #(q_i != T)) 2^(6 j) (they end at 32 + tau - d), rows with m & 3 = 3 carry v at scale 2 and start at 2 #(q_i != T) - 2 tau - 1.
 void count3_mfma_table(uint64_t query, size_t k, unsigned tau, Count3MfmaTable *t) {
@@ -218,8 +218,9 @@ void count3_mfma_table(uint64_t query, size_t k, unsigned tau, Count3MfmaTable *
                 uint32_t w = 0;
                 for (int bb = 0; bb < 4; ++bb) {
                     const int b = 4 * i + bb;
-                    const uint32_t lo = s < 2 ? nibble(m, 32 * s + 16 * h + b, 0) : nibble(m, 32 * h + 2 * b + 1, 2);
-                    const uint32_t hi = s < 2 ? nibble(m, 32 * s + 16 * h + b, 1) : nibble(m, 32 * h + 2 * b, 2);
+                    const int gp = 32 * h + 8 * (b >> 2) + (b & 3); // K-step 2, byte b of the lane's 16: bases gp (low nibble) and gp + 4 (high nibble) of positions 32 h .. + 31
+                    const uint32_t lo = s < 2 ? nibble(m, 32 * s + 16 * h + b, 0) : nibble(m, gp, 2);
+                    const uint32_t hi = s < 2 ? nibble(m, 32 * s + 16 * h + b, 1) : nibble(m, gp + 4, 2);
                     w |= (lo | hi << 4) << (8 * bb);
                 }
                 t->w[lane][4 * s + i] = w;

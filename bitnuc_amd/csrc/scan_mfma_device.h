@@ -208,10 +208,10 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
 // The fused count with THREE channels per base: three MFMAs per 1024 windows instead of four.  [b != q] is affine in a 3-channel code (A, C, G one-hot; T = 0):
 // 1 - x_q for q in {A, C, G}, x_A + x_C + x_G for q = T, so d = #(q_i != T) + sum of (-1 | +1) entries times x.  63 positions x 3 channels = 189 nibbles fit the
 // 192 of three K-steps, and because the ORDER of (position, channel) pairs inside the K dimension is free, every operand is an aligned 16-byte piece of one of two
-// arrays the strip holds: the (A, C) byte of every base -- the existing low-LUT output, one v_perm per ASCII dword -- and the G nibble of every base, packed two to
-// a byte (v_perm + v_lshl_or per ASCII dword, one gathering v_perm per two).  K-step 0 / 1: lane (n, h) reads the (A, C) bytes of group 2 n + h / 2 n + 2 + h (even
+// arrays the strip holds: the (A, C) byte of every base -- the low-LUT output, one v_perm per ASCII dword -- and the G nibble of every base, packed two to
+// a byte (one v_perm per ASCII dword, one v_lshl_or per two: byte t of a dword holds bases t and t + 4).  K-step 0 / 1: lane (n, h) reads the (A, C) bytes of group 2 n + h / 2 n + 2 + h (even
 // and odd groups in separate regions, 16 banks apart, as above); K-step 2: the G nibbles of positions 32 h .. 32 h + 31 of its segment.  Per round: three
-// ds_read_b128 instead of four, ds_write_b128 + ds_write_b64 instead of two ds_write_b128, six more vector instructions for the nibble packing, a quarter fewer
+// ds_read_b128 instead of four, ds_write_b128 + ds_write_b64 instead of two ds_write_b128, two more vector instructions for the nibble packing, a quarter fewer
 // matrix instructions -- whose power is what lowers the clock (profiles/r05_ablate_count_parts.txt).  An invalid byte reads as T; the call fails anyway.
 // w[lane][4 s + i]: the lane's 16-byte operand of K-step s (built on the host: kmer.hip count3_mfma_table); c as CountMfmaTable's.
 // The threshold is inside the product: the entries are signed and A's rows carry the E8M0 scale 2^(6 j), j = row & 3 < 3, the accumulator starts at
@@ -269,16 +269,15 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
     const unsigned rd_g = 2u * kAc + 16u * (m32 + hh);            // K-step 2: + 512 u
 
     auto expand = [&](const u32x4 &x, u32x4 &ac, uint32_t &g0, uint32_t &g1) {
-        uint32_t t[4];
+        uint32_t g[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t si = x[i] & 0x07070707u;
-            ac[i] = __builtin_amdgcn_perm(0u, 0x20000200u, si);              // A -> 0x02, C -> 0x20
-            const uint32_t g = __builtin_amdgcn_perm(0x02000000u, 0u, si);    // G -> 0x02
-            t[i] = (g << 12) | g;                                              // byte 1 = g1 | g0 << 4, byte 3 = g3 | g2 << 4
+            ac[i] = __builtin_amdgcn_perm(0u, 0x20000200u, si);      // A -> 0x02, C -> 0x20
+            g[i] = __builtin_amdgcn_perm(0x02000000u, 0u, si);        // G -> 0x02
         }
-        g0 = __builtin_amdgcn_perm(t[1], t[0], 0x07050301u);
-        g1 = __builtin_amdgcn_perm(t[3], t[2], 0x07050301u);
+        g0 = (g[1] << 4) | g[0]; // byte t: low nibble = base t, high nibble = base t + 4 (the order inside the K dimension is free: the host's table follows it)
+        g1 = (g[3] << 4) | g[2]; // ... bases 8 + t and 12 + t
     };
 
     while (r0 < rounds) {
