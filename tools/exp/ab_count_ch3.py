@@ -35,19 +35,24 @@ rng = np.random.default_rng(10)
 ALPHA8 = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
 ctx.require_variant("scan_mfma_count_emit", 2)
 
-FORMS = [(1, 3, 18), (2, 3, 18), (2, 3, 24), (2, 4, 12), (2, 4, 18), (2, 2, 24)]  # (count_form, rounds per trip, workgroups per CU)
+FORMS = [(1, 3, 18), (2, 3, 18), (2, 3, 24), (2, 4, 12), (2, 4, 18), (2, 2, 24), (2, 4, 12, 1), (2, 3, 18, 1)]  # (count_form, rounds per trip, workgroups per CU[, 1 = a wave owns a contiguous run of trips and copies the halo's operands from the strip])
 if len(sys.argv) > 1:
     FORMS = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+
+
+def chained(f):
+    return " chained" if len(f) > 3 and f[3] else ""
 
 
 def use(f):
     ctx.require_variant("scan_mfma_count_form", f[0])
     ctx.require_variant("scan_mfma_count_rounds", f[1])
     ctx.require_variant("scan_mfma_count_grid", f[2])
+    ctx.require_variant("scan_mfma_count_chain", f[3] if len(f) > 3 else 0)
 
 
 small_ok = True
-for f in sorted({(e, U, 18) for e, U, _ in FORMS}):
+for f in sorted({(f[0], f[1], 18, f[3] if len(f) > 3 else 0) for f in FORMS}) + sorted({(f[0], f[1], 1, 1) for f in FORMS if len(f) > 3 and f[3]}):
     use(f)
     for kk in (1, 2, 15, 16, 17, 31, 32):
         for nn in (kk, 1055, 1056, 1057, 2080, 2081, 4128, 4129, 5153, 9 * 1024 + 77, 200003):
@@ -69,7 +74,7 @@ for f in sorted({(e, U, 18) for e, U, _ in FORMS}):
                     ctx.kmer_hdist_count_dev(t_, nn, kk, qq, tau, cnt)
                     ctx.sync()
                     if int(cnt.item()) != int((want_d <= tau).sum()):
-                        print(f"SMALL MISMATCH form {f[0]} U {f[1]} {kind} k {kk} n {nn} tau {tau}: {int(cnt.item())} != {int((want_d <= tau).sum())}")
+                        print(f"SMALL MISMATCH form {f} U {f[1]} {kind} k {kk} n {nn} tau {tau}: {int(cnt.item())} != {int((want_d <= tau).sum())}")
                         small_ok = False
     bad = ALPHA8[rng.integers(0, 8, size=50000)].copy()
     for pos in (0, 15, 16, 1023, 1024, 1040, 1055, 1056, 3071, 3072, 3104, 4096, 4097, 30000, 49999):
@@ -99,7 +104,7 @@ for tau in (18, 8, 23, 31):
             ctx.kmer_hdist_count_dev(ref, n, k, q, tau, cnt)
             ctx.sync()
             if int(cnt.item()) != want:
-                print(f"MISMATCH form {f[0]} U {f[1]} grid {f[2]} tau {tau}: {int(cnt.item())} != {want}")
+                print(f"MISMATCH form {f} U {f[1]} grid {f[2]} tau {tau}: {int(cnt.item())} != {want}")
                 ok = False
 print("counts at 10^9 bases:", "ok" if ok else "FAILED", flush=True)
 TAU = 8
@@ -141,5 +146,5 @@ for f in FORMS:
     m = statistics.median(res[f])
     use(f)
     mean, first, settled, worst = sorted(queue() for _ in range(3))[1]  # the median of three queues, each from an idle chip
-    print(f"form {f[0]} trips of {f[1]} grid {f[2]:2d}/CU: bursts {m*1e3:6.1f} us ({(n-k+1)/m/8e7:4.1f} % of 8 TB/s)   from idle (groups of 8): mean of 96 {mean:6.1f} us, first 8 {first:6.1f}, last 16 {settled:6.1f}, slowest group {worst:6.1f} us", flush=True)
+    print(f"form {f[0]}{chained(f)} trips of {f[1]} grid {f[2]:2d}/CU: bursts {m*1e3:6.1f} us ({(n-k+1)/m/8e7:4.1f} % of 8 TB/s)   from idle (groups of 8): mean of 96 {mean:6.1f} us, first 8 {first:6.1f}, last 16 {settled:6.1f}, slowest group {worst:6.1f} us", flush=True)
 sys.exit(0 if ok and small_ok else 1)
