@@ -77,7 +77,7 @@ __device__ __forceinline__ void scan_trip_load(const uint8_t *__restrict__ ref, 
             for (int i = 0; i < 8; ++i) t.hw[u][i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hp[i]);
         }
     }
-    if constexpr (SHIFT == 1 || (SHIFT >= 3 && SHIFT != 7)) { // (7: the trip's bytes only -- the caller already holds the halo's operands)
+    if constexpr (SHIFT == 1 || SHIFT >= 3) {
         t.hv = u32x4{0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
         if (lane < 2) t.hv = load_group<false, true>(ref + ((r0 + m) << 10) + 16 * lane);
     }
@@ -224,11 +224,7 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
 // are in the strip, into the same registers, and fly during the matrix phase.
 struct Count3MfmaTable { uint32_t w[64][12]; float c[4]; };
 
-// CHAIN: false = the waves stride over the trips (trip w, w + nwaves, ...: every trip loads and expands its own 32-byte halo);
-//   true = a wave owns a CONTIGUOUS run of trips and walks it from the high end down: a trip's halo is then the first two groups of the trip the wave
-//   finished just before, whose operands still sit at the start of the strip -- lanes 0 and 1 copy them (one ds_read_b128 + one ds_read_b64, no global
-//   load, no expansion: 16 vector instructions fewer per trip); only a wave's first trip loads its halo from memory.
-template <int U, bool NTLD, bool CHAIN = false>
+template <int U, bool NTLD>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
                         unsigned long long *__restrict__ result, unsigned long long *__restrict__ total /* zero between launches */,
@@ -245,13 +241,8 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
     uint8_t *strip = strips[wave_in_block()];
 
     ScanTrip<U> cur;
-    // CHAIN: trips [t_lo, t_hi) of this wave, walked downwards; r0 = the current trip's first round, r_lo = the run's first round
-    const unsigned long long trips = (rounds + U - 1) / U, per_wave = (trips + nwaves - 1) / nwaves;
-    const unsigned long long t_lo = wave * per_wave, t_hi = t_lo + per_wave < trips ? t_lo + per_wave : trips;
-    const unsigned long long r_lo = t_lo * U;
-    unsigned long long r0 = CHAIN ? (t_hi > t_lo ? (t_hi - 1) * U : rounds) : wave * U;
+    unsigned long long r0 = wave * U;
     if (r0 < rounds) scan_trip_load<U, 3, NTLD>(ref, r0, rounds, lane, cur);
-    bool first = true; // CHAIN: the wave's first trip (the only one whose halo comes from memory)
     const unsigned m32 = lane & 31u, hh = lane >> 5;
     i32x8 A[3];
 #pragma unroll
@@ -291,18 +282,8 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
 
     while (r0 < rounds) {
         const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
-        // the next trip and whether there is one (CHAIN: the trip below this one, down to the run's first)
-        const bool more = CHAIN ? r0 > r_lo : r0 + nwaves * U < rounds;
-        const unsigned long long rn = CHAIN ? r0 - U : r0 + nwaves * U;
+        const unsigned long long rn = r0 + nwaves * U;
         wave_lds_fence(); // the previous trip's readers are done
-        u32x4 chain_ac = {0, 0, 0, 0};
-        u32x2 chain_g = {0, 0};
-        if constexpr (CHAIN) {
-            if (!first && lane < 2) { // the previous (higher) trip's groups 0 and 1 = this trip's halo (the LDS is in order: these reads see the old entries)
-                chain_ac = *reinterpret_cast<const u32x4 *>(strip + lane * kAc);
-                chain_g = *reinterpret_cast<const u32x2 *>(strip + 2 * kAc + 8 * lane);
-            }
-        }
         uint32_t trip_bad = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -315,24 +296,18 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
             *reinterpret_cast<u32x4 *>(strip + wr_ac + 512 * u) = ac;
             *reinterpret_cast<u32x2 *>(strip + wr_g + 512 * u) = u32x2{g0, g1};
         }
-        if (!CHAIN || first) {
-            if (lane < 2) { // the halo: groups 64 m and 64 m + 1 (after the last VALID round; in-order LDS: the later write wins over a clamped copy)
-                u32x4 ac;
-                uint32_t g0, g1;
-                expand(cur.hv, ac, g0, g1);
-                *reinterpret_cast<u32x4 *>(strip + lane * kAc + 512 * m) = ac;
-                *reinterpret_cast<u32x2 *>(strip + 2 * kAc + 512 * m + 8 * lane) = u32x2{g0, g1};
-            }
-        } else if (lane < 2) { // (a later trip of a run is a whole one: m = U)
-            *reinterpret_cast<u32x4 *>(strip + lane * kAc + 512 * U) = chain_ac;
-            *reinterpret_cast<u32x2 *>(strip + 2 * kAc + 512 * U + 8 * lane) = chain_g;
+        if (lane < 2) { // the halo: groups 64 m and 64 m + 1 (after the last VALID round; in-order LDS: the later write wins over a clamped copy)
+            u32x4 ac;
+            uint32_t g0, g1;
+            expand(cur.hv, ac, g0, g1);
+            *reinterpret_cast<u32x4 *>(strip + lane * kAc + 512 * m) = ac;
+            *reinterpret_cast<u32x2 *>(strip + 2 * kAc + 512 * m + 8 * lane) = u32x2{g0, g1};
         }
-        first = false;
         if (__builtin_expect((trip_bad & 0xDFDFDFDFu) != 0u, 0)) { // some lane of the trip holds an invalid byte: find the round
 #pragma unroll 1
             for (unsigned u = 0; u < m; ++u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
         }
-        if (more) scan_trip_load<U, CHAIN ? 7 : 3, NTLD>(ref, rn, rounds, lane, cur); // cur's bytes are in the strip: its registers take the next trip
+        if (rn < rounds) scan_trip_load<U, 3, NTLD>(ref, rn, rounds, lane, cur); // cur's bytes are in the strip: its registers take the next trip
         wave_lds_fence();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -354,7 +329,7 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
                 lane_hits += (uint32_t)__builtin_popcount((x | __float_as_uint(d3)) & 0x80020820u);
             }
         }
-        r0 = more ? rn : rounds;
+        r0 = rn;
     }
 
     uint32_t tail_hits = scan_tail_windows<true>(ref, rounds << 10, nwin, k, query, tau, nullptr, slot);
