@@ -188,7 +188,7 @@ def test_config3_every_dense_31mer_against_the_closed_form(ctx, oracle):
 
 
 def test_config5_every_window_of_the_scan_against_the_oracle(ctx, oracle):
-    """BASELINE config 5 at full size: 10^9 bases, k = 31, one query: ALL 10^9 - 30 distances against the oracle's loop
+    """BASELINE config 5 at full size: 10^9 bases, k = 31, one query: ALL 10^9 - 30 distances -- and the fused count of d <= tau for nine thresholds -- against the oracle's loop
     (naive.rs:3-20 per window, then hamming/scalar.rs:11-48) run over the whole input on the host cores -- 32-window-aligned slices
     from bitnuc_amd.dist.scan_shard_range, one thread each (the oracle is the checker here, nothing of it is timed or shipped).
     Compared by a 64-bit sum per 1 MiB block, with a full compare of a block that differs."""
@@ -209,6 +209,13 @@ def test_config5_every_window_of_the_scan_against_the_oracle(ctx, oracle):
     ctx.kmer_hdist_scan_dev(ref, n, k, q, dist)
     ctx.sync()
     assert int(dist[qpos]) == 0 and int(dist.max()) <= k
+    # ... and the fused count (three channels per base, the threshold inside the product) for thresholds from "almost nothing" to "everything"
+    taus = (0, 8, 16, 20, 23, 26, 30, 31, 40)
+    cnt = torch.zeros(len(taus), dtype=torch.int64, device=dev)
+    for i, tau in enumerate(taus):
+        ctx.kmer_hdist_count_dev(ref, n, k, q, tau, cnt[i:])
+    ctx.sync()
+    got_counts = [int(x) for x in cnt.cpu()]
     h_ref = ref.cpu().numpy()
     assert np.array_equal(h_ref[:1 << 20], oracle.nucgen(1 << 20, SEED))  # the input is the oracle's stream too
     h_got = dist.cpu().numpy()
@@ -242,3 +249,6 @@ def test_config5_every_window_of_the_scan_against_the_oracle(ctx, oracle):
         raise AssertionError(f"window {i}: kernel {h_got[i]}, oracle {h_exp[i]} ({len(badblocks)} of {whole // BLK} blocks differ)")
     assert np.array_equal(h_got[whole:], h_exp[whole:])
     assert np.array_equal(h_got, h_exp)  # a 1 GB memcmp is cheap: the block sums above only localise a failure
+    below = np.cumsum(np.bincount(h_exp, minlength=k + 1))  # below[t] = windows with d <= t, from the ORACLE's distances
+    assert got_counts == [int(below[min(t, k)]) for t in taus], (got_counts, [int(below[min(t, k)]) for t in taus])
+    assert got_counts[0] >= 1 and got_counts[-1] == nwin
