@@ -44,7 +44,9 @@ def test_a_wrong_word_in_a_peer_slot_fails_the_run():
     """Config 4's check is literal: the gathered buffer is compared slot by slot with what every rank's shard must pack to (here, without a
     GPU, arange + rank), so a gather that delivered garbage into a PEER's slot is caught -- the line says so and the run exits 3."""
     rc, lines, err = run("--gpus", "2", "--rehearse-cpu", "--backend", "gloo", "--steps", "3", "--warmup", "1", BITNUC_BENCH_PLANT_BAD_SLOT="1")
-    assert rc != 0 and "exitcode: 3" in err, (rc, err[-2000:])  # the rank exits 3 (as for parity_vs_oracle); the launcher folds a failed rank into its own non-zero code
+    # the rank exits 3 (as for parity_vs_oracle); the launcher folds a failed rank into its own non-zero code and names the FIRST failure it saw as the root
+    # cause -- usually rank 0's "exitcode: 3", now and then its peer's, torn down while rank 0 was exiting (seen once in round 5): the line below is the evidence
+    assert rc != 0, (rc, err[-2000:])
     line = json.loads(lines[0])
     assert line["allgather_packed"]["own_slot_ok"] is True and line["allgather_packed"]["all_slots_ok"] is False
     assert line["allgather_packed"]["first_bad_slot"] == 1  # rank 0 prints the line: the wrong word sits in its peer's slot
