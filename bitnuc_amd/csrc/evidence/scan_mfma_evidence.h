@@ -4,6 +4,7 @@
 //                             operand (SHIFT), pack (PACK), trip (U) and grid (PERSIST) forms and the fused count on that tiling (COUNT)
 //   kmer_count_mfma_kernel    the fused count on segments of 32 windows with FOUR channels per base (four MFMAs): the threshold compared per register (EMIT 0) or
 //                             inside the product (1, 2) -- shipped until the three-channel form (kmer_count3_mfma_kernel) replaced it
+//   kmer_scan_seg3_mfma_kernel the distance bytes with three channels per base (three MFMAs): no faster than the shipped four-channel scan
 //   scan_count_finish_kernel  the second launch of the one-trip-per-wave fused count
 #pragma once
 
@@ -464,6 +465,94 @@ kmer_count_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, un
         if (s) add_performed(total, s);
         if (draw_last_ticket(ticket)) *result = atomicExch(total, 0ull);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// kmer_scan_seg3_mfma_kernel: the distance bytes with THREE channels per base (kmer_count3_mfma_kernel's operands: three MFMAs per 1024 windows instead of the shipped
+// scan's four).  d = #(q_i != T) + sum (-1 | +1) x: the rows carry the pack's scales 2^(8 j) and the accumulators start at 2^23 + #(q_i != T) 2^(8 j).
+// Measured against the shipped four-channel form: profiles/r05_ab_scan_seg3.txt.
+template <int POLICY, int U>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+kmer_scan_seg3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, uint8_t *__restrict__ dist,
+                           unsigned long long *__restrict__ slot, const Count3MfmaTable tab) {
+    constexpr bool NTLD = (POLICY & 1) != 0, NTST = (POLICY & 2) != 0;
+    constexpr int kAc = (32 * U + 1) * 16 + 48;
+    static_assert(kAc % 128 == 64, "the two parities of one store must land 16 banks apart");
+    constexpr int kG = (32 * U + 1) * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t strips[kBlock / 64][2 * kAc + kG];
+    const unsigned long long nwin = n - k + 1;
+    const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
+    uint8_t *strip = strips[wave_in_block()];
+    const unsigned long long r0 = wave * U;
+    if (r0 < rounds) {
+        ScanTrip<U> cur;
+        scan_trip_load<U, 3, NTLD>(ref, r0, rounds, lane, cur);
+        const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
+        const unsigned m32 = lane & 31u, hh = lane >> 5;
+        i32x8 A[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            A[j] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[j][i] = (int)tab.w[lane][4 * j + i];
+        }
+        const int scale_a = 127 + 8 * (int)((m32 & 3u) == 3u ? 0u : (m32 & 3u));
+        f32x16 c0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c0[i] = tab.c[i & 3];
+        asm volatile("" : "+v"(c0));
+        const unsigned wr_ac = (lane & 1u) * kAc + 16u * (lane >> 1), wr_g = 2u * kAc + 8u * lane;
+        const unsigned rd_ac = hh * kAc + 16u * m32, rd_g = 2u * kAc + 16u * (m32 + hh);
+        uint32_t trip_bad = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32x4 x = cur.v[u][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) trip_bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
+            u32x4 ac;
+            uint32_t g0, g1;
+            expand3(x, ac, g0, g1);
+            *reinterpret_cast<u32x4 *>(strip + wr_ac + 512 * u) = ac;
+            *reinterpret_cast<u32x2 *>(strip + wr_g + 512 * u) = u32x2{g0, g1};
+        }
+        if (lane < 2) {
+            u32x4 ac;
+            uint32_t g0, g1;
+            expand3(cur.hv, ac, g0, g1);
+            *reinterpret_cast<u32x4 *>(strip + lane * kAc + 512 * m) = ac;
+            *reinterpret_cast<u32x2 *>(strip + 2 * kAc + 512 * m + 8 * lane) = u32x2{g0, g1};
+        }
+        if (__builtin_expect((trip_bad & 0xDFDFDFDFu) != 0u, 0)) {
+#pragma unroll 1
+            for (unsigned u = 0; u < m; ++u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((unsigned)u >= m) break; // wave-uniform
+            i32x8 B[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(strip + (j < 2 ? rd_ac + 16 * j : rd_g) + 512 * u);
+                B[j] = i32x8{(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+            }
+            f32x16 acc = c0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[j], acc, 4, 4, 0, scale_a, 0, 127);
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float d0 = acc[4 * q], d1 = acc[4 * q + 1], d2 = acc[4 * q + 2], d3 = acc[4 * q + 3];
+                o[q] = __builtin_amdgcn_perm(__float_as_uint(d3), __float_as_uint(d0) | __float_as_uint(d1) | __float_as_uint(d2), 0x04020100u);
+            }
+            const auto s02 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
+            const auto s13 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
+            store_group<NTST, true>(dist + ((r0 + u) << 10) + 16u * (2u * m32 + hh), u32x4{s02[0], s02[1], s13[0], s13[1]});
+        }
+    }
+    scan_tail_windows<false>(ref, rounds << 10, nwin, k, query, 0u, dist, slot);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -199,8 +199,9 @@ void count_mfma_table(uint64_t query, size_t k, CountMfmaTable *t, bool threshol
 // the lane's operand -- K-steps 0 / 1: the (A, C) bytes of positions 32 s + 16 h + b; K-step 2: the G nibbles of positions 32 h .. + 31, byte b holding positions 8 (b >> 2) + (b & 3) and that + 4.
 // d = #(q_i != T) + sum over the window of v(q_i, channel) x[channel], v = -1 on channel q for q in {A, C, G}, +1 on all three for q = T; rows with m & 3 < 3 carry
 // -v and start at 2^23 + (32 + tau - #(q_i != T)) 2^(6 j) (they end at 32 + tau - d), rows with m & 3 = 3 carry v at scale 2 and start at 2 #(q_i != T) - 2 tau - 1.
-void count3_mfma_table(uint64_t query, size_t k, unsigned tau, Count3MfmaTable *t) {
-    const bool all = tau >= k;
+// distance = true (evidence build's three-channel scan): every row carries v and starts at 2^23 + #(q_i != T) 2^(8 j) (j = 3: 2^23 + #): the product is d itself.
+void count3_mfma_table(uint64_t query, size_t k, unsigned tau, Count3MfmaTable *t, bool distance = false) {
+    const bool all = !distance && tau >= k;
     unsigned non_t = 0;
     for (size_t i = 0; i < k; ++i) non_t += ((query >> (2 * i)) & 3) != 3;
     auto nibble = [&](int m, int p, unsigned ch) -> uint32_t {
@@ -208,7 +209,7 @@ void count3_mfma_table(uint64_t query, size_t k, unsigned tau, Count3MfmaTable *
         if (all || i < 0 || i >= (int)k) return 0u;
         const unsigned q = (unsigned)((query >> (2 * i)) & 3);
         const int v = q == 3 ? 1 : (ch == q ? -1 : 0);
-        const int e = (m & 3) == 3 ? v : -v;
+        const int e = distance || (m & 3) == 3 ? v : -v;
         return e == 0 ? 0u : e > 0 ? 0x2u : 0xAu;
     };
     for (int lane = 0; lane < 64; ++lane) {
@@ -225,6 +226,10 @@ void count3_mfma_table(uint64_t query, size_t k, unsigned tau, Count3MfmaTable *
                 }
                 t->w[lane][4 * s + i] = w;
             }
+    }
+    if (distance) {
+        for (int j = 0; j < 4; ++j) t->c[j] = 8388608.f + (float)(non_t << (j == 3 ? 0 : 8 * j));
+        return;
     }
     for (int j = 0; j < 3; ++j) t->c[j] = 8388608.f + (float)((all ? 32u : 32u + tau - non_t) << (6 * j));
     t->c[3] = all ? -1.f : (float)(2 * (int)non_t - 2 * (int)tau - 1);
@@ -264,6 +269,14 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
 #ifdef BITNUC_SWEEP_VARIANTS
         const int U = knobs(c).scan_mfma_unroll;
         const unsigned grid = scan_mfma_grid(c, rounds, U, false);
+        if (knobs(c).scan_mfma_ch3) { // three channels per base: three MFMAs per 1024 windows
+            Count3MfmaTable c3;
+            count3_mfma_table(query, k, 0u, &c3, true);
+            if (U == 2) kmer_scan_seg3_mfma_kernel<3, 2><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, c3);
+            else if (U == 3) kmer_scan_seg3_mfma_kernel<3, 3><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, c3);
+            else kmer_scan_seg3_mfma_kernel<3, 4><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, c3);
+            return hipGetLastError();
+        }
         if (U == 2) kmer_scan_seg_mfma_kernel<3, 2><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
         else if (U == 3) kmer_scan_seg_mfma_kernel<3, 3><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
         else kmer_scan_seg_mfma_kernel<3, 4><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);

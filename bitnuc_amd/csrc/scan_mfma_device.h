@@ -224,6 +224,20 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
 // are in the strip, into the same registers, and fly during the matrix phase.
 struct Count3MfmaTable { uint32_t w[64][12]; float c[4]; };
 
+// 16 bases (four ASCII dwords) -> their 16 (A, C) bytes and their 16 G nibbles (the three-channel operands)
+__device__ __forceinline__ void expand3(const u32x4 &x, u32x4 &ac, uint32_t &g0, uint32_t &g1) {
+    uint32_t g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t si = x[i] & 0x07070707u;
+        ac[i] = __builtin_amdgcn_perm(0u, 0x20000200u, si);      // A -> 0x02, C -> 0x20
+        g[i] = __builtin_amdgcn_perm(0x02000000u, 0u, si);        // G -> 0x02
+    }
+    g0 = (g[1] << 4) | g[0]; // byte t: low nibble = base t, high nibble = base t + 4 (the order inside the K dimension is free: the host's table follows it)
+    g1 = (g[3] << 4) | g[2]; // ... bases 8 + t and 12 + t
+}
+
+
 template <int U, bool NTLD>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
@@ -268,18 +282,6 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
     const unsigned rd_ac = hh * kAc + 16u * m32;                  // K-step s < 2 of round u: + 16 s + 512 u
     const unsigned rd_g = 2u * kAc + 16u * (m32 + hh);            // K-step 2: + 512 u
 
-    auto expand = [&](const u32x4 &x, u32x4 &ac, uint32_t &g0, uint32_t &g1) {
-        uint32_t g[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t si = x[i] & 0x07070707u;
-            ac[i] = __builtin_amdgcn_perm(0u, 0x20000200u, si);      // A -> 0x02, C -> 0x20
-            g[i] = __builtin_amdgcn_perm(0x02000000u, 0u, si);        // G -> 0x02
-        }
-        g0 = (g[1] << 4) | g[0]; // byte t: low nibble = base t, high nibble = base t + 4 (the order inside the K dimension is free: the host's table follows it)
-        g1 = (g[3] << 4) | g[2]; // ... bases 8 + t and 12 + t
-    };
-
     while (r0 < rounds) {
         const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
         const unsigned long long rn = r0 + nwaves * U;
@@ -292,14 +294,14 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
             for (int i = 0; i < 4; ++i) trip_bad |= x[i] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x[i] & 0x07070707u);
             u32x4 ac;
             uint32_t g0, g1;
-            expand(x, ac, g0, g1);
+            expand3(x, ac, g0, g1);
             *reinterpret_cast<u32x4 *>(strip + wr_ac + 512 * u) = ac;
             *reinterpret_cast<u32x2 *>(strip + wr_g + 512 * u) = u32x2{g0, g1};
         }
         if (lane < 2) { // the halo: groups 64 m and 64 m + 1 (after the last VALID round; in-order LDS: the later write wins over a clamped copy)
             u32x4 ac;
             uint32_t g0, g1;
-            expand(cur.hv, ac, g0, g1);
+            expand3(cur.hv, ac, g0, g1);
             *reinterpret_cast<u32x4 *>(strip + lane * kAc + 512 * m) = ac;
             *reinterpret_cast<u32x2 *>(strip + 2 * kAc + 512 * m + 8 * lane) = u32x2{g0, g1};
         }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The matrix-core scan (distance bytes): the shipped natural-layout tiling (scan_impl 7: six MFMAs per 1024 windows, half of each multiplying zeros, results
 already in store order) against the count's tiling (scan_impl 8: segments of 32 windows x 32 shifts, four MFMAs, two v_permlane32_swap put the results in
-store order), trips of 4 / 3 / 2 rounds.  Why: profiles/r05_ablate_count_parts.txt -- the matrix pipe's power is what lowers the clock in a queue from idle.
+store order), trips of 4 / 3 rounds, and the count's tiling with three channels per base (scan_mfma_ch3 1: three MFMAs).  Why: profiles/r05_ablate_count_parts.txt -- the matrix pipe's power is what lowers the clock in a queue from idle.
 Bursts of 8 and a 96-launch queue from an idle chip in groups of 8, interleaved three times; outputs compared; invalid bytes planted at round / trip
 boundaries must be reported by every form."""
 import os
@@ -24,7 +24,11 @@ ref = torch.empty(n, dtype=torch.uint8, device=dev)
 ctx.nucgen_dev(ref, n, 0xB17C0DE)
 outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
 ctx.sync()
-FORMS = [(7, 4), (8, 4), (8, 3), (8, 2)]  # (scan_impl, rounds per trip)
+FORMS = [(8, 4, 0), (8, 4, 1), (8, 3, 1), (7, 4, 0)]  # (scan_impl, rounds per trip, 1 = three channels per base: kmer_scan_seg3_mfma_kernel)
+
+
+def chan(f):
+    return "three channels" if f[2] else "four channels "
 
 
 def use(f):
@@ -32,6 +36,7 @@ def use(f):
     ctx.require_variant("scan_mfma_shift", 4)
     ctx.require_variant("scan_impl", f[0])
     ctx.require_variant("scan_mfma_unroll", f[1])
+    ctx.require_variant("scan_mfma_ch3", f[2])
 
 
 base = None
@@ -108,4 +113,4 @@ for rep in range(3):
         use(U)
         g = queue()
         m = statistics.median(res[U])
-        print(f"scan_impl {U[0]} trips of {U[1]}: bursts {m*1e3:6.1f} us ({alg/m/8e7:4.1f} %)   from idle: mean {sum(g)/len(g):6.1f} us ({alg/(sum(g)/len(g))/8e4:4.1f} %), settled {sum(g[-2:])/2:6.1f}, slowest group {max(g):6.1f}   groups: {' '.join(f'{x:.0f}' for x in g)}", flush=True)
+        print(f"scan_impl {U[0]} trips of {U[1]} {chan(U)}: bursts {m*1e3:6.1f} us ({alg/m/8e7:4.1f} %)   from idle: mean {sum(g)/len(g):6.1f} us ({alg/(sum(g)/len(g))/8e4:4.1f} %), settled {sum(g[-2:])/2:6.1f}, slowest group {max(g):6.1f}   groups: {' '.join(f'{x:.0f}' for x in g)}", flush=True)
