@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config-5 scan: kmer_scan2_kernel GEN 1 (scan_impl 1: bit-planes + v_alignbit + v_bcnt, 9.4 vector instructions per window) against
-kmer_scan_mfma_kernel (scan_impl 7: the one-hot contraction on the matrix cores, csrc/scan_mfma_device.h) -- evidence build, one process.
+kmer_scan_mfma_kernel (scan_impl 7: the one-hot contraction on the matrix cores, csrc/evidence/scan_mfma_evidence.h: the natural-layout tiling that shipped first) -- evidence build, one process.
 Correctness first: impl 7 (every pack mode / trip length) against the oracle on sizes around the rounds for k in {1, 2, 15, 16, 17, 31, 32},
 against impl 1 on 10^9 bases, the fused count, the first invalid byte.  Then three timing readings per form, interleaved (the bit-plane
 scan is VALU-issue bound and follows the chip's clock, profiles/r04_clock_series.txt):

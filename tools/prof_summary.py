@@ -75,7 +75,7 @@ def main():
     side = {}
     CFG = {"cfg3": ("kmer_dense_kernel", 10**8 * 39, "10^8 dense 31-mers: 39 B per k-mer (31 read + 8 written)"),
            "cfg5": ("kmer_scan", 2 * (10**9 - 30), "10^9-base scan: 2 B per window (1 read + 1 written)"),  # kmer_scan_mfma_kernel since round 5, kmer_scan2_kernel before
-           "cfg5count": ("kmer_count", 10**9 - 30, "10^9-base scan, fused d <= tau count: 1 B per window (read only)")}  # kmer_count_mfma_kernel
+           "cfg5count": ("kmer_count", 10**9 - 30, "10^9-base scan, fused d <= tau count: 1 B per window (read only)")}  # kmer_count3_mfma_kernel (round 5)
     for cfg, (kname, alg, what) in CFG.items():
         tpath = glob.glob(os.path.join(src, cfg + "_trace", "**", "trace_kernel_stats.csv"), recursive=True)
         if not tpath:

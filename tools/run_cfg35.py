@@ -2,7 +2,7 @@
 """ONE BASELINE side config at full size and nothing else (for rocprofv3 --kernel-trace --stats / --pmc passes whose per-kernel averages must
 not be mixed with small launches of the same kernel):
   cfg3   10^8 dense 31-mers as_2bit -> u64 (kmer_dense_kernel): 3.1 GB read + 0.8 GB written per launch = 39 B per k-mer
-  cfg5   sliding 31-mer pack + Hamming distance to one query over 10^9 bases (kmer_scan_mfma_kernel since round 5; kmer_scan2_kernel before): 1 B read + 1 B written per window
+  cfg5   sliding 31-mer pack + Hamming distance to one query over 10^9 bases (kmer_scan_seg_mfma_kernel since round 5; kmer_scan2_kernel before): 1 B read + 1 B written per window
 N launches in ONE queue (default 24 for cfg3, 96 for cfg5; the PMC passes use 12), two output buffers in rotation (the 256 MiB Infinity
 Cache holds neither the input nor an output).  cfg5's kernel is VALU-issue bound and the chip lowers its clock under it for the
 first ~40 launches of a queue (profiles/r04_launch_series.txt): a long queue makes the trace's AVERAGE the settled rate while its
