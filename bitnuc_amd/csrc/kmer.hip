@@ -277,14 +277,6 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
             else kmer_scan_seg3_mfma_kernel<3, 4><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, c3);
             return hipGetLastError();
         }
-        if (knobs(c).scan_mfma_trips > 1) { // several consecutive trips per wave, the next one loaded into the registers the current one has just left
-            const int T = knobs(c).scan_mfma_trips;
-            const unsigned g2 = scan_mfma_grid(c, rounds, 4 * T, false);
-            if (T == 2) kmer_scan_seg_mfma_kernel<3, 4, 2><<<g2, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
-            else if (T == 3) kmer_scan_seg_mfma_kernel<3, 4, 3><<<g2, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
-            else kmer_scan_seg_mfma_kernel<3, 4, 4><<<g2, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
-            return hipGetLastError();
-        }
         if (U == 2) kmer_scan_seg_mfma_kernel<3, 2><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
         else if (U == 3) kmer_scan_seg_mfma_kernel<3, 3><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
         else kmer_scan_seg_mfma_kernel<3, 4><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);

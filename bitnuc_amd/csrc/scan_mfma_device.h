@@ -120,9 +120,7 @@ struct CountMfmaTable { uint32_t w[40][16]; float c[4]; }; // c[r & 3]: where re
 // consecutive distance bytes, and two v_permlane32_swap (lanes l and l + 32 exchange a register) give lane (n, 0) the dwords (q0, partner's q0, q1, partner's q1) =
 // bytes 32 n .. 32 n + 15 and lane (n, 1) (partner's q2, q2, partner's q3, q3) = bytes 32 n + 16 .. 32 n + 31: one natural dwordx4 store per lane at 16 (2 n + h).
 // One trip of U rounds per wave; the hardware dispatcher walks the trips (how every streaming kernel of this library runs fastest).
-// T: consecutive trips per wave (1 ships: one trip per wave).  With T > 1 the next trip is loaded into the registers the current one has just left, as soon as its bytes
-// are in the strip, and the wave's setup (table, start values, addresses) is paid once per T trips.
-template <int POLICY, int U, int T = 1>
+template <int POLICY, int U>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, uint8_t *__restrict__ dist,
                           unsigned long long *__restrict__ slot, const CountMfmaTable tab) {
@@ -137,10 +135,11 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
     const unsigned lane = threadIdx.x & 63;
     const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block();
     uint8_t *strip = strips[wave_in_block()];
-    unsigned long long r0 = wave * (U * T);
+    const unsigned long long r0 = wave * U;
     if (r0 < rounds) {
         ScanTrip<U> cur;
         scan_trip_load<U, 3, NTLD>(ref, r0, rounds, lane, cur); // before the table: its loads overlap these
+        const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
         const unsigned m32 = lane & 31u, hh = lane >> 5;
         i32x8 A[4];
 #pragma unroll
@@ -149,10 +148,6 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
 #pragma unroll
             for (int i = 0; i < 4; ++i) A[j][i] = (int)tab.w[m32 + 8u - 8u * hh][4 * j + i];
         }
-        if constexpr (T > 1) { // the table's loads end BEFORE the loop (kmer_count3_mfma_kernel's note)
-            asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[0][3]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2]), "+v"(A[1][3]),
-                              "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[2][2]), "+v"(A[2][3]), "+v"(A[3][0]), "+v"(A[3][1]), "+v"(A[3][2]), "+v"(A[3][3]));
-        }
         const int scale_a = 127 + 8 * (int)((m32 & 3u) == 3u ? 0u : (m32 & 3u)); // E8M0: 2^(8 (row & 3)) for row & 3 < 3 (scan_mfma_emit's pack)
         f32x16 c0;
 #pragma unroll
@@ -160,10 +155,6 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
         asm volatile("" : "+v"(c0)); // sixteen registers used as an untied C operand (a splat constant is re-materialised by 16 v_mov per round)
         const unsigned wr0 = (lane & 1u) * kRegion + 16u * (lane >> 1);
         const unsigned rd = hh * 2u * kRegion + 16u * m32;
-#pragma unroll 1
-        for (int t = 0; t < T; ++t) {
-        const unsigned m = rounds - r0 < (unsigned long long)U ? (unsigned)(rounds - r0) : (unsigned)U;
-        if (T > 1 && t > 0) wave_lds_fence(); // the previous trip's readers are done
         uint32_t trip_bad = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -183,8 +174,6 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
 #pragma unroll 1
             for (unsigned u = 0; u < m; ++u) rescan_bytes(ref, ((r0 + u) << 10) + 16 * lane, 16, slot);
         }
-        const bool more = T > 1 && t + 1 < T && r0 + U < rounds;
-        if (more) scan_trip_load<U, 3, NTLD>(ref, r0 + U, rounds, lane, cur); // cur's bytes are in the strip: its registers take the next trip
         wave_lds_fence();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -209,9 +198,6 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
             const auto s02 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
             const auto s13 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
             store_group<NTST, true>(dist + ((r0 + u) << 10) + 16u * (2u * m32 + hh), u32x4{s02[0], s02[1], s13[0], s13[1]});
-        }
-        if (!more) break;
-        r0 += U;
         }
     }
 

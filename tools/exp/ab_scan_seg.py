@@ -24,11 +24,11 @@ ref = torch.empty(n, dtype=torch.uint8, device=dev)
 ctx.nucgen_dev(ref, n, 0xB17C0DE)
 outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
 ctx.sync()
-FORMS = [(8, 4, 0), (8, 4, 0, 2), (8, 4, 0, 3), (8, 4, 0, 4)]  # (scan_impl, rounds per trip, 1 = three channels per base: kmer_scan_seg3_mfma_kernel)
+FORMS = [(8, 4, 0), (8, 4, 1), (8, 3, 1), (7, 4, 0)]  # (scan_impl, rounds per trip, 1 = three channels per base: kmer_scan_seg3_mfma_kernel)
 
 
 def chan(f):
-    return ("three channels" if f[2] else "four channels ") + (f", {f[3]} trips per wave" if len(f) > 3 else "")
+    return "three channels" if f[2] else "four channels "
 
 
 def use(f):
@@ -37,7 +37,6 @@ def use(f):
     ctx.require_variant("scan_impl", f[0])
     ctx.require_variant("scan_mfma_unroll", f[1])
     ctx.require_variant("scan_mfma_ch3", f[2])
-    ctx.require_variant("scan_mfma_trips", f[3] if len(f) > 3 else 1)
 
 
 base = None
