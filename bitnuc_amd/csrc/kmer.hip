@@ -523,11 +523,9 @@ int bitnuc_kmer_hdist_count_dev(bitnuc_ctx *c, const uint8_t *d_ref, size_t n, s
             count3_mfma_table(query, k, tau, &c3);
             const int CU_ = knobs(c).scan_mfma_count_rounds;
             const unsigned g = count_mfma_grid(c, rounds, CU_);
-#define COUNT3(UU, PP) kmer_count3_mfma_kernel<UU, true, PP><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, c3)
-#define COUNT3_P(UU) do { if (knobs(c).scan_mfma_count_pipe) COUNT3(UU, true); else COUNT3(UU, false); } while (0)
-            if (CU_ == 2) COUNT3_P(2); else if (CU_ == 3) COUNT3_P(3); else COUNT3_P(4);
-#undef COUNT3_P
-#undef COUNT3
+            if (CU_ == 2) kmer_count3_mfma_kernel<2, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, c3);
+            else if (CU_ == 3) kmer_count3_mfma_kernel<3, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, c3);
+            else kmer_count3_mfma_kernel<4, true><<<g, kBlock, 0, c->stream>>>(d_ref, n, (unsigned)k, query, tau, res, c->d_acc + 5, c->d_tickets + 2, slot, c3);
             HIPCHK(hipGetLastError());
             return BITNUC_OK;
         }

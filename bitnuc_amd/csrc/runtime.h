@@ -59,7 +59,6 @@ struct SweepKnobs {
                                  //     3 = the one-hot operands through the strip, 4 = ... with the lane's own operands kept in registers (ships)
     int scan_mfma_ch3 = 0;           // ... the shipped scan's tiling with three channels per base instead of four (kmer_scan_seg3_mfma_kernel: three MFMAs per 1024 windows), evidence build
     int scan_mfma_match = 0;         // ... the query's side of the product: 0 = 1.0 on the channels that DIFFER from the query's base (three of four), 1 = -1.0 on the one that EQUALS it, counted down from k (a third of the non-zero entries)
-    int scan_mfma_count_pipe = 0;    // ... the three-channel count: 1 = the trip's matrix phase software-pipelined (round u - 1 thresholded in the shadow of round u's MFMAs: kmer_count3_mfma_kernel's PIPE)
     int scan_mfma_count_emit = 2;    // ... its own tiling's results -> count: 0 = v_cmp + s_bcnt1 per register, 1 = threshold fields inside the product (v_or3 + v_bitop3 + v_bcnt per four windows), 2 = 1 + the next trip loaded into the same registers (ships)
     int scan_mfma_count_form = 2;    // ... the fused count: 2 = segments of 32 windows with three channels per base (kmer_count3_mfma_kernel: 3 MFMAs per 1024 windows, ships), 1 = four channels (kmer_count_mfma_kernel: 4 MFMAs), 0 = the scan's natural-layout tiling (6)
     int scan_mfma_count_rounds = 4;  // kmer_count3_mfma_kernel / kmer_count_mfma_kernel: rounds per trip (2, 3, 4); the four-channel form shipped with 3 (six waves share a SIMD)

@@ -328,7 +328,6 @@ constexpr SweepKey kSweepKeys[] = {
     {"scan_mfma_count_form", &bitnuc_rt::SweepKnobs::scan_mfma_count_form, 0, 2, 0, {0, 0, 0}},
     {"scan_mfma_ch3", &bitnuc_rt::SweepKnobs::scan_mfma_ch3, 0, 1, 0, {0, 0, 0}},
     {"scan_mfma_match", &bitnuc_rt::SweepKnobs::scan_mfma_match, 0, 1, 0, {0, 0, 0}},
-    {"scan_mfma_count_pipe", &bitnuc_rt::SweepKnobs::scan_mfma_count_pipe, 0, 1, 0, {0, 0, 0}},
     {"scan_mfma_count_emit", &bitnuc_rt::SweepKnobs::scan_mfma_count_emit, 0, 2, 0, {0, 0, 0}},
     {"scan_mfma_count_rounds", &bitnuc_rt::SweepKnobs::scan_mfma_count_rounds, 2, 4, 0, {0, 0, 0}},
     {"scan_mfma_count_grid", &bitnuc_rt::SweepKnobs::scan_mfma_count_grid, 1, 64, 0, {0, 0, 0}},

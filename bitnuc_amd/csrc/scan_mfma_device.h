@@ -238,9 +238,7 @@ __device__ __forceinline__ void expand3(const u32x4 &x, u32x4 &ac, uint32_t &g0,
 }
 
 
-// PIPE: a whole trip's matrix phase is software-pipelined -- round u's three MFMAs are issued, THEN round u - 1's results are thresholded (twelve vector instructions
-// that run in the shadow of the chain instead of waiting for it); a second set of sixteen result registers.  A trip cut short by the end of the input runs the plain loop.
-template <int U, bool NTLD, bool PIPE = false>
+template <int U, bool NTLD>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, unsigned tau,
                         unsigned long long *__restrict__ result, unsigned long long *__restrict__ total /* zero between launches */,
@@ -313,7 +311,9 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
         }
         if (rn < rounds) scan_trip_load<U, 3, NTLD>(ref, rn, rounds, lane, cur); // cur's bytes are in the strip: its registers take the next trip
         wave_lds_fence();
-        auto chain = [&](int u) { // round u's operands from the strip, three dependent MFMAs
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((unsigned)u >= m) break; // wave-uniform
             i32x8 B[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -323,31 +323,12 @@ kmer_count3_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, u
             f32x16 acc = c0;
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[j], acc, 4, 4, 0, scale_a, 0, 127);
-            return acc;
-        };
-        auto threshold = [&](const f32x16 &acc) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // (__float_as_uint on a copy: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
                 const float d0 = acc[4 * q], d1 = acc[4 * q + 1], d2 = acc[4 * q + 2], d3 = acc[4 * q + 3];
                 const uint32_t x = __float_as_uint(d0) | __float_as_uint(d1) | __float_as_uint(d2);
                 lane_hits += (uint32_t)__builtin_popcount((x | __float_as_uint(d3)) & 0x80020820u);
-            }
-        };
-        if (PIPE && m == (unsigned)U) { // a whole trip (wave-uniform): the static schedule
-            f32x16 prev = chain(0);
-#pragma unroll
-            for (int u = 1; u < U; ++u) {
-                const f32x16 acc = chain(u);
-                threshold(prev); // the previous round's results, beside this round's chain
-                prev = acc;
-            }
-            threshold(prev);
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if ((unsigned)u >= m) break; // wave-uniform
-                threshold(chain(u));
             }
         }
         r0 = rn;

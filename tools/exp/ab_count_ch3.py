@@ -41,20 +41,19 @@ if len(sys.argv) > 1:
 
 
 def chained(f):
-    return (" chained" if f[3] == 1 else " pipelined") if len(f) > 3 and f[3] else ""
+    return " chained" if len(f) > 3 and f[3] else ""
 
 
 def use(f):
     ctx.require_variant("scan_mfma_count_form", f[0])
     ctx.require_variant("scan_mfma_count_rounds", f[1])
     ctx.require_variant("scan_mfma_count_grid", f[2])
-    ctx.require_variant("scan_mfma_count_pipe", 1 if len(f) > 3 and f[3] == 2 else 0)
-    if len(f) > 3 and f[3] == 1:
+    if len(f) > 3 and f[3]:
         ctx.require_variant("scan_mfma_count_chain", 1)  # (the chained form lives in commit 7c7c8a3 only: it lost its A/B, profiles/r05_ab_count_chain.txt)
 
 
 small_ok = True
-for f in sorted({(f[0], f[1], 18, f[3] if len(f) > 3 else 0) for f in FORMS}) + sorted({(f[0], f[1], 1, f[3]) for f in FORMS if len(f) > 3 and f[3]}):
+for f in sorted({(f[0], f[1], 18, f[3] if len(f) > 3 else 0) for f in FORMS}) + sorted({(f[0], f[1], 1, 1) for f in FORMS if len(f) > 3 and f[3]}):
     use(f)
     for kk in (1, 2, 15, 16, 17, 31, 32):
         for nn in (kk, 1055, 1056, 1057, 2080, 2081, 4128, 4129, 5153, 9 * 1024 + 77, 200003):
