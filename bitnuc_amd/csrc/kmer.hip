@@ -263,7 +263,9 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
         for (int j = 0; j < 4; ++j) ct.c[j] = 8388608.f;
         const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
         if constexpr (!kEvidenceBuild) {
-            kmer_scan_seg_mfma_kernel<3, 4><<<scan_mfma_grid(c, rounds, 4, false), kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
+            // workgroups of ONE wave (the strips are wave-private, nothing is shared inside a workgroup): 19 waves fit a CU's LDS instead of 16, and the dispatcher
+            // refills a CU wave by wave (profiles/r05_ab_scan_block.txt: 1 % faster from idle than workgroups of four waves)
+            kmer_scan_seg_mfma_kernel<3, 4, 64><<<(unsigned)(rounds / 4 + 1), 64, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
             return hipGetLastError();
         }
 #ifdef BITNUC_SWEEP_VARIANTS
@@ -275,6 +277,13 @@ hipError_t launch_scan(bitnuc_ctx *c, const uint8_t *ref, size_t n, size_t k, ui
             if (U == 2) kmer_scan_seg3_mfma_kernel<3, 2><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, c3);
             else if (U == 3) kmer_scan_seg3_mfma_kernel<3, 3><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, c3);
             else kmer_scan_seg3_mfma_kernel<3, 4><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, c3);
+            return hipGetLastError();
+        }
+        if (knobs(c).scan_mfma_block != kBlock && U == 4 && !knobs(c).scan_mfma_ch3) { // workgroups of one wave (ships) or two
+            const int kb = knobs(c).scan_mfma_block;
+            const unsigned g2 = (unsigned)(rounds / ((kb / 64) * 4ull) + 1);
+            if (kb == 128) kmer_scan_seg_mfma_kernel<3, 4, 128><<<g2, 128, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
+            else kmer_scan_seg_mfma_kernel<3, 4, 64><<<g2, 64, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);
             return hipGetLastError();
         }
         if (U == 2) kmer_scan_seg_mfma_kernel<3, 2><<<grid, kBlock, 0, c->stream>>>(ref, n, (unsigned)k, query, dist, slot, ct);

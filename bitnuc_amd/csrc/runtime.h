@@ -57,6 +57,7 @@ struct SweepKnobs {
     int scan_mfma_policy = 3;    // ... bit 0: nt loads (stores are nt)
     int scan_mfma_shift = 4;     // ... the shifted operands: 0 = two more global loads, 1 = the bytes through a wave-private LDS strip, 2 = DPP + scalar halo,
                                  //     3 = the one-hot operands through the strip, 4 = ... with the lane's own operands kept in registers (ships)
+    int scan_mfma_block = 64;        // ... kmer_scan_seg_mfma_kernel: threads per workgroup: 64 (one wave: ships), 128, 256 (trips of four rounds only)
     int scan_mfma_ch3 = 0;           // ... the shipped scan's tiling with three channels per base instead of four (kmer_scan_seg3_mfma_kernel: three MFMAs per 1024 windows), evidence build
     int scan_mfma_match = 0;         // ... the query's side of the product: 0 = 1.0 on the channels that DIFFER from the query's base (three of four), 1 = -1.0 on the one that EQUALS it, counted down from k (a third of the non-zero entries)
     int scan_mfma_count_emit = 2;    // ... its own tiling's results -> count: 0 = v_cmp + s_bcnt1 per register, 1 = threshold fields inside the product (v_or3 + v_bitop3 + v_bcnt per four windows), 2 = 1 + the next trip loaded into the same registers (ships)

@@ -326,6 +326,7 @@ constexpr SweepKey kSweepKeys[] = {
     {"scan_mfma_unroll", &bitnuc_rt::SweepKnobs::scan_mfma_unroll, 0, 0, 1ull << 2 | 1ull << 3 | 1ull << 4, {0, 0, 0}},
     {"scan_mfma_shift", &bitnuc_rt::SweepKnobs::scan_mfma_shift, 0, 6, 0, {0, 0, 0}},
     {"scan_mfma_count_form", &bitnuc_rt::SweepKnobs::scan_mfma_count_form, 0, 2, 0, {0, 0, 0}},
+    {"scan_mfma_block", &bitnuc_rt::SweepKnobs::scan_mfma_block, 0, 0, 0, {64, 128, 256}},
     {"scan_mfma_ch3", &bitnuc_rt::SweepKnobs::scan_mfma_ch3, 0, 1, 0, {0, 0, 0}},
     {"scan_mfma_match", &bitnuc_rt::SweepKnobs::scan_mfma_match, 0, 1, 0, {0, 0, 0}},
     {"scan_mfma_count_emit", &bitnuc_rt::SweepKnobs::scan_mfma_count_emit, 0, 2, 0, {0, 0, 0}},

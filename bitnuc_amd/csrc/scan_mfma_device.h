@@ -120,8 +120,8 @@ struct CountMfmaTable { uint32_t w[40][16]; float c[4]; }; // c[r & 3]: where re
 // consecutive distance bytes, and two v_permlane32_swap (lanes l and l + 32 exchange a register) give lane (n, 0) the dwords (q0, partner's q0, q1, partner's q1) =
 // bytes 32 n .. 32 n + 15 and lane (n, 1) (partner's q2, q2, partner's q3, q3) = bytes 32 n + 16 .. 32 n + 31: one natural dwordx4 store per lane at 16 (2 n + h).
 // One trip of U rounds per wave; the hardware dispatcher walks the trips (how every streaming kernel of this library runs fastest).
-template <int POLICY, int U>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+template <int POLICY, int U, int BLOCK = kBlock>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, uint8_t *__restrict__ dist,
                           unsigned long long *__restrict__ slot, const CountMfmaTable tab) {
     constexpr bool NTLD = (POLICY & 1) != 0, NTST = (POLICY & 2) != 0;
@@ -129,7 +129,7 @@ kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n,
     // serves 8 consecutive lanes at a time = 4 even groups (64 B of region 0) + 4 odd ones (64 B of region 1), which must not share a bank
     constexpr int kRegion = (32 * U + 1) * 16 + 48;
     static_assert(kRegion % 128 == 64, "the two parities of one store must land 16 banks apart");
-    __shared__ __attribute__((aligned(16))) uint8_t strips[kBlock / 64][4 * kRegion];
+    __shared__ __attribute__((aligned(16))) uint8_t strips[BLOCK / 64][4 * kRegion];
     const unsigned long long nwin = n - k + 1;
     const unsigned long long rounds = n >= 1056 ? (n - 32) >> 10 : 0;
     const unsigned lane = threadIdx.x & 63;

@@ -140,7 +140,7 @@ def test_product_library_holds_no_evidence_kernels():
     assert "encode_kernel" in product and "kmer_scan2_kernel" in product
     # the matrix-core scan ships in exactly one instantiation (distance bytes: one trip per wave) and the fused count in one (three channels per base, a
     # resident grid); their other operand / pack / trip / tiling / channel forms are evidence
-    assert set(re.findall(r"kmer_scan_seg_mfma_kernel<([^>]*)>", product)) == {"3, 4"} and "kmer_scan_mfma_kernel<" not in product
+    assert set(re.findall(r"kmer_scan_seg_mfma_kernel<([^>]*)>", product)) == {"3, 4, 64"} and "kmer_scan_mfma_kernel<" not in product
     assert set(re.findall(r"kmer_count3_mfma_kernel<([^>]*)>", product)) == {"4, true"} and "kmer_count_mfma_kernel<" not in product
     leaked = [n for n in names if n + "<" in product or n + "(" in product]
     assert not leaked, leaked

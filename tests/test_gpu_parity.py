@@ -157,7 +157,7 @@ def test_product_ships_only_the_variants_in_use(ctx, oracle):
     # the other formulations that lost their A/B are evidence too: the product holds one form of each kernel
     for key, shipped, others in (("plan_tiles", 1, (2, 4)), ("plan_enc_tiles", 1, (2, 4)), ("plan_store", 2, (0, 1)), ("fixed_dec_strip", 2, (0, 1)),
                                  ("slide_rounds", 1, (2, 4, 8)), ("slide2_rounds", 4, (1, 2)), ("slide_impl", 1, (0,)), ("batch_tables_impl", 1, (0,)), ("scan_impl", 8, (0, 1, 2, 6, 7)), ("scan_unroll", 4, (1, 2)), ("scan_policy", 3, (0, 1, 2)),
-                                 ("scan_mfma_shift", 4, (0, 1, 2, 3, 5)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2, 3)), ("scan_mfma_persist", 0, (1,)), ("scan_mfma_count_persist", 1, (0,)), ("scan_mfma_ch3", 0, (1,)), ("scan_mfma_match", 0, (1,)), ("scan_mfma_count_form", 2, (0, 1)), ("scan_mfma_count_emit", 2, (0, 1)), ("scan_mfma_count_rounds", 4, (2, 3)), ("scan_mfma_count_grid", 12, (4, 18)),
+                                 ("scan_mfma_shift", 4, (0, 1, 2, 3, 5)), ("scan_mfma_pack", 1, (0, 2)), ("scan_mfma_unroll", 4, (2, 3)), ("scan_mfma_persist", 0, (1,)), ("scan_mfma_count_persist", 1, (0,)), ("scan_mfma_block", 64, (128, 256)), ("scan_mfma_ch3", 0, (1,)), ("scan_mfma_match", 0, (1,)), ("scan_mfma_count_form", 2, (0, 1)), ("scan_mfma_count_emit", 2, (0, 1)), ("scan_mfma_count_rounds", 4, (2, 3)), ("scan_mfma_count_grid", 12, (4, 18)),
                                  ("dense_unroll", 1, (2, 4)), ("dense_policy", 3, (0, 1, 2)), ("batch_abl", 0, (1,)),
                                  ("batch_dense", 1, (0,)), ("batch_slide", 1, (0,)), ("batch_host_plan", 1, (0,)), ("fixed_stream", 1, (0,)), ("owner_est", 3, (0, 1, 2)),
                                  ("plan_enc_block", 256, (64, 128)), ("kmer_block", 256, (64, 128)), ("hdist_tiled", 0, (1,)), ("hdist_words_impl", 1, (0,)),
@@ -492,19 +492,19 @@ def test_kmer_batch_errors(ctx, oracle):
 
 
 # Forms of the config-5 scan.  "ships" runs on the PRODUCT library: the one-hot contraction on the matrix cores in the fused count's tiling (scan_impl 8: segments
-# of 32 windows x 32 shifts, four MFMAs per 1024 windows, two v_permlane32_swap put the packed results in store order, one trip of 4 rounds per wave).  The others
-# live in the evidence build: its trips of 2 / 3 rounds; the same tiling with three channels per base (scan_mfma_ch3: three MFMAs, 1.5 % slower); the natural-layout tiling that shipped first (scan_impl 7: six MFMAs, results already in store order) with
+# of 32 windows x 32 shifts, four MFMAs per 1024 windows, two v_permlane32_swap put the packed results in store order, one trip of 4 rounds per wave, workgroups of one wave).  The others
+# live in the evidence build: its trips of 2 / 3 rounds and workgroups of 2 / 4 waves; the same tiling with three channels per base (scan_mfma_ch3: three MFMAs, 1.5 % slower); the natural-layout tiling that shipped first (scan_impl 7: six MFMAs, results already in store order) with
 # its operand / pack / trip / grid forms (shift: 0 global re-loads, 1 bytes through the strip, 2 DPP, 3 all six operands through the strip, 4 the lane's own kept in
 # registers, 5 the software-pipelined trip, 6 less bookkeeping; pack: 0 v_cvt_pk_u8, 2 bias by a seventh instruction; match: the table marks the equal channel and counts down from k)
 # and rounds 1-4's bit-plane forms (scan_impl, scan_unroll): 1 = line-aligned rounds of 1024 windows (GEN 1 at unroll 4: shipped in round 4), 6 = rounds 2-3's plane
 # build, 0 = rounds of 992 windows, 2 / 3 / 4 = kmer_scan3_kernel with 12 / 20 / 16 rounds per wave.
 SCAN_FORMS = [("ships", {})] + \
-    [(f"seg-U{u}", dict(scan_impl=8, scan_mfma_unroll=u)) for u in (3, 2)] + [(f"seg-three-channels-U{u}", dict(scan_impl=8, scan_mfma_unroll=u, scan_mfma_ch3=1)) for u in (4, 3, 2)] + \
+    [(f"seg-U{u}", dict(scan_impl=8, scan_mfma_unroll=u)) for u in (3, 2)] + [(f"seg-workgroups-of-{b}", dict(scan_impl=8, scan_mfma_block=b)) for b in (128, 256)] + [(f"seg-three-channels-U{u}", dict(scan_impl=8, scan_mfma_unroll=u, scan_mfma_ch3=1)) for u in (4, 3, 2)] + \
     [(f"mfma-shift{sh}-pack{pk}-U{u}-persist{ps}" + ("-match" if mt else ""), dict(scan_impl=7, scan_mfma_shift=sh, scan_mfma_pack=pk, scan_mfma_unroll=u, scan_mfma_persist=ps, scan_mfma_match=mt))
      for sh, pk, u, ps, mt in ((4, 1, 4, 0, 0), (4, 1, 4, 1, 0), (4, 0, 2, 0, 0), (4, 2, 4, 0, 0), (4, 1, 3, 0, 0), (5, 0, 4, 0, 0), (5, 1, 2, 1, 0), (3, 1, 4, 0, 0), (3, 0, 2, 1, 0), (1, 1, 4, 0, 0), (1, 2, 2, 1, 0), (2, 1, 4, 0, 0), (2, 0, 2, 1, 0),
                                (0, 1, 2, 1, 0), (0, 0, 2, 0, 0), (6, 1, 4, 0, 0), (4, 1, 4, 0, 1), (6, 1, 2, 1, 1))] + \
     [(f"bitplane-impl{i}-unroll{u}", dict(scan_impl=i, scan_unroll=u)) for i, u in ((1, 4), (1, 2), (1, 1), (6, 4), (0, 4), (0, 2), (0, 1), (2, 4), (3, 4), (4, 4))]
-SCAN_DEFAULTS = dict(scan_impl=8, scan_mfma_ch3=0, scan_mfma_match=0, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1, scan_mfma_count_form=2, scan_mfma_count_emit=2, scan_mfma_count_rounds=4, scan_mfma_count_grid=12)
+SCAN_DEFAULTS = dict(scan_impl=8, scan_mfma_block=64, scan_mfma_ch3=0, scan_mfma_match=0, scan_unroll=4, scan_mfma_shift=4, scan_mfma_pack=1, scan_mfma_unroll=4, scan_mfma_persist=0, scan_mfma_count_persist=1, scan_mfma_count_form=2, scan_mfma_count_emit=2, scan_mfma_count_rounds=4, scan_mfma_count_grid=12)
 
 
 @pytest.mark.parametrize("form", SCAN_FORMS, ids=[name for name, _ in SCAN_FORMS])

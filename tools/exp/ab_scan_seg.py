@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The matrix-core scan (distance bytes): the shipped natural-layout tiling (scan_impl 7: six MFMAs per 1024 windows, half of each multiplying zeros, results
 already in store order) against the count's tiling (scan_impl 8: segments of 32 windows x 32 shifts, four MFMAs, two v_permlane32_swap put the results in
-store order), trips of 4 / 3 rounds, and the count's tiling with three channels per base (scan_mfma_ch3 1: three MFMAs).  Why: profiles/r05_ablate_count_parts.txt -- the matrix pipe's power is what lowers the clock in a queue from idle.
+store order), workgroups of 64 (ships) / 128 / 256 threads, trips of 4 / 3 rounds, and the count's tiling with three channels per base (scan_mfma_ch3 1: three MFMAs).  Why: profiles/r05_ablate_count_parts.txt -- the matrix pipe's power is what lowers the clock in a queue from idle.
 Bursts of 8 and a 96-launch queue from an idle chip in groups of 8, interleaved three times; outputs compared; invalid bytes planted at round / trip
 boundaries must be reported by every form."""
 import os
@@ -24,11 +24,11 @@ ref = torch.empty(n, dtype=torch.uint8, device=dev)
 ctx.nucgen_dev(ref, n, 0xB17C0DE)
 outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
 ctx.sync()
-FORMS = [(8, 4, 0), (8, 4, 1), (8, 3, 1), (7, 4, 0)]  # (scan_impl, rounds per trip, 1 = three channels per base: kmer_scan_seg3_mfma_kernel)
+FORMS = [(8, 4, 0, 64), (8, 4, 0, 128), (8, 4, 0, 256), (8, 3, 0, 256), (8, 4, 1, 256), (7, 4, 0, 256)]  # (scan_impl, rounds per trip, 1 = three channels per base, threads per workgroup)  # (scan_impl, rounds per trip, 1 = three channels per base: kmer_scan_seg3_mfma_kernel)
 
 
 def chan(f):
-    return "three channels" if f[2] else "four channels "
+    return ("three channels" if f[2] else "four channels ") + (f", workgroups of {f[3]} threads" if len(f) > 3 else "")
 
 
 def use(f):
@@ -37,6 +37,7 @@ def use(f):
     ctx.require_variant("scan_impl", f[0])
     ctx.require_variant("scan_mfma_unroll", f[1])
     ctx.require_variant("scan_mfma_ch3", f[2])
+    ctx.require_variant("scan_mfma_block", f[3] if len(f) > 3 else 256)
 
 
 base = None
