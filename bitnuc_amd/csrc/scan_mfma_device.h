@@ -15,7 +15,7 @@
 //
 // WHAT SHIPS (this file; the product library instantiates exactly these two -- the tilings, operand, pack and threshold forms that lost their A/B are in
 // evidence/scan_mfma_evidence.h, compiled into the evidence build only: profiles/r05_ab_*.txt):
-//   kmer_scan_seg_mfma_kernel<POLICY 3, U 4>   the distance bytes: a column is a SEGMENT of 32 consecutive windows, a row one of its 32 shifts (four MFMAs per 1024
+//   kmer_scan_seg_mfma_kernel<POLICY 3, U 4, BLOCK 64>  the distance bytes (workgroups of one wave): a column is a SEGMENT of 32 consecutive windows, a row one of its 32 shifts (four MFMAs per 1024
 //                                              windows), two v_permlane32_swap put the packed results in store order, one trip of four rounds per wave
 //   kmer_count3_mfma_kernel<U 4, nt loads>     the fused count of d <= tau: the same segments with THREE channels per base (three MFMAs per 1024 windows), the
 //                                              threshold inside the product, a bounded grid with a ticketed reduction
@@ -119,7 +119,8 @@ struct CountMfmaTable { uint32_t w[40][16]; float c[4]; }; // c[r & 3]: where re
 // The distance bytes.  Lane (n, h) ends up holding windows 32 n + 8 q + 4 h + i (q = r >> 2, i = r & 3), i.e. after the 2^23-bias pack one dword per q with four
 // consecutive distance bytes, and two v_permlane32_swap (lanes l and l + 32 exchange a register) give lane (n, 0) the dwords (q0, partner's q0, q1, partner's q1) =
 // bytes 32 n .. 32 n + 15 and lane (n, 1) (partner's q2, q2, partner's q3, q3) = bytes 32 n + 16 .. 32 n + 31: one natural dwordx4 store per lane at 16 (2 n + h).
-// One trip of U rounds per wave; the hardware dispatcher walks the trips (how every streaming kernel of this library runs fastest).
+// One trip of U rounds per wave; the hardware dispatcher walks the trips (how every streaming kernel of this library runs fastest).  BLOCK: threads per workgroup --
+// nothing is shared inside one (the strips are wave-private), and with one wave per workgroup 19 waves fit a CU's LDS instead of 16 (profiles/r05_ab_scan_block.txt).
 template <int POLICY, int U, int BLOCK = kBlock>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 kmer_scan_seg_mfma_kernel(const uint8_t *__restrict__ ref, unsigned long long n, unsigned k, unsigned long long query, uint8_t *__restrict__ dist,
